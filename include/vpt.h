@@ -1,0 +1,157 @@
+/*
+ * vpt.h — C-ABI of the MI355X-native renderer path (libvpt_hip.so).
+ *
+ * Drop-in boundary for the per-pixel generate / integrate / render / reset passes of the
+ * MIP, EAM, MCS and MCM renderers of MOj0/vpt.  Every entry point cites the reference
+ * interface (file:line under the reference tree) it replaces.  Plain pointers and sizes
+ * only; no C++ or torch types.  All functions return VPT_OK (0) or a negative error code;
+ * vpt_last_error() gives the message (the reference only throws Error(msg):
+ * WebGL.js:14,28,180; Volume.js:40,103 — bindings convert non-zero into a thrown Error).
+ *
+ * Threading: like the reference (single JS thread, Ticker.js:5-8) a context is not
+ * thread-safe.  Calls enqueue work on the context's HIP stream and return; only
+ * vpt_context_synchronize, vpt_renderer_read* and vpt_renderer_sample_count block.
+ *
+ * Image convention: row 0 is the BOTTOM row (GL framebuffer origin), pixels are x-fastest.
+ */
+#ifndef VPT_H
+#define VPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPT_API __attribute__((visibility("default")))
+
+#define VPT_OK               0
+#define VPT_ERR_INVALID     -1   /* bad argument / bad state */
+#define VPT_ERR_HIP         -2   /* HIP runtime error */
+#define VPT_ERR_NO_VOLUME   -3   /* renderer has no (ready) volume: Volume.getTexture() == null, Volume.js:107-113 */
+#define VPT_ERR_UNSUPPORTED -4
+
+/* RendererFactory.js:10-23 ('mip' | 'eam' | 'mcs' | 'mcm'; the other names are out of scope) */
+#define VPT_RENDERER_MIP 0
+#define VPT_RENDERER_EAM 1
+#define VPT_RENDERER_MCS 2
+#define VPT_RENDERER_MCM 3
+
+/* Volume.js:115-125 setFilter('linear' | 'nearest') */
+#define VPT_FILTER_NEAREST 0
+#define VPT_FILTER_LINEAR  1
+
+/* Volume formats (RAWReader.js:36-38: format RED, internalFormat R8, type UNSIGNED_BYTE) */
+#define VPT_FORMAT_R8 0
+
+/* Buffers readable through vpt_renderer_read (SingleBuffer.js / DoubleBuffer.js attachments) */
+#define VPT_BUFFER_RENDER 0      /* RGBA16F, 8 B/pixel  (AbstractRenderer.js:142-155, getTexture() :114-116) */
+#define VPT_BUFFER_FRAME  1      /* MIP R8 | EAM RGBA8 | MCS RGBA32F  (_getFrameBufferSpec) */
+#define VPT_BUFFER_ACCUM  2      /* MIP R8 | EAM RGBA8 | MCS RGBA32F  (_getAccumulationBufferSpec, read side) */
+#define VPT_BUFFER_MCM_POSITION      3   /* RGBA32F [pos.xyz, 0]            (MCMRenderer.js:214-263) */
+#define VPT_BUFFER_MCM_DIRECTION     4   /* RGBA32F [dir.xyz, bounces]      */
+#define VPT_BUFFER_MCM_TRANSMITTANCE 5   /* RGBA32F [transmittance.rgb, 0]  */
+#define VPT_BUFFER_MCM_RADIANCE      6   /* RGBA32F [radiance.rgb, samples] */
+
+typedef struct vpt_context  vpt_context;
+typedef struct vpt_volume   vpt_volume;
+typedef struct vpt_renderer vpt_renderer;
+
+/*
+ * The uniforms the reference uploads before each draw (gl.uniform* calls in
+ * MIPRenderer.js:82-97, EAMRenderer.js:99-116, MCSRenderer.js:88-117, MCMRenderer.js:91-106,155-175).
+ * Values the reference draws with Math.random() (uOffset, uRandSeed, the MCS light direction)
+ * are explicit inputs so a run is reproducible ("fixed-seed mode").
+ * uInverseResolution is derived by the library from the renderer's size (fl32(1/W), fl32(1/H)).
+ */
+typedef struct vpt_uniforms {
+    float    mvp_inverse[16];   /* uMvpInverseMatrix, column-major (gl-matrix layout) */
+    float    rand_seed;         /* uRandSeed */
+    float    offset;            /* uOffset            (MIP, EAM) */
+    float    step_size;         /* uStepSize = 1/steps (MIP) or 1/slices (EAM) */
+    float    extinction;        /* uExtinction        (EAM, MCS, MCM) */
+    float    anisotropy;        /* uAnisotropy        (MCM) */
+    uint32_t max_bounces;       /* uMaxBounces        (MCM) */
+    uint32_t steps;             /* uSteps             (MCM) */
+    float    light_direction[3];/* uScatteringDirection (MCS) */
+    float    mix;               /* uMix (EAM: 1/frameNumber) | uInvFrameNumber (MCS) */
+    float    blur;              /* uBlur              (MCM, always 0 in the reference: MCMRenderer.js:93,157) */
+} vpt_uniforms;
+
+/* ---- context: replaces the WebGL2RenderingContext the reference passes as `gl` (RenderingContext.js:66-106) */
+VPT_API int vpt_device_count(int *count);
+VPT_API int vpt_context_create(int device_ordinal, vpt_context **out);
+VPT_API int vpt_context_destroy(vpt_context *ctx);
+VPT_API int vpt_context_synchronize(vpt_context *ctx);
+VPT_API const char *vpt_last_error(void);
+VPT_API const char *vpt_version(void);
+
+/* ---- volume: Volume.js:31-78 (texStorage3D + texSubImage3D per placement), :115-125 (setFilter), :17-22 (destroy) */
+VPT_API int vpt_volume_create(vpt_context *ctx, int width, int height, int depth, int format, vpt_volume **out);
+VPT_API int vpt_volume_upload_block(vpt_volume *vol, int x, int y, int z, int width, int height, int depth,
+                                    const void *host_data, size_t nbytes);
+/* same, source already resident in HBM on this context's device (skips PCIe) */
+VPT_API int vpt_volume_upload_block_device(vpt_volume *vol, int x, int y, int z, int width, int height, int depth,
+                                           const void *device_data, size_t nbytes);
+/* builds the bricked Z-order layout from the uploaded blocks; called implicitly by the first pass that needs it */
+VPT_API int vpt_volume_finalize(vpt_volume *vol);
+VPT_API int vpt_volume_set_filter(vpt_volume *vol, int filter);
+VPT_API int vpt_volume_destroy(vpt_volume *vol);
+/* bytes of the bricked layout in HBM (for reporting) */
+VPT_API int vpt_volume_bricked_bytes(vpt_volume *vol, uint64_t *nbytes);
+
+/* ---- renderer: AbstractRenderer.js:17-116 and the four subclasses */
+/* new R(gl, volume, camera, environmentTexture, {resolution}) — AbstractRenderer.js:17-49; width != height is the
+ * documented extension (uInverseResolution = (1/W, 1/H)).  Buffers are allocated as in _rebuildBuffers :78-92. */
+VPT_API int vpt_renderer_create(vpt_context *ctx, int kind, int width, int height, vpt_renderer **out);
+/* image-plane sharding (no reference counterpart): this renderer owns the row blocks b with b % world == rank,
+ * rows_per_block rows each; all buffers then hold only the owned rows (vpt_renderer_local_rows). */
+VPT_API int vpt_renderer_set_shard(vpt_renderer *r, int rank, int world, int rows_per_block);
+VPT_API int vpt_renderer_local_rows(vpt_renderer *r, int *rows);
+/* global row index of local row l (identity when unsharded); -1 for padding rows */
+VPT_API int vpt_renderer_global_row(vpt_renderer *r, int local_row, int *global_row);
+VPT_API int vpt_renderer_destroy(vpt_renderer *r);                                   /* destroy() :51-58 */
+VPT_API int vpt_renderer_set_volume(vpt_renderer *r, vpt_volume *vol);               /* setVolume() :94-97 (caller resets) */
+VPT_API int vpt_renderer_set_transfer_function(vpt_renderer *r, const uint8_t *rgba, int width, int height); /* :99-104 */
+VPT_API int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba, int width, int height);       /* RenderingContext.js:90-101,136-141 */
+VPT_API int vpt_renderer_resize(vpt_renderer *r, int width, int height);             /* setResolution() :106-112 (caller resets) */
+
+/* the four hooks; integrate and reset include the DoubleBuffer swap (AbstractRenderer.js:60-76) */
+VPT_API int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u);              /* reset(): _resetFrame + swap */
+VPT_API int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u);           /* _generateFrame */
+VPT_API int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u);          /* _integrateFrame + swap */
+VPT_API int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u);       /* _renderFrame */
+/* render(): generate -> integrate -> swap -> renderFrame in ONE launch (same results as the three hooks) */
+VPT_API int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u);
+
+/* read-back (the reference never reads back; it hands getTexture() to the tone mapper). Row-major, local rows. */
+VPT_API int vpt_renderer_read(vpt_renderer *r, int buffer, void *host_dst, size_t nbytes);
+/* device pointer of the row-major RGBA16F render buffer (for the RCCL frame gather) */
+VPT_API int vpt_renderer_render_buffer_device(vpt_renderer *r, void **device_ptr, size_t *nbytes);
+/* volume samples executed since creation / last clear (SURVEY §8d metric) */
+VPT_API int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count);
+VPT_API int vpt_renderer_clear_sample_count(vpt_renderer *r);
+
+/* per-launch HIP-event timing of the dominant kernel (generate for MIP/EAM/MCS, integrate for MCM) on the
+ * context's stream; enable, run, then query: sum of durations in ms and number of timed launches. */
+VPT_API int vpt_renderer_set_profiling(vpt_renderer *r, int enabled);
+VPT_API int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t *launches);
+
+/* ---- test probes: evaluate device-side building blocks on the GPU (tests/ compares with the oracle) */
+#define VPT_PROBE_LOG     0   /* out[i] = log(in[i]) */
+#define VPT_PROBE_SIN     1
+#define VPT_PROBE_COS     2
+#define VPT_PROBE_ASIN    3
+#define VPT_PROBE_ATAN2   4   /* in = pairs (y, x) ; n outputs */
+#define VPT_PROBE_PCG     5   /* bit patterns: out[i] = pcg(in[i]) */
+#define VPT_PROBE_UNIFORM 6   /* bit pattern state in -> float uniform out */
+#define VPT_PROBE_F16     7   /* out[i] (low 16 bits) = half(in[i]) */
+VPT_API int vpt_probe_math(vpt_context *ctx, int which, const float *in, float *out, size_t n);
+/* samples texture(uVolume, p) -> transfer function at n positions (xyz triples); out = n RGBA float4 */
+VPT_API int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPT_H */

@@ -1,0 +1,185 @@
+"""ctypes binding of the CPU oracle (oracle/vpt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under vpt_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvpt_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "vpt_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libvpt_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("volume", C.c_void_p), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+        ("filter", C.c_int32),
+        ("tf_rgba", C.c_void_p), ("tf_w", C.c_int32), ("tf_h", C.c_int32),
+        ("env_rgba", C.c_void_p), ("env_w", C.c_int32), ("env_h", C.c_int32),
+    ]
+
+
+class Frame(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("y0", C.c_int32), ("y1", C.c_int32),
+        ("mvp_inv", C.c_float * 16),
+        ("seed", C.c_float), ("offset", C.c_float), ("step", C.c_float),
+        ("extinction", C.c_float), ("anisotropy", C.c_float),
+        ("max_bounces", C.c_uint32), ("steps", C.c_uint32),
+        ("light_dir", C.c_float * 3),
+        ("mix", C.c_float), ("blur", C.c_float), ("inv_res", C.c_float * 2),
+        ("nthreads", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.vpo_logf.restype = C.c_float; L.vpo_logf.argtypes = [C.c_float]
+        L.vpo_sincosf.restype = None; L.vpo_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.vpo_atan2f.restype = C.c_float; L.vpo_atan2f.argtypes = [C.c_float, C.c_float]
+        L.vpo_asinf.restype = C.c_float; L.vpo_asinf.argtypes = [C.c_float]
+        L.vpo_pcg.restype = C.c_uint32; L.vpo_pcg.argtypes = [C.c_uint32]
+        L.vpo_hash3.restype = C.c_uint32; L.vpo_hash3.argtypes = [C.c_uint32] * 3
+        L.vpo_random_uniform.restype = C.c_float; L.vpo_random_uniform.argtypes = [C.POINTER(C.c_uint32)]
+        L.vpo_random_sphere.restype = None; L.vpo_random_sphere.argtypes = [C.POINTER(C.c_uint32), C.c_void_p]
+        L.vpo_f32_to_f16.restype = C.c_uint16; L.vpo_f32_to_f16.argtypes = [C.c_float]
+        L.vpo_srgb_to_linear.restype = C.c_float; L.vpo_srgb_to_linear.argtypes = [C.c_uint8]
+        P = C.c_void_p
+        SP, FP = C.POINTER(Scene), C.POINTER(Frame)
+        for name in ("mip", "eam", "mcs"):
+            g = getattr(L, "vpo_%s_generate" % name); g.restype = C.c_uint64; g.argtypes = [SP, FP, P]
+            f = getattr(L, "vpo_%s_integrate" % name); f.restype = None; f.argtypes = [FP, P, P]
+            f = getattr(L, "vpo_%s_render" % name); f.restype = None; f.argtypes = [FP, P, P]
+            f = getattr(L, "vpo_%s_reset" % name); f.restype = None; f.argtypes = [FP, P]
+        L.vpo_mcm_reset.restype = None; L.vpo_mcm_reset.argtypes = [FP, P, P, P, P]
+        L.vpo_mcm_integrate.restype = C.c_uint64; L.vpo_mcm_integrate.argtypes = [SP, FP, P, P, P, P]
+        L.vpo_mcm_render.restype = None; L.vpo_mcm_render.argtypes = [FP, P, P]
+        L.vpo_sample_volume.restype = C.c_float; L.vpo_sample_volume.argtypes = [SP, C.c_float, C.c_float, C.c_float]
+        L.vpo_sample_volume_color.restype = None; L.vpo_sample_volume_color.argtypes = [SP, C.c_float, C.c_float, C.c_float, P]
+        L.vpo_sample_environment.restype = None; L.vpo_sample_environment.argtypes = [SP, C.c_float, C.c_float, C.c_float, P]
+        L.vpo_unproject.restype = None; L.vpo_unproject.argtypes = [P, C.c_float, C.c_float, P, P]
+        L.vpo_intersect_cube.restype = None; L.vpo_intersect_cube.argtypes = [P, P, P]
+        L.vpo_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+DEFAULT_TF = np.array([[[255, 0, 0, 0], [255, 0, 0, 255]]], dtype=np.uint8)   # AbstractRenderer.js:34
+DEFAULT_ENV = np.array([[[255, 255, 255, 255]]], dtype=np.uint8)              # RenderingContext.js:93
+
+
+class OracleScene:
+    """Holds numpy arrays alive and exposes the ctypes Scene."""
+
+    def __init__(self, volume, filter="linear", tf=None, env=None):
+        volume = np.ascontiguousarray(volume, dtype=np.uint8)
+        assert volume.ndim == 3, "volume is [z][y][x] uint8"
+        self.volume = volume
+        self.tf = np.ascontiguousarray(DEFAULT_TF if tf is None else tf, dtype=np.uint8)
+        self.env = np.ascontiguousarray(DEFAULT_ENV if env is None else env, dtype=np.uint8)
+        assert self.tf.ndim == 3 and self.tf.shape[2] == 4
+        assert self.env.ndim == 3 and self.env.shape[2] == 4
+        s = Scene()
+        s.volume = _ptr(self.volume)
+        s.nz, s.ny, s.nx = volume.shape
+        s.filter = 1 if filter == "linear" else 0
+        s.tf_rgba = _ptr(self.tf); s.tf_h, s.tf_w = self.tf.shape[:2]
+        s.env_rgba = _ptr(self.env); s.env_h, s.env_w = self.env.shape[:2]
+        self.c = s
+
+
+def make_frame(width, height, mvp_inv, *, seed=0.0, offset=0.0, steps=64, extinction=1.0, anisotropy=0.0,
+               max_bounces=8, mcm_steps=8, light_dir=(0.0, 0.0, 1.0), mix=1.0, blur=0.0, y0=0, y1=None,
+               nthreads=1):
+    f = Frame()
+    f.width, f.height = width, height
+    f.y0 = y0; f.y1 = height if y1 is None else y1
+    m = np.asarray(mvp_inv, dtype=np.float32).reshape(16)
+    for i in range(16):
+        f.mvp_inv[i] = float(m[i])
+    f.seed = float(np.float32(seed)); f.offset = float(np.float32(offset))
+    f.step = float(np.float32(1.0 / steps))
+    f.extinction = float(np.float32(extinction)); f.anisotropy = float(np.float32(anisotropy))
+    f.max_bounces = int(max_bounces); f.steps = int(mcm_steps)
+    for i in range(3):
+        f.light_dir[i] = float(np.float32(light_dir[i]))
+    f.mix = float(np.float32(mix)); f.blur = float(np.float32(blur))
+    f.inv_res[0] = float(np.float32(1.0 / width)); f.inv_res[1] = float(np.float32(1.0 / height))
+    f.nthreads = nthreads
+    return f
+
+
+class OracleRenderer:
+    """Drives the oracle passes in AbstractRenderer.render() order (AbstractRenderer.js:60-76)."""
+
+    def __init__(self, kind, scene, width, height):
+        self.kind, self.scene, self.w, self.h = kind, scene, width, height
+        n = width * height
+        if kind == "mip":
+            self.frame = np.zeros(n, np.uint8); self.acc = np.zeros(n, np.uint8)
+        elif kind == "eam":
+            self.frame = np.zeros(4 * n, np.uint8); self.acc = np.zeros(4 * n, np.uint8)
+        elif kind == "mcs":
+            self.frame = np.zeros(4 * n, np.float32); self.acc = np.zeros(4 * n, np.float32)
+        elif kind == "mcm":
+            self.state = [np.zeros(4 * n, np.float32) for _ in range(4)]
+        else:
+            raise ValueError(kind)
+        self.out = np.zeros(4 * n, np.uint16)
+        self.samples = 0
+
+    def reset(self, fr):
+        L = lib()
+        if self.kind == "mcm":
+            L.vpo_mcm_reset(C.byref(fr), *[_ptr(s) for s in self.state])
+        else:
+            getattr(L, "vpo_%s_reset" % self.kind)(C.byref(fr), _ptr(self.acc))
+
+    def generate(self, fr):
+        if self.kind == "mcm":
+            return 0
+        n = getattr(lib(), "vpo_%s_generate" % self.kind)(C.byref(self.scene.c), C.byref(fr), _ptr(self.frame))
+        self.samples += n
+        return n
+
+    def integrate(self, fr):
+        L = lib()
+        if self.kind == "mcm":
+            n = L.vpo_mcm_integrate(C.byref(self.scene.c), C.byref(fr), *[_ptr(s) for s in self.state])
+            self.samples += n
+            return n
+        getattr(L, "vpo_%s_integrate" % self.kind)(C.byref(fr), _ptr(self.acc), _ptr(self.frame))
+        return 0
+
+    def render_frame(self, fr):
+        L = lib()
+        if self.kind == "mcm":
+            L.vpo_mcm_render(C.byref(fr), _ptr(self.state[3]), _ptr(self.out))
+        else:
+            getattr(L, "vpo_%s_render" % self.kind)(C.byref(fr), _ptr(self.acc), _ptr(self.out))
+
+    def render(self, fr):
+        self.generate(fr); self.integrate(fr); self.render_frame(fr)
+
+    def image_f16(self):
+        return self.out.view(np.float16).reshape(self.h, self.w, 4)

@@ -1,0 +1,287 @@
+"""GPU parity: the HIP path (through the C-ABI, via the host mirror) against the CPU oracle on the same
+seeded inputs.  Bar: BIT-EXACT for every buffer (u8, f32 bit patterns, f16 bit patterns) — the kernels and
+the oracle implement the same fp32 operation sequence."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import vpt_amd
+from vpt_amd import _native as N
+from vpt_amd.scene import Transform, Node, default_camera, mvp_inverse_matrix
+from vpt_amd.synthetic import sphere_volume, colour_tf, ramp_tf, GoldenRatioRng
+
+from conftest import orbit_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view({2: np.uint16, 4: np.uint32, 1: np.uint8}[a.dtype.itemsize])
+
+
+def assert_same_bits(got, want, what):
+    g, w = bits(got).reshape(-1), bits(want).reshape(-1)
+    assert g.shape == w.shape, what
+    bad = np.nonzero(g != w)[0]
+    assert bad.size == 0, "%s: %d of %d elements differ, first at %d: got %r want %r" % (
+        what, bad.size, g.size, bad[0], np.asarray(got).reshape(-1)[bad[0]], np.asarray(want).reshape(-1)[bad[0]])
+
+
+# ---------------------------------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------------------------------
+def test_math_probes_bit_exact(gpu_ctx, oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(1)
+    # log on the exact domain of random_uniform: k * 2^-32 (rounded), plus edge values
+    k = rng.integers(1, 2 ** 32, size=200000, dtype=np.uint64)
+    u = (k.astype(np.float32) * np.float32(2.0 ** -32)).astype(np.float32)
+    u = np.concatenate([u, np.array([0.0, 1.0, 2.0 ** -32, 0.5, 0.70710678, 0.70710677, 1e-30, 3.0, np.inf], np.float32)])
+    got = gpu_ctx.probe_math(N.PROBE_LOG, u)
+    want = np.array([L.vpo_logf(float(x)) for x in u], dtype=np.float32)
+    assert_same_bits(got, want, "log")
+    # sin / cos on [0, 2*pi]
+    a = (rng.random(100000, dtype=np.float32) * np.float32(6.28318530718)).astype(np.float32)
+    a = np.concatenate([a, np.array([0.0, 6.28318530718, 1.5707964, 3.1415927, 4.712389], np.float32)])
+    s, c = C.c_float(), C.c_float()
+    ws, wc = np.empty_like(a), np.empty_like(a)
+    for i, x in enumerate(a):
+        L.vpo_sincosf(float(x), C.byref(s), C.byref(c)); ws[i] = s.value; wc[i] = c.value
+    assert_same_bits(gpu_ctx.probe_math(N.PROBE_SIN, a), ws, "sin")
+    assert_same_bits(gpu_ctx.probe_math(N.PROBE_COS, a), wc, "cos")
+    # asin / atan2
+    x = np.concatenate([rng.uniform(-1, 1, 50000).astype(np.float32), np.array([-1, 1, 0, 0.5, -0.5, 1.0000001], np.float32)])
+    want = np.array([L.vpo_asinf(float(v)) for v in x], dtype=np.float32)
+    got = gpu_ctx.probe_math(N.PROBE_ASIN, x)
+    nan = np.isnan(want)
+    assert (np.isnan(got) == nan).all()
+    assert_same_bits(got[~nan], want[~nan], "asin")
+    yx = rng.normal(size=(50000, 2)).astype(np.float32)
+    yx = np.concatenate([yx, np.array([[0, 0], [0, -1], [1, 0], [-1, 0], [0, 1], [-0.0, -1], [3, 3], [-2, 2]], np.float32)])
+    want = np.array([L.vpo_atan2f(float(p[0]), float(p[1])) for p in yx], dtype=np.float32)
+    assert_same_bits(gpu_ctx.probe_math(N.PROBE_ATAN2, yx.reshape(-1)), want, "atan2")
+
+
+def test_rng_and_half_probes(gpu_ctx, oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(2)
+    st = rng.integers(0, 2 ** 32, size=100000, dtype=np.uint64).astype(np.uint32)
+    st[:4] = [0, 1, 0xffffffff, 12345]
+    got = gpu_ctx.probe_math(N.PROBE_PCG, st.view(np.float32)).view(np.uint32)
+    want = np.array([L.vpo_pcg(int(s)) for s in st], dtype=np.uint32)
+    assert (got == want).all()
+    gotu = gpu_ctx.probe_math(N.PROBE_UNIFORM, st.view(np.float32))
+    wantu = np.empty(st.size, np.float32)
+    for i, s in enumerate(st):
+        cs = C.c_uint32(int(s)); wantu[i] = L.vpo_random_uniform(C.byref(cs))
+    assert_same_bits(gotu, wantu, "uniform")
+    f = np.concatenate([rng.normal(size=100000).astype(np.float32) * np.float32(3),
+                        np.array([0, -0.0, 1, 65504, 65519.9, 65520, 1e-8, 6e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 1e6, np.inf, -np.inf], np.float32),
+                        (rng.random(20000, dtype=np.float32) * np.float32(1e-4)).astype(np.float32)])
+    goth = gpu_ctx.probe_math(N.PROBE_F16, f).view(np.uint32).astype(np.uint16)
+    wanth = np.array([L.vpo_f32_to_f16(float(v)) for v in f], dtype=np.uint16)
+    assert (goth == wanth).all()
+    assert (goth == f.astype(np.float16).view(np.uint16)).all()
+
+
+@pytest.mark.parametrize("dims", [(32, 32, 32), (17, 23, 9), (4, 4, 4), (1, 1, 1), (5, 64, 3)])
+@pytest.mark.parametrize("filt", ["linear", "nearest"])
+def test_volume_sampler_and_transfer_function(gpu_ctx, oracle, dims, filt):
+    """texture(uVolume,p) -> texture(uTransferFunction,(r,0)): bricked Z-order + LDS TF vs linear volume + 2D bilinear"""
+    rng = np.random.default_rng(3)
+    vol = rng.integers(0, 256, size=dims, dtype=np.uint8)
+    tf = colour_tf(37, 5)
+    sc = oracle.OracleScene(vol, filt, tf=tf)
+    v = vpt_amd.Volume.from_array(gpu_ctx, vol, filt)
+    r = vpt_amd.MIPRenderer(gpu_ctx, v, default_camera(), None, {'resolution': 16})
+    r.setTransferFunction(tf)
+    p = rng.uniform(-0.3, 1.3, size=(20000, 3)).astype(np.float32)
+    nx, ny, nz = dims[2], dims[1], dims[0]
+    edge = np.array([[0, 0, 0], [1, 1, 1], [0.5 / nx, 0.5 / ny, 0.5 / nz], [1 - 0.5 / nx, 1 - 0.5 / ny, 1 - 0.5 / nz],
+                     [np.inf, 0.5, 0.5], [-np.inf, 0.5, 0.5], [np.nan, 0.5, 0.5], [0.5, np.nan, -np.inf], [1e30, -1e30, 0.25]], np.float32)
+    centres = np.stack([(rng.integers(0, nx, 500) + 0.5) / nx, (rng.integers(0, ny, 500) + 0.5) / ny,
+                        (rng.integers(0, nz, 500) + 0.5) / nz], axis=1).astype(np.float32)
+    p = np.concatenate([p, edge, centres])
+    got = r.probe_sample(p)
+    want = np.empty_like(got)
+    L = oracle.lib()
+    buf = np.empty(4, np.float32)
+    for i in range(p.shape[0]):
+        L.vpo_sample_volume_color(C.byref(sc.c), float(p[i, 0]), float(p[i, 1]), float(p[i, 2]), buf.ctypes.data_as(C.c_void_p))
+        want[i] = buf
+    assert_same_bits(got, want, "sampleVolumeColor %s %s" % (dims, filt))
+    r.destroy(); v.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# renderer passes
+# ---------------------------------------------------------------------------------------------------
+class Scene:
+    def __init__(self, gpu_ctx, oracle, n, w, h, filt="linear", tf=None, env=None, camera=None, noise=40.0, dims=None):
+        self.vol = sphere_volume(n, noise=noise, dims=dims)
+        self.w, self.h = w, h
+        self.tf, self.env = tf, env
+        self.osc = oracle.OracleScene(self.vol, filt, tf=tf, env=env)
+        self.gvol = vpt_amd.Volume.from_array(gpu_ctx, self.vol, filt)
+        self.camera = camera if camera is not None else default_camera(w / h)
+        self.transform = Transform(Node())
+        self.m = mvp_inverse_matrix(self.camera, self.transform)
+        self.ctx = gpu_ctx
+
+    def renderer(self, kind, **opts):
+        o = {'resolution': (self.w, self.h), 'transform': self.transform, 'rng': GoldenRatioRng()}
+        o.update(opts)
+        r = vpt_amd.RendererFactory(kind)(self.ctx, self.gvol, self.camera, self.env, o)
+        if self.tf is not None:
+            r.setTransferFunction(self.tf)
+        return r
+
+
+def to_frame(oracle, sc, u, **kw):
+    """oracle Frame from the uniforms the host mirror actually sent"""
+    fr = oracle.make_frame(sc.w, sc.h, np.array(list(u.mvp_inverse), np.float32), **kw)
+    fr.seed = u.rand_seed; fr.offset = u.offset; fr.step = u.step_size
+    fr.extinction = u.extinction; fr.anisotropy = u.anisotropy
+    fr.max_bounces = u.max_bounces; fr.steps = u.steps
+    for i in range(3):
+        fr.light_dir[i] = u.light_direction[i]
+    fr.mix = u.mix; fr.blur = u.blur
+    return fr
+
+
+@pytest.mark.parametrize("filt", ["linear", "nearest"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_mip_parity(gpu_ctx, oracle, filt, fused):
+    sc = Scene(gpu_ctx, oracle, 64, 256, 256, filt, camera=orbit_camera(1.0))
+    r = sc.renderer('mip', fused=fused)
+    r.steps = 48                                   # non power of two: fp32 accumulation of 1/steps decides the trip count
+    o = oracle.OracleRenderer('mip', sc.osc, sc.w, sc.h)
+    r.reset(); o.reset(oracle.make_frame(sc.w, sc.h, sc.m))
+    for k in range(3):
+        r.render()
+        fr = to_frame(oracle, sc, r._u)
+        o.render(fr)
+        assert_same_bits(r.read(N.BUFFER_ACCUM), o.acc.reshape(sc.h, sc.w), "MIP accumulation frame %d" % k)
+        if not fused:
+            assert_same_bits(r.read(N.BUFFER_FRAME), o.frame.reshape(sc.h, sc.w), "MIP frame %d" % k)
+        assert_same_bits(r.getTexture(), o.image_f16(), "MIP render frame %d" % k)
+    assert r.sample_count() == o.samples
+    assert o.acc.max() > 0 and o.acc.min() == 0
+    r.destroy(); sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_eam_parity(gpu_ctx, oracle, fused):
+    sc = Scene(gpu_ctx, oracle, 48, 200, 120, tf=colour_tf(64, 1), camera=orbit_camera(200 / 120))
+    r = sc.renderer('eam', fused=fused)
+    r.slices = 40; r.extinction = 60
+    o = oracle.OracleRenderer('eam', sc.osc, sc.w, sc.h)
+    r.reset(); o.reset(oracle.make_frame(sc.w, sc.h, sc.m))
+    for k in range(4):
+        r.render()
+        fr = to_frame(oracle, sc, r._u)
+        o.render(fr)
+        assert_same_bits(r.read(N.BUFFER_ACCUM), o.acc.reshape(sc.h, sc.w, 4), "EAM accumulation frame %d" % k)
+        if not fused:
+            assert_same_bits(r.read(N.BUFFER_FRAME), o.frame.reshape(sc.h, sc.w, 4), "EAM frame %d" % k)
+        assert_same_bits(r.getTexture(), o.image_f16(), "EAM render frame %d" % k)
+    assert r.sample_count() == o.samples
+    r.destroy(); sc.gvol.destroy()
+
+
+def env_map(w, h, seed=5):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("fused,env", [(False, None), (True, None), (True, (16, 8))])
+def test_mcs_parity(gpu_ctx, oracle, fused, env):
+    e = env_map(*env) if env else None
+    sc = Scene(gpu_ctx, oracle, 40, 160, 96, tf=colour_tf(256, 1), env=e, camera=orbit_camera(160 / 96))
+    r = sc.renderer('mcs', fused=fused)
+    r.extinction = 12
+    o = oracle.OracleRenderer('mcs', sc.osc, sc.w, sc.h)
+    r.reset(); o.reset(oracle.make_frame(sc.w, sc.h, sc.m))
+    for k in range(4):
+        r.render()
+        fr = to_frame(oracle, sc, r._u)
+        o.render(fr)
+        assert_same_bits(r.read(N.BUFFER_ACCUM), o.acc.reshape(sc.h, sc.w, 4), "MCS accumulation frame %d" % k)
+        if not fused:
+            assert_same_bits(r.read(N.BUFFER_FRAME), o.frame.reshape(sc.h, sc.w, 4), "MCS frame %d" % k)
+        assert_same_bits(r.getTexture(), o.image_f16(), "MCS render frame %d" % k)
+    assert r.sample_count() == o.samples
+    r.destroy(); sc.gvol.destroy()
+
+
+MCM_BUFFERS = [N.BUFFER_MCM_POSITION, N.BUFFER_MCM_DIRECTION, N.BUFFER_MCM_TRANSMITTANCE, N.BUFFER_MCM_RADIANCE]
+
+
+@pytest.mark.parametrize("fused,g,env,ext", [(False, 0.0, None, 1.0), (True, 0.0, None, 8.0), (True, 0.6, None, 8.0),
+                                             (True, -0.4, (16, 8), 20.0)])
+def test_mcm_parity(gpu_ctx, oracle, fused, g, env, ext):
+    e = env_map(*env) if env else None
+    sc = Scene(gpu_ctx, oracle, 40, 144, 80, tf=colour_tf(256, 1), env=e, camera=orbit_camera(144 / 80))
+    r = sc.renderer('mcm', fused=fused)
+    r.extinction = ext; r.anisotropy = g; r.bounces = 3; r.steps = 6
+    o = oracle.OracleRenderer('mcm', sc.osc, sc.w, sc.h)
+    r.reset()
+    fr = oracle.make_frame(sc.w, sc.h, sc.m, seed=np.float32(GoldenRatioRng()()))
+    o.reset(fr)
+    for b, s in zip(MCM_BUFFERS, o.state):
+        assert_same_bits(r.read(b), s.reshape(sc.h, sc.w, 4), "MCM reset buffer %d" % b)
+    for k in range(5):
+        r.render()
+        fr = to_frame(oracle, sc, r._u)
+        o.render(fr)
+        for b, s in zip(MCM_BUFFERS, o.state):
+            assert_same_bits(r.read(b), s.reshape(sc.h, sc.w, 4), "MCM state buffer %d pass %d" % (b, k))
+        assert_same_bits(r.getTexture(), o.image_f16(), "MCM render pass %d" % k)
+    assert r.sample_count() == o.samples == sc.w * sc.h * 6 * 5
+    r.destroy(); sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "mcm"])
+@pytest.mark.parametrize("world,rows", [(2, 8), (3, 5), (8, 8)])
+def test_sharded_equals_unsharded(gpu_ctx, oracle, kind, world, rows):
+    """image-plane sharding: every rank's rows, scattered back, equal the single-renderer image bit for bit"""
+    sc = Scene(gpu_ctx, oracle, 32, 100, 70, tf=colour_tf(64, 1), camera=orbit_camera(100 / 70))
+
+    def run(r):
+        if kind in ('mcs', 'mcm'):
+            r.extinction = 9
+        r.reset()
+        for _ in range(3):
+            r.render()
+        return r.getTexture()
+
+    full = sc.renderer(kind)
+    want = run(full)
+    got = np.zeros_like(want)
+    seen = np.zeros(sc.h, dtype=bool)
+    for rank in range(world):
+        r = sc.renderer(kind, shard=(rank, world, rows))
+        img = run(r)
+        rows_g = r.global_rows()
+        assert img.shape[0] == rows_g.size
+        for l, j in enumerate(rows_g):
+            if j >= 0:
+                assert not seen[j]
+                seen[j] = True
+                got[j] = img[l]
+        r.destroy()
+    assert seen.all()
+    assert_same_bits(got, want, "%s sharded %d" % (kind, world))
+    full.destroy(); sc.gvol.destroy()
+
+
+def test_errors_are_loud(gpu_ctx):
+    with pytest.raises(RuntimeError, match="No suitable class"):
+        vpt_amd.RendererFactory('iso')
+    r = vpt_amd.MIPRenderer(gpu_ctx, None, default_camera(), None, {'resolution': 32})
+    r.reset()
+    with pytest.raises(vpt_amd.VptError, match="no ready volume"):
+        r.render()
+    r.destroy()

@@ -1,0 +1,17 @@
+"""vpt_amd — MI355X-native re-host of the MIP / EAM / MCS / MCM renderer path of MOj0/vpt.
+
+Host-side mirror of the reference's Renderer plugin surface over a C-ABI HIP library
+(include/vpt.h -> vpt_amd/libvpt_hip.so).  Importing the package does not load the library;
+constructing a Context does, and raises if it is missing (no CPU fallback)."""
+from .property_bag import PropertyBag, EventTarget, Event, CustomEvent
+from .scene import Node, Transform, PerspectiveCamera, mat4, quat, vec3, default_camera, mvp_inverse_matrix
+from .context import Context
+from .volume import Volume, RAWReader
+from .renderers import (AbstractRenderer, MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer, RendererFactory)
+from ._native import VptError
+
+__all__ = [
+    'PropertyBag', 'EventTarget', 'Event', 'CustomEvent', 'Node', 'Transform', 'PerspectiveCamera',
+    'mat4', 'quat', 'vec3', 'default_camera', 'mvp_inverse_matrix', 'Context', 'Volume', 'RAWReader',
+    'AbstractRenderer', 'MIPRenderer', 'EAMRenderer', 'MCSRenderer', 'MCMRenderer', 'RendererFactory', 'VptError',
+]

@@ -1,0 +1,104 @@
+"""ctypes binding of libvpt_hip.so (C-ABI: include/vpt.h).  There is NO CPU fallback: if the HIP
+library is missing or a call fails, this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvpt_hip.so")
+
+OK = 0
+RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM = 0, 1, 2, 3
+FILTER_NEAREST, FILTER_LINEAR = 0, 1
+FORMAT_R8 = 0
+BUFFER_RENDER, BUFFER_FRAME, BUFFER_ACCUM = 0, 1, 2
+BUFFER_MCM_POSITION, BUFFER_MCM_DIRECTION, BUFFER_MCM_TRANSMITTANCE, BUFFER_MCM_RADIANCE = 3, 4, 5, 6
+PROBE_LOG, PROBE_SIN, PROBE_COS, PROBE_ASIN, PROBE_ATAN2, PROBE_PCG, PROBE_UNIFORM, PROBE_F16 = range(8)
+
+# every symbol include/vpt.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "vpt_device_count", "vpt_context_create", "vpt_context_destroy", "vpt_context_synchronize",
+    "vpt_last_error", "vpt_version",
+    "vpt_volume_create", "vpt_volume_upload_block", "vpt_volume_upload_block_device", "vpt_volume_finalize",
+    "vpt_volume_set_filter", "vpt_volume_destroy", "vpt_volume_bricked_bytes",
+    "vpt_renderer_create", "vpt_renderer_set_shard", "vpt_renderer_local_rows", "vpt_renderer_global_row",
+    "vpt_renderer_destroy", "vpt_renderer_set_volume", "vpt_renderer_set_transfer_function",
+    "vpt_renderer_set_environment", "vpt_renderer_resize",
+    "vpt_renderer_reset", "vpt_renderer_generate", "vpt_renderer_integrate", "vpt_renderer_render_frame",
+    "vpt_renderer_render", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
+    "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
+    "vpt_renderer_set_profiling", "vpt_renderer_profile",
+    "vpt_probe_math", "vpt_probe_sample",
+]
+
+
+class Uniforms(C.Structure):
+    """struct vpt_uniforms (include/vpt.h)"""
+    _fields_ = [
+        ("mvp_inverse", C.c_float * 16),
+        ("rand_seed", C.c_float), ("offset", C.c_float), ("step_size", C.c_float),
+        ("extinction", C.c_float), ("anisotropy", C.c_float),
+        ("max_bounces", C.c_uint32), ("steps", C.c_uint32),
+        ("light_direction", C.c_float * 3),
+        ("mix", C.c_float), ("blur", C.c_float),
+    ]
+
+
+class VptError(RuntimeError):
+    """Non-zero return code of the C-ABI, carrying vpt_last_error() (the reference throws Error(msg))."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libvpt_hip.so not found at %s — build it with `make -C vpt_amd/csrc` (or __graft_entry__.build()). "
+            "vpt_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    P, I, SZ = C.c_void_p, C.c_int, C.c_size_t
+    PP = C.POINTER(C.c_void_p)
+    UP = C.POINTER(Uniforms)
+    sig = {
+        "vpt_device_count": [C.POINTER(I)],
+        "vpt_context_create": [I, PP], "vpt_context_destroy": [P], "vpt_context_synchronize": [P],
+        "vpt_volume_create": [P, I, I, I, I, PP],
+        "vpt_volume_upload_block": [P, I, I, I, I, I, I, P, SZ],
+        "vpt_volume_upload_block_device": [P, I, I, I, I, I, I, P, SZ],
+        "vpt_volume_finalize": [P], "vpt_volume_set_filter": [P, I], "vpt_volume_destroy": [P],
+        "vpt_volume_bricked_bytes": [P, C.POINTER(C.c_uint64)],
+        "vpt_renderer_create": [P, I, I, I, PP],
+        "vpt_renderer_set_shard": [P, I, I, I], "vpt_renderer_local_rows": [P, C.POINTER(I)],
+        "vpt_renderer_global_row": [P, I, C.POINTER(I)],
+        "vpt_renderer_destroy": [P], "vpt_renderer_set_volume": [P, P],
+        "vpt_renderer_set_transfer_function": [P, P, I, I], "vpt_renderer_set_environment": [P, P, I, I],
+        "vpt_renderer_resize": [P, I, I],
+        "vpt_renderer_reset": [P, UP], "vpt_renderer_generate": [P, UP], "vpt_renderer_integrate": [P, UP],
+        "vpt_renderer_render_frame": [P, UP], "vpt_renderer_render": [P, UP],
+        "vpt_renderer_read": [P, I, P, SZ],
+        "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
+        "vpt_renderer_sample_count": [P, C.POINTER(C.c_uint64)], "vpt_renderer_clear_sample_count": [P],
+        "vpt_renderer_set_profiling": [P, I],
+        "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],
+        "vpt_probe_math": [P, I, P, P, SZ], "vpt_probe_sample": [P, P, P, SZ],
+    }
+    for name, argtypes in sig.items():
+        f = getattr(L, name)
+        f.argtypes = argtypes
+        f.restype = I
+    L.vpt_last_error.restype = C.c_char_p; L.vpt_last_error.argtypes = []
+    L.vpt_version.restype = C.c_char_p; L.vpt_version.argtypes = []
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != OK:
+        raise VptError(code, lib().vpt_last_error().decode("utf-8", "replace"))

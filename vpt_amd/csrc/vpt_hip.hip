@@ -1,0 +1,650 @@
+// vpt_hip.hip — C-ABI implementation (include/vpt.h) over the HIP kernels in vpt_kernels.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+//        -fno-gpu-flush-denormals-to-zero -shared -fPIC (see vpt_amd/csrc/Makefile)
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vpt.h"
+#include "vpt_kernels.h"
+#include "vpt_srgb_lut.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail(VPT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define VPT_TRY(expr) do { int r_ = (expr); if (r_ != VPT_OK) return r_; } while (0)
+
+extern "C" const char *vpt_last_error(void) { return g_err; }
+extern "C" const char *vpt_version(void) { return "vpt-mi355x 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------------------------
+struct vpt_context {
+    int device;
+    hipStream_t stream;
+};
+
+struct vpt_volume {
+    vpt_context *ctx;
+    int nx, ny, nz;
+    int filter;
+    uint8_t *linear;       // nx*ny*nz, the "texture storage" blocks are uploaded into
+    uint8_t *bricks;       // apron bricks, Morton order
+    size_t brick_bytes;
+    bool dirty;            // blocks uploaded since the last brickify
+    bool any_upload;
+    uint8_t *staging; size_t staging_bytes;
+};
+
+struct vpt_renderer {
+    vpt_context *ctx;
+    int kind;
+    int W, H;
+    int G, g, R;
+    int local_h;
+    int tiles_x, tiles_y, ntiles;
+    size_t npix_padded;     // ntiles * 256
+    uint64_t valid_pixels;  // owned pixels inside the image
+    vpt_volume *vol;
+    float4 *tf; int tf_w, tf_h;
+    float4 *env; int env_w, env_h; float4 env_const;
+    void *frame, *acc;
+    float4 *st[4];
+    uint2 *render;
+    unsigned long long *samples;   // device counter (MIP/EAM/MCS)
+    uint64_t samples_host;         // analytic part (MCM)
+    void *scratch; size_t scratch_bytes;
+    bool profiling;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used;
+};
+
+static size_t frame_elem(int kind) {
+    switch (kind) {
+        case VPT_RENDERER_MIP: return 1;
+        case VPT_RENDERER_EAM: return 4;
+        case VPT_RENDERER_MCS: return 16;
+        default: return 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int vpt_device_count(int *count) {
+    if (!count) return fail(VPT_ERR_INVALID, "count is null");
+    HIP_TRY(hipGetDeviceCount(count));
+    return VPT_OK;
+}
+extern "C" int vpt_context_create(int device, vpt_context **out) {
+    if (!out) return fail(VPT_ERR_INVALID, "out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(VPT_ERR_INVALID, "device %d out of range (%d devices)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    vpt_context *c = new vpt_context();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(VPT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = c;
+    return VPT_OK;
+}
+extern "C" int vpt_context_destroy(vpt_context *c) {
+    if (!c) return VPT_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return VPT_OK;
+}
+extern "C" int vpt_context_synchronize(vpt_context *c) {
+    if (!c) return fail(VPT_ERR_INVALID, "context is null");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// volume — Volume.js:31-78
+// ---------------------------------------------------------------------------------------------
+static uint32_t host_spread3(uint32_t x) {
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format, vpt_volume **out) {
+    if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
+    if (format != VPT_FORMAT_R8) return fail(VPT_ERR_UNSUPPORTED, "Unknown volume datatype: %d", format);  // Volume.js:103
+    if (w < 1 || h < 1 || d < 1 || w > 4096 || h > 4096 || d > 4096)
+        return fail(VPT_ERR_INVALID, "volume dimensions %dx%dx%d out of range [1,4096]", w, h, d);
+    HIP_TRY(hipSetDevice(c->device));
+    vpt_volume *v = new vpt_volume();
+    memset(v, 0, sizeof(*v));
+    v->ctx = c; v->nx = w; v->ny = h; v->nz = d;
+    v->filter = VPT_FILTER_LINEAR;                       // Volume.js:53-54
+    int nbx = (w + 3) / 4, nby = (h + 3) / 4, nbz = (d + 3) / 4;
+    size_t max_slot = (size_t)(host_spread3(nbx - 1) | (host_spread3(nby - 1) << 1) | (host_spread3(nbz - 1) << 2));
+    v->brick_bytes = (max_slot + 1) * VPT_BRICK_BYTES;
+    hipError_t e = hipMalloc(&v->linear, (size_t)w * h * d);
+    if (e == hipSuccess) e = hipMalloc(&v->bricks, v->brick_bytes + 64);   // +64: the 8-byte tap windows end <= byte 125+7
+    if (e != hipSuccess) {
+        if (v->linear) hipFree(v->linear);
+        delete v;
+        return fail(VPT_ERR_HIP, "hipMalloc volume %dx%dx%d: %s", w, h, d, hipGetErrorString(e));
+    }
+    HIP_TRY(hipMemsetAsync(v->linear, 0, (size_t)w * h * d, c->stream));   // texStorage3D zero-initialises
+    v->dirty = true;
+    *out = v;
+    return VPT_OK;
+}
+static int volume_upload(vpt_volume *v, int x, int y, int z, int w, int h, int d, const void *data, size_t nbytes, bool on_device) {
+    if (!v || !data) return fail(VPT_ERR_INVALID, "null argument");
+    if (w < 1 || h < 1 || d < 1 || x < 0 || y < 0 || z < 0 || x + w > v->nx || y + h > v->ny || z + d > v->nz)
+        return fail(VPT_ERR_INVALID, "block (%d,%d,%d)+(%d,%d,%d) outside volume %dx%dx%d", x, y, z, w, h, d, v->nx, v->ny, v->nz);
+    size_t need = (size_t)w * h * d;
+    if (nbytes < need) return fail(VPT_ERR_INVALID, "block data too short: %zu < %zu", nbytes, need);
+    vpt_context *c = v->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    bool full_xy = (x == 0 && y == 0 && w == v->nx && h == v->ny);
+    if (full_xy) {   // contiguous run of z-slices (RAWReader.js:47-63 produces exactly these)
+        uint8_t *dst = v->linear + (size_t)z * v->nx * v->ny;
+        HIP_TRY(hipMemcpyAsync(dst, data, need, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    } else {
+        const uint8_t *src = (const uint8_t *)data;
+        if (!on_device) {
+            if (v->staging_bytes < need) {
+                if (v->staging) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(v->staging)); v->staging = nullptr; }
+                HIP_TRY(hipMalloc(&v->staging, need));
+                v->staging_bytes = need;
+            }
+            HIP_TRY(hipMemcpyAsync(v->staging, data, need, hipMemcpyHostToDevice, c->stream));
+            src = v->staging;
+        }
+        int grid = (int)((need + 255) / 256); if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(k_blit_block, dim3(grid), dim3(256), 0, c->stream, v->linear, v->nx, v->ny, src, x, y, z, w, h, d);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));   // host buffer may be released by the caller
+    v->dirty = true; v->any_upload = true;
+    return VPT_OK;
+}
+extern "C" int vpt_volume_upload_block(vpt_volume *v, int x, int y, int z, int w, int h, int d, const void *data, size_t nbytes) {
+    return volume_upload(v, x, y, z, w, h, d, data, nbytes, false);
+}
+extern "C" int vpt_volume_upload_block_device(vpt_volume *v, int x, int y, int z, int w, int h, int d, const void *data, size_t nbytes) {
+    return volume_upload(v, x, y, z, w, h, d, data, nbytes, true);
+}
+extern "C" int vpt_volume_finalize(vpt_volume *v) {
+    if (!v) return fail(VPT_ERR_INVALID, "volume is null");
+    if (!v->dirty) return VPT_OK;
+    vpt_context *c = v->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int nbx = (v->nx + 3) / 4, nby = (v->ny + 3) / 4, nbz = (v->nz + 3) / 4;
+    size_t nbricks = (size_t)nbx * nby * nbz;
+    if (nbricks > 0x7fffffffu) return fail(VPT_ERR_UNSUPPORTED, "too many bricks");
+    hipLaunchKernelGGL(k_brickify, dim3((unsigned)nbricks), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, nbx, nby);
+    HIP_TRY(hipGetLastError());
+    v->dirty = false;
+    return VPT_OK;
+}
+extern "C" int vpt_volume_set_filter(vpt_volume *v, int filter) {
+    if (!v) return fail(VPT_ERR_INVALID, "volume is null");
+    v->filter = (filter == VPT_FILTER_LINEAR) ? VPT_FILTER_LINEAR : VPT_FILTER_NEAREST;   // Volume.js:121
+    return VPT_OK;
+}
+extern "C" int vpt_volume_bricked_bytes(vpt_volume *v, uint64_t *n) {
+    if (!v || !n) return fail(VPT_ERR_INVALID, "null argument");
+    *n = v->brick_bytes;
+    return VPT_OK;
+}
+extern "C" int vpt_volume_destroy(vpt_volume *v) {
+    if (!v) return VPT_OK;
+    hipSetDevice(v->ctx->device);
+    hipStreamSynchronize(v->ctx->stream);
+    if (v->linear) hipFree(v->linear);
+    if (v->bricks) hipFree(v->bricks);
+    if (v->staging) hipFree(v->staging);
+    delete v;
+    return VPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// renderer
+// ---------------------------------------------------------------------------------------------
+static void renderer_free_buffers(vpt_renderer *r) {
+    if (r->frame) hipFree(r->frame);
+    if (r->acc) hipFree(r->acc);
+    for (int i = 0; i < 4; i++) if (r->st[i]) hipFree(r->st[i]);
+    if (r->render) hipFree(r->render);
+    if (r->scratch) hipFree(r->scratch);
+    r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
+    for (int i = 0; i < 4; i++) r->st[i] = nullptr;
+}
+// _rebuildBuffers: AbstractRenderer.js:78-92 (+ the per-renderer buffer specs)
+static int renderer_alloc_buffers(vpt_renderer *r) {
+    vpt_context *c = r->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    renderer_free_buffers(r);
+    int nblocks = (r->H + r->R - 1) / r->R;                 // row blocks in the image
+    int mine = (nblocks - r->g + r->G - 1) / r->G;          // blocks b with b % G == g
+    int max_blocks = (nblocks + r->G - 1) / r->G;           // every rank pads to this (equal-size gather)
+    if (mine < 0) mine = 0;
+    r->local_h = max_blocks * r->R;
+    if (r->G == 1) r->local_h = r->H;
+    r->tiles_x = (r->W + VPT_TILE - 1) / VPT_TILE;
+    r->tiles_y = (r->local_h + VPT_TILE - 1) / VPT_TILE;
+    r->ntiles = r->tiles_x * r->tiles_y;
+    r->npix_padded = (size_t)r->ntiles * VPT_BLOCK;
+    uint64_t valid = 0;
+    for (int l = 0; l < r->local_h; l++) {
+        int lb = l / r->R; int j = (lb * r->G + r->g) * r->R + (l - lb * r->R);
+        if (j < r->H) valid += (uint64_t)r->W;
+    }
+    r->valid_pixels = valid;
+    size_t fe = frame_elem(r->kind);
+    if (fe) {
+        HIP_TRY(hipMalloc(&r->frame, r->npix_padded * fe));
+        HIP_TRY(hipMalloc(&r->acc, r->npix_padded * fe));
+        HIP_TRY(hipMemsetAsync(r->frame, 0, r->npix_padded * fe, c->stream));
+        HIP_TRY(hipMemsetAsync(r->acc, 0, r->npix_padded * fe, c->stream));
+    } else {
+        for (int i = 0; i < 4; i++) {
+            HIP_TRY(hipMalloc(&r->st[i], r->npix_padded * sizeof(float4)));
+            HIP_TRY(hipMemsetAsync(r->st[i], 0, r->npix_padded * sizeof(float4), c->stream));
+        }
+    }
+    size_t rb = (size_t)r->W * r->local_h * sizeof(uint2);
+    HIP_TRY(hipMalloc(&r->render, rb));
+    HIP_TRY(hipMemsetAsync(r->render, 0, rb, c->stream));
+    return VPT_OK;
+}
+static int upload_table(vpt_context *c, float4 **dst, const std::vector<float4> &host) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (*dst) { HIP_TRY(hipFree(*dst)); *dst = nullptr; }
+    HIP_TRY(hipMalloc(dst, host.size() * sizeof(float4)));
+    HIP_TRY(hipMemcpy(*dst, host.data(), host.size() * sizeof(float4), hipMemcpyHostToDevice));
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_set_transfer_function(vpt_renderer *r, const uint8_t *rgba, int w, int h) {
+    if (!r || !rgba) return fail(VPT_ERR_INVALID, "null argument");
+    if (w < 1 || h < 1 || w > 2048 || h > 4096) return fail(VPT_ERR_INVALID, "transfer function size %dx%d out of range", w, h);
+    // SRGB8_ALPHA8: rgb decoded before filtering, alpha linear (AbstractRenderer.js:36,99-104)
+    std::vector<float4> t((size_t)w * h);
+    for (size_t i = 0; i < t.size(); i++)
+        t[i] = make_float4(VPT_SRGB_TO_LINEAR[rgba[4 * i]], VPT_SRGB_TO_LINEAR[rgba[4 * i + 1]],
+                           VPT_SRGB_TO_LINEAR[rgba[4 * i + 2]], (float)rgba[4 * i + 3] / 255.0f);
+    VPT_TRY(upload_table(r->ctx, &r->tf, t));
+    r->tf_w = w; r->tf_h = h;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba, int w, int h) {
+    if (!r || !rgba) return fail(VPT_ERR_INVALID, "null argument");
+    if (w < 1 || h < 1 || w > 16384 || h > 16384) return fail(VPT_ERR_INVALID, "environment size %dx%d out of range", w, h);
+    std::vector<float4> t((size_t)w * h);
+    for (size_t i = 0; i < t.size(); i++)
+        t[i] = make_float4((float)rgba[4 * i] / 255.0f, (float)rgba[4 * i + 1] / 255.0f,
+                           (float)rgba[4 * i + 2] / 255.0f, (float)rgba[4 * i + 3] / 255.0f);
+    VPT_TRY(upload_table(r->ctx, &r->env, t));
+    r->env_w = w; r->env_h = h; r->env_const = t[0];
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int height, vpt_renderer **out) {
+    if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
+    if (kind < VPT_RENDERER_MIP || kind > VPT_RENDERER_MCM) return fail(VPT_ERR_INVALID, "No suitable class");  // RendererFactory.js:21
+    if (width < 1 || height < 1 || width > 32768 || height > 32768) return fail(VPT_ERR_INVALID, "resolution %dx%d out of range", width, height);
+    HIP_TRY(hipSetDevice(c->device));
+    vpt_renderer *r = new vpt_renderer();
+    r->ctx = c; r->kind = kind; r->W = width; r->H = height;
+    r->G = 1; r->g = 0; r->R = 8;
+    r->vol = nullptr; r->tf = nullptr; r->env = nullptr;
+    r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
+    for (int i = 0; i < 4; i++) r->st[i] = nullptr;
+    r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0;
+    int rc = renderer_alloc_buffers(r);
+    if (rc == VPT_OK) {
+        hipError_t e = hipMalloc(&r->samples, sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(r->samples, 0, sizeof(unsigned long long), c->stream);
+        if (e != hipSuccess) rc = fail(VPT_ERR_HIP, "hipMalloc counter: %s", hipGetErrorString(e));
+    }
+    static const uint8_t default_tf[8] = { 255, 0, 0, 0, 255, 0, 0, 255 };   // AbstractRenderer.js:31-44
+    static const uint8_t default_env[4] = { 255, 255, 255, 255 };            // RenderingContext.js:90-101
+    if (rc == VPT_OK) rc = vpt_renderer_set_transfer_function(r, default_tf, 2, 1);
+    if (rc == VPT_OK) rc = vpt_renderer_set_environment(r, default_env, 1, 1);
+    if (rc != VPT_OK) { vpt_renderer_destroy(r); return rc; }
+    *out = r;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
+    if (!r) return VPT_OK;
+    hipSetDevice(r->ctx->device);
+    hipStreamSynchronize(r->ctx->stream);
+    renderer_free_buffers(r);                 // renderer-owned buffers only; volume is NOT owned (Volume.js:17-22)
+    if (r->tf) hipFree(r->tf);
+    if (r->env) hipFree(r->env);
+    if (r->samples) hipFree(r->samples);
+    for (auto &ev : r->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    delete r;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_set_shard(vpt_renderer *r, int rank, int world, int rows_per_block) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    if (world < 1 || rank < 0 || rank >= world || rows_per_block < 1) return fail(VPT_ERR_INVALID, "bad shard %d/%d rows %d", rank, world, rows_per_block);
+    r->G = world; r->g = rank; r->R = rows_per_block;
+    return renderer_alloc_buffers(r);
+}
+extern "C" int vpt_renderer_local_rows(vpt_renderer *r, int *rows) {
+    if (!r || !rows) return fail(VPT_ERR_INVALID, "null argument");
+    *rows = r->local_h;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_global_row(vpt_renderer *r, int l, int *j) {
+    if (!r || !j) return fail(VPT_ERR_INVALID, "null argument");
+    if (l < 0 || l >= r->local_h) return fail(VPT_ERR_INVALID, "local row %d out of range", l);
+    int lb = l / r->R; int g = (lb * r->G + r->g) * r->R + (l - lb * r->R);
+    *j = (g < r->H) ? g : -1;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_resize(vpt_renderer *r, int width, int height) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    if (width < 1 || height < 1 || width > 32768 || height > 32768) return fail(VPT_ERR_INVALID, "resolution %dx%d out of range", width, height);
+    if (width == r->W && height == r->H) return VPT_OK;   // AbstractRenderer.js:107
+    r->W = width; r->H = height;
+    return renderer_alloc_buffers(r);
+}
+extern "C" int vpt_renderer_set_volume(vpt_renderer *r, vpt_volume *v) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    if (v && v->ctx != r->ctx) return fail(VPT_ERR_INVALID, "volume belongs to another context");
+    r->vol = v;
+    return VPT_OK;
+}
+
+static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, PassArgs *a) {
+    memset(a, 0, sizeof(*a));
+    a->pm.W = r->W; a->pm.H = r->H; a->pm.local_h = r->local_h;
+    a->pm.tiles_x = r->tiles_x; a->pm.ntiles = r->ntiles;
+    a->pm.G = r->G; a->pm.g = r->g; a->pm.R = r->R;
+    if (need_volume) {
+        if (!r->vol || !r->vol->any_upload) return fail(VPT_ERR_NO_VOLUME, "renderer has no ready volume");
+        VPT_TRY(vpt_volume_finalize(r->vol));
+        vpt_volume *v = r->vol;
+        a->vol.bricks = v->bricks; a->vol.nx = v->nx; a->vol.ny = v->ny; a->vol.nz = v->nz;
+        a->vol.fnx = (float)v->nx; a->vol.fny = (float)v->ny; a->vol.fnz = (float)v->nz;
+        a->vol.filter = v->filter;
+    }
+    a->env.texels = r->env; a->env.w = r->env_w; a->env.h = r->env_h; a->env.constant = r->env_const;
+    a->tf = r->tf; a->tf_w = r->tf_w; a->tf_fw = (float)r->tf_w;
+    if (u) {
+        memcpy(a->mvp_inv.m, u->mvp_inverse, sizeof(float) * 16);
+        a->seed = u->rand_seed; a->offset = u->offset; a->step = u->step_size;
+        a->extinction = u->extinction; a->anisotropy = u->anisotropy;
+        a->max_bounces = u->max_bounces; a->steps = u->steps;
+        a->light = f3{ u->light_direction[0], u->light_direction[1], u->light_direction[2] };
+        a->mix = u->mix; a->blur = u->blur;
+    }
+    a->inv_w = (float)(1.0 / (double)r->W);     // gl.uniform2f(uInverseResolution, 1/res, 1/res): MCMRenderer.js:91,155
+    a->inv_h = (float)(1.0 / (double)r->H);
+    a->frame = r->frame; a->acc = r->acc;
+    a->st0 = r->st[0]; a->st1 = r->st[1]; a->st2 = r->st[2]; a->st3 = r->st[3];
+    a->render = r->render;
+    a->samples = r->samples;
+    return VPT_OK;
+}
+static size_t tf_lds_bytes(const vpt_renderer *r) { return (size_t)r->tf_w * sizeof(float4); }
+
+static int check_step(const vpt_uniforms *u) {
+    // step sizes <= 0 or NaN would never advance t: the reference's spinner enforces min 1 (MIPRenderer.js:24, EAMRenderer.js:34)
+    if (!(u->step_size > 0.0f)) return fail(VPT_ERR_INVALID, "step_size must be > 0");
+    if (u->step_size < 1.0f / 65536.0f) return fail(VPT_ERR_INVALID, "step_size below 1/65536 (more than 65536 steps per ray)");
+    return VPT_OK;
+}
+
+struct Timed {   // per-launch HIP events around the dominant kernel
+    vpt_renderer *r; bool on; size_t idx;
+    Timed(vpt_renderer *r_, bool dominant) : r(r_), on(r_->profiling && dominant), idx(0) {
+        if (!on) return;
+        if (r->events_used == r->events.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            r->events.push_back({ a, b });
+        }
+        idx = r->events_used++;
+        hipEventRecord(r->events[idx].first, r->ctx->stream);
+    }
+    ~Timed() { if (on) hipEventRecord(r->events[idx].second, r->ctx->stream); }
+};
+
+#define LAUNCH(kernel, r, a, lds) hipLaunchKernelGGL(kernel, dim3((unsigned)(r)->ntiles), dim3(VPT_BLOCK), (lds), (r)->ctx->stream, (a))
+
+extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    if (r->kind == VPT_RENDERER_MCM && !u) return fail(VPT_ERR_INVALID, "MCM reset needs uniforms (uMvpInverseMatrix, uRandSeed)");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    PassArgs a;
+    VPT_TRY(make_args(r, u, false, &a));
+    switch (r->kind) {
+        case VPT_RENDERER_MIP: LAUNCH(k_mip_reset, r, a, 0); break;
+        case VPT_RENDERER_EAM: LAUNCH(k_eam_reset, r, a, 0); break;
+        case VPT_RENDERER_MCS: LAUNCH(k_mcs_reset, r, a, 0); break;
+        case VPT_RENDERER_MCM: LAUNCH(k_mcm_reset, r, a, 0); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
+    if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind == VPT_RENDERER_MCM) return VPT_OK;                 // MCMRenderer.js:118-119: empty
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    if (r->kind != VPT_RENDERER_MCS) VPT_TRY(check_step(u));
+    PassArgs a;
+    VPT_TRY(make_args(r, u, true, &a));
+    {
+        Timed t(r, true);
+        switch (r->kind) {
+            case VPT_RENDERER_MIP: LAUNCH(k_mip<0>, r, a, tf_lds_bytes(r)); break;
+            case VPT_RENDERER_EAM: LAUNCH(k_eam<0>, r, a, tf_lds_bytes(r)); break;
+            case VPT_RENDERER_MCS: LAUNCH(k_mcs<0>, r, a, tf_lds_bytes(r)); break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
+    if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    PassArgs a;
+    VPT_TRY(make_args(r, u, r->kind == VPT_RENDERER_MCM, &a));
+    switch (r->kind) {
+        case VPT_RENDERER_MIP: LAUNCH(k_mip_integrate, r, a, 0); break;
+        case VPT_RENDERER_EAM: LAUNCH(k_eam_integrate, r, a, 0); break;
+        case VPT_RENDERER_MCS: LAUNCH(k_mcs_integrate, r, a, 0); break;
+        case VPT_RENDERER_MCM: {
+            Timed t(r, true);
+            LAUNCH(k_mcm_integrate<false>, r, a, tf_lds_bytes(r));
+            r->samples_host += r->valid_pixels * (uint64_t)u->steps;   // exactly W*H*steps per pass (MCMRenderer.glsl:129-133)
+        } break;
+    }
+    HIP_TRY(hipGetLastError());
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    PassArgs a;
+    VPT_TRY(make_args(r, u, false, &a));
+    switch (r->kind) {
+        case VPT_RENDERER_MIP: LAUNCH(k_mip_render, r, a, 0); break;
+        case VPT_RENDERER_EAM: LAUNCH(k_eam_render, r, a, 0); break;
+        case VPT_RENDERER_MCS: LAUNCH(k_mcs_render, r, a, 0); break;
+        case VPT_RENDERER_MCM: LAUNCH(k_mcm_render, r, a, 0); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
+    if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    if (r->kind == VPT_RENDERER_MIP || r->kind == VPT_RENDERER_EAM) VPT_TRY(check_step(u));
+    PassArgs a;
+    VPT_TRY(make_args(r, u, true, &a));
+    {
+        Timed t(r, true);
+        switch (r->kind) {
+            case VPT_RENDERER_MIP: LAUNCH(k_mip<1>, r, a, tf_lds_bytes(r)); break;
+            case VPT_RENDERER_EAM: LAUNCH(k_eam<1>, r, a, tf_lds_bytes(r)); break;
+            case VPT_RENDERER_MCS: LAUNCH(k_mcs<1>, r, a, tf_lds_bytes(r)); break;
+            case VPT_RENDERER_MCM:
+                LAUNCH(k_mcm_integrate<true>, r, a, tf_lds_bytes(r));
+                r->samples_host += r->valid_pixels * (uint64_t)u->steps;
+                break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return VPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// read-back, counters, profiling
+// ---------------------------------------------------------------------------------------------
+extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t nbytes) {
+    if (!r || !dst) return fail(VPT_ERR_INVALID, "null argument");
+    vpt_context *c = r->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t npix = (size_t)r->W * r->local_h;
+    if (buffer == VPT_BUFFER_RENDER) {
+        if (nbytes < npix * 8) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, npix * 8);
+        HIP_TRY(hipMemcpyAsync(dst, r->render, npix * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return VPT_OK;
+    }
+    const void *src = nullptr; size_t elem = 0;
+    if (buffer == VPT_BUFFER_FRAME || buffer == VPT_BUFFER_ACCUM) {
+        elem = frame_elem(r->kind);
+        if (!elem) return fail(VPT_ERR_INVALID, "MCM has no frame/accumulation colour buffer; read the MCM state buffers");
+        src = (buffer == VPT_BUFFER_FRAME) ? r->frame : r->acc;
+    } else if (buffer >= VPT_BUFFER_MCM_POSITION && buffer <= VPT_BUFFER_MCM_RADIANCE) {
+        if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_INVALID, "not an MCM renderer");
+        elem = 16; src = r->st[buffer - VPT_BUFFER_MCM_POSITION];
+    } else {
+        return fail(VPT_ERR_INVALID, "unknown buffer %d", buffer);
+    }
+    if (nbytes < npix * elem) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, npix * elem);
+    if (r->scratch_bytes < npix * elem) {
+        if (r->scratch) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(r->scratch)); r->scratch = nullptr; }
+        HIP_TRY(hipMalloc(&r->scratch, npix * elem));
+        r->scratch_bytes = npix * elem;
+    }
+    PassArgs a;
+    VPT_TRY(make_args(r, nullptr, false, &a));
+    hipLaunchKernelGGL(k_detile, dim3((unsigned)r->ntiles), dim3(VPT_BLOCK), 0, c->stream, a.pm, (const uint8_t *)src, (uint8_t *)r->scratch, (int)elem);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dst, r->scratch, npix * elem, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_render_buffer_device(vpt_renderer *r, void **ptr, size_t *nbytes) {
+    if (!r || !ptr || !nbytes) return fail(VPT_ERR_INVALID, "null argument");
+    *ptr = r->render; *nbytes = (size_t)r->W * r->local_h * 8;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count) {
+    if (!r || !count) return fail(VPT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    unsigned long long dev = 0;
+    HIP_TRY(hipMemcpyAsync(&dev, r->samples, sizeof(dev), hipMemcpyDeviceToHost, r->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    *count = (uint64_t)dev + r->samples_host;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_clear_sample_count(vpt_renderer *r) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    HIP_TRY(hipMemsetAsync(r->samples, 0, sizeof(unsigned long long), r->ctx->stream));
+    r->samples_host = 0;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_set_profiling(vpt_renderer *r, int enabled) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    r->profiling = enabled != 0;
+    r->events_used = 0;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t *launches) {
+    if (!r || !total_ms || !launches) return fail(VPT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    double sum = 0.0;
+    for (size_t i = 0; i < r->events_used; i++) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, r->events[i].first, r->events[i].second));
+        sum += (double)ms;
+    }
+    *total_ms = sum; *launches = (uint32_t)r->events_used;
+    return VPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// probes
+// ---------------------------------------------------------------------------------------------
+extern "C" int vpt_probe_math(vpt_context *c, int which, const float *in, float *out, size_t n) {
+    if (!c || !in || !out) return fail(VPT_ERR_INVALID, "null argument");
+    if (which < 0 || which > VPT_PROBE_F16) return fail(VPT_ERR_INVALID, "unknown probe %d", which);
+    if (n == 0) return VPT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t nin = (which == VPT_PROBE_ATAN2) ? 2 * n : n;
+    float *din = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&din, nin * sizeof(float)));
+    hipError_t e = hipMalloc(&dout, n * sizeof(float));
+    if (e != hipSuccess) { hipFree(din); return fail(VPT_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    e = hipMemcpyAsync(din, in, nin * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, which, din, dout, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(din); hipFree(dout);
+    if (e != hipSuccess) return fail(VPT_ERR_HIP, "probe: %s", hipGetErrorString(e));
+    return VPT_OK;
+}
+extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n) {
+    if (!r || !xyz || !rgba) return fail(VPT_ERR_INVALID, "null argument");
+    if (n == 0) return VPT_OK;
+    vpt_context *c = r->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    PassArgs a;
+    VPT_TRY(make_args(r, nullptr, true, &a));
+    float *din = nullptr; float4 *dout = nullptr;
+    HIP_TRY(hipMalloc(&din, 3 * n * sizeof(float)));
+    hipError_t e = hipMalloc(&dout, n * sizeof(float4));
+    if (e != hipSuccess) { hipFree(din); return fail(VPT_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    e = hipMemcpyAsync(din, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_sample, dim3((unsigned)((n + 255) / 256)), dim3(VPT_BLOCK), tf_lds_bytes(r), c->stream, a, din, dout, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(rgba, dout, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(din); hipFree(dout);
+    if (e != hipSuccess) return fail(VPT_ERR_HIP, "probe: %s", hipGetErrorString(e));
+    return VPT_OK;
+}

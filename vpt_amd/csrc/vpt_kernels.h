@@ -1,0 +1,515 @@
+// vpt_kernels.h — the per-pixel pass kernels (gfx950, wave64).
+//
+// Launch shape: one thread per pixel, 256-thread workgroups covering a 16x16 pixel
+// tile as 2x2 waves of 8x8 pixels (neighbouring rays of a wave walk the same bricks).  Workgroup ids
+// are remapped so that the blocks that share an XCD (blockIdx % 8) own a contiguous band of tiles and
+// therefore a compact sub-volume in that XCD's L2.  Per-pixel buffers (frame, accumulation, MCM photon
+// state) are stored in THREAD order (tile-major), so every wave access is one contiguous 64*size
+// segment; only the RGBA16F render buffer — the product handed to the caller — is row-major.
+#pragma once
+#include "vpt_device.h"
+
+#define VPT_TILE        16
+#define VPT_BLOCK       256
+#define VPT_MAX_TRACK_ITERS 65536u
+
+struct PixMap {
+    int W, H;          // full image plane
+    int local_h;       // rows held by this renderer (== H when unsharded)
+    int tiles_x, ntiles;
+    int G, g, R;       // shard: world, rank, rows per block
+};
+struct Pix { int i, j, l, k; bool valid; };
+
+VPT_DEV int xcd_swizzle(int b, int n) {
+    int q = n >> 3, r = n & 7;
+    int xcd = b & 7, idx = b >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+VPT_DEV Pix map_pixel(const PixMap &m) {
+    int t = xcd_swizzle((int)blockIdx.x, m.ntiles);
+    int tx = t % m.tiles_x, ty = t / m.tiles_x;
+    int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    Pix p;
+    p.i = tx * VPT_TILE + (w & 1) * 8 + (lane & 7);
+    p.l = ty * VPT_TILE + (w >> 1) * 8 + (lane >> 3);
+    p.k = t * VPT_BLOCK + (int)threadIdx.x;
+    int lb = p.l / m.R;
+    p.j = (lb * m.G + m.g) * m.R + (p.l - lb * m.R);
+    p.valid = (p.i < m.W) && (p.l < m.local_h) && (p.j < m.H);
+    return p;
+}
+
+struct PassArgs {
+    PixMap pm;
+    DevVolume vol;
+    DevEnv env;
+    const float4 *tf; int tf_w; float tf_fw;
+    Mat4 mvp_inv;
+    float seed, offset, step, extinction, anisotropy;
+    uint32_t max_bounces, steps;
+    f3 light;
+    float mix, blur, inv_w, inv_h;
+    void *frame;                 // tile order
+    void *acc;                   // tile order (ping-pong collapsed: each pixel reads and writes only itself)
+    float4 *st0, *st1, *st2, *st3;   // MCM photon state, tile order
+    uint2 *render;               // RGBA16F, row-major local rows
+    unsigned long long *samples; // volume-sample counter
+};
+
+VPT_DEV void stage_tf(float4 *lds, const PassArgs &a) {
+    for (int t = (int)threadIdx.x; t < a.tf_w; t += VPT_BLOCK) lds[t] = a.tf[t];
+    __syncthreads();
+}
+// sampleVolumeColor: MIPRenderer.glsl:45-49 (= EAM :46-50, MCS :64-68, MCM :85-89)
+VPT_DEV float4 sample_volume_color(const PassArgs &a, const float4 *tf_lds, f3 p) {
+    float r = sample_volume(a.vol, p);
+    return sample_tf(tf_lds, a.tf_w, a.tf_fw, r);
+}
+VPT_DEV void count_samples(unsigned long long *ctr, uint32_t n) {
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+    if (((int)threadIdx.x & 63) == 0 && n) atomicAdd(ctr, (unsigned long long)n);
+}
+VPT_DEV uint2 pack_half4(float x, float y, float z, float w) {
+    uint2 r;
+    r.x = (uint32_t)to_half_bits(x) | ((uint32_t)to_half_bits(y) << 16);
+    r.y = (uint32_t)to_half_bits(z) | ((uint32_t)to_half_bits(w) << 16);
+    return r;
+}
+
+// =============================================================================================
+// MIP — MIPRenderer.glsl
+// =============================================================================================
+// generate/fragment main(): MIPRenderer.glsl:51-72; returns the unorm8 frame value
+VPT_DEV uint32_t mip_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p, uint32_t &ns) {
+    f3 rf, rt;
+    unproject(pixel_ndc(p.i, a.pm.W), pixel_ndc(p.j, a.pm.H), a.mvp_inv, rf, rt);
+    f3 dir = sub3(rt, rf);
+    f2 tb = intersect_cube(rf, dir);
+    tb.x = vmax(tb.x, 0.0f); tb.y = vmax(tb.y, 0.0f);
+    float out = 0.0f;
+    if (!(tb.x >= tb.y)) {
+        f3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
+        float tt = 0.0f, val = 0.0f, offset = a.offset;
+        do {
+            f3 pos = mix3(from, to, offset);
+            val = vmax(sample_volume_color(a, tf_lds, pos).w, val);
+            ns++;
+            tt += a.step;
+            float m = offset + a.step;
+            offset = m - floorf(m);
+        } while (tt < 1.0f);
+        out = val;
+    }
+    return to_unorm8(out);
+}
+// MODE 0: _generateFrame only (frame <- value).  MODE 1: whole render(): generate, integrate
+// (MIPRenderer.glsl:105-109, max on unorm8), renderFrame (:141-144) in one pass.
+template <int MODE>
+__global__ void __launch_bounds__(VPT_BLOCK) k_mip(PassArgs a) {
+    extern __shared__ float4 tf_lds[];
+    stage_tf(tf_lds, a);
+    Pix p = map_pixel(a.pm);
+    uint32_t ns = 0;
+    if (p.valid) {
+        uint32_t q = mip_pixel(a, tf_lds, p, ns);
+        uint8_t *frame = (uint8_t *)a.frame, *acc = (uint8_t *)a.acc;
+        if (MODE == 0) {
+            frame[p.k] = (uint8_t)q;
+        } else {
+            uint32_t m = max((uint32_t)acc[p.k], q);
+            acc[p.k] = (uint8_t)m;
+            float v = from_unorm8(m);
+            a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(v, v, v, 1.0f);
+        }
+    }
+    count_samples(a.samples, ns);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_mip_integrate(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    uint8_t *frame = (uint8_t *)a.frame, *acc = (uint8_t *)a.acc;
+    // max(acc, frame) on unorm8 values == integer max (c/255 is monotone)
+    acc[p.k] = (uint8_t)max((uint32_t)acc[p.k], (uint32_t)frame[p.k]);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_mip_render(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    float v = from_unorm8(((uint8_t *)a.acc)[p.k]);
+    a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(v, v, v, 1.0f);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_mip_reset(PassArgs a) {   // MIPRenderer.glsl:168-170
+    Pix p = map_pixel(a.pm);
+    ((uint8_t *)a.acc)[p.k] = 0;
+}
+
+// =============================================================================================
+// EAM — EAMRenderer.glsl
+// =============================================================================================
+// generate/fragment main(): EAMRenderer.glsl:52-80; returns packed RGBA8
+VPT_DEV uint32_t eam_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p, uint32_t &ns) {
+    f3 rf, rt;
+    unproject(pixel_ndc(p.i, a.pm.W), pixel_ndc(p.j, a.pm.H), a.mvp_inv, rf, rt);
+    f3 dir = sub3(rt, rf);
+    f2 tb = intersect_cube(rf, dir);
+    tb.x = vmax(tb.x, 0.0f); tb.y = vmax(tb.y, 0.0f);
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+    if (!(tb.x >= tb.y)) {
+        f3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
+        float ray_step_length = length3(sub3(from, to)) * a.step;
+        float tt = a.step * a.offset;
+        float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;
+        float kk = ray_step_length * a.extinction;
+        while (tt < 1.0f && aw < 0.99f) {
+            f3 pos = mix3(from, to, tt);
+            float4 c = sample_volume_color(a, tf_lds, pos);
+            ns++;
+            c.w *= kk;
+            c.x *= c.w; c.y *= c.w; c.z *= c.w;
+            float w = 1.0f - aw;
+            ax = fmaf(w, c.x, ax); ay = fmaf(w, c.y, ay); az = fmaf(w, c.z, az); aw = fmaf(w, c.w, aw);
+            tt += a.step;
+        }
+        if (aw > 1.0f) { ax /= aw; ay /= aw; az /= aw; }
+        ox = ax; oy = ay; oz = az;
+    }
+    return to_unorm8(ox) | (to_unorm8(oy) << 8) | (to_unorm8(oz) << 16) | (255u << 24);
+}
+// integrate: EAMRenderer.glsl:115-119, per channel, re-quantised to unorm8
+VPT_DEV uint32_t eam_mix(uint32_t acc, uint32_t frame, float m) {
+    uint32_t r = 0;
+    for (int c = 0; c < 4; c++) {
+        float av = from_unorm8((acc >> (8 * c)) & 0xffu), fv = from_unorm8((frame >> (8 * c)) & 0xffu);
+        r |= to_unorm8(mixf(av, fv, m)) << (8 * c);
+    }
+    return r;
+}
+VPT_DEV uint2 eam_to_half4(uint32_t q) {   // render: EAMRenderer.glsl:151-153
+    return pack_half4(from_unorm8(q & 0xffu), from_unorm8((q >> 8) & 0xffu),
+                      from_unorm8((q >> 16) & 0xffu), from_unorm8(q >> 24));
+}
+template <int MODE>
+__global__ void __launch_bounds__(VPT_BLOCK) k_eam(PassArgs a) {
+    extern __shared__ float4 tf_lds[];
+    stage_tf(tf_lds, a);
+    Pix p = map_pixel(a.pm);
+    uint32_t ns = 0;
+    if (p.valid) {
+        uint32_t q = eam_pixel(a, tf_lds, p, ns);
+        uint32_t *frame = (uint32_t *)a.frame, *acc = (uint32_t *)a.acc;
+        if (MODE == 0) {
+            frame[p.k] = q;
+        } else {
+            uint32_t m = eam_mix(acc[p.k], q, a.mix);
+            acc[p.k] = m;
+            a.render[(size_t)p.l * a.pm.W + p.i] = eam_to_half4(m);
+        }
+    }
+    count_samples(a.samples, ns);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_eam_integrate(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    uint32_t *frame = (uint32_t *)a.frame, *acc = (uint32_t *)a.acc;
+    acc[p.k] = eam_mix(acc[p.k], frame[p.k], a.mix);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_eam_render(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    a.render[(size_t)p.l * a.pm.W + p.i] = eam_to_half4(((uint32_t *)a.acc)[p.k]);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_eam_reset(PassArgs a) {   // EAMRenderer.glsl:177-179
+    Pix p = map_pixel(a.pm);
+    ((uint32_t *)a.acc)[p.k] = 0xff000000u;
+}
+
+// =============================================================================================
+// MCS — MCSRenderer.glsl
+// =============================================================================================
+// sampleDistance: MCSRenderer.glsl:70-87
+VPT_DEV float mcs_sample_distance(const PassArgs &a, const float4 *tf_lds, uint32_t &state, f3 from, f3 to, uint32_t &ns) {
+    float max_distance = length3(sub3(from, to));
+    float dist = 0.0f;
+    for (uint32_t it = 0; it < VPT_MAX_TRACK_ITERS; it++) {
+        dist += random_exponential(state, a.extinction);
+        if (!(dist <= max_distance)) break;
+        f3 p = mix3(from, to, dist / max_distance);
+        float4 ts = sample_volume_color(a, tf_lds, p);
+        ns++;
+        if (random_uniform(state) < ts.w) break;
+    }
+    return dist;
+}
+// sampleTransmittance: MCSRenderer.glsl:89-105
+VPT_DEV float mcs_sample_transmittance(const PassArgs &a, const float4 *tf_lds, uint32_t &state, f3 from, f3 to, uint32_t &ns) {
+    float max_distance = length3(sub3(from, to));
+    float dist = 0.0f, tr = 1.0f;
+    for (uint32_t it = 0; it < VPT_MAX_TRACK_ITERS; it++) {
+        dist += random_exponential(state, a.extinction);
+        if (!(dist <= max_distance)) break;
+        f3 p = mix3(from, to, dist / max_distance);
+        float4 ts = sample_volume_color(a, tf_lds, p);
+        ns++;
+        tr *= 1.0f - ts.w;
+    }
+    return tr;
+}
+// generate/fragment main(): MCSRenderer.glsl:107-137
+VPT_DEV float4 mcs_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p, uint32_t &ns) {
+    float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
+    f3 rf, rt;
+    unproject(px, py, a.mvp_inv, rf, rt);
+    f3 dir = sub3(rt, rf);
+    f3 dir_unit = normalize3(dir);
+    f2 tb = intersect_cube(rf, dir);
+    tb.x = vmax(tb.x, 0.0f); tb.y = vmax(tb.y, 0.0f);
+    if (tb.x >= tb.y) return sample_environment(a.env, dir_unit);
+    f3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
+    float max_distance = length3(sub3(from, to));
+    uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    float dist = mcs_sample_distance(a, tf_lds, state, from, to, ns);
+    if (!(dist <= max_distance)) return sample_environment(a.env, dir_unit);
+    from = mix3(from, to, dist / max_distance);
+    f2 tb2 = intersect_cube(from, a.light);
+    tb2.y = vmax(tb2.y, 0.0f);
+    to = madd3(from, tb2.y, a.light);
+    float4 diffuse = sample_volume_color(a, tf_lds, from);
+    ns++;
+    float4 light = sample_environment(a.env, a.light);
+    float tr = mcs_sample_transmittance(a, tf_lds, state, from, to, ns);
+    return make_float4((diffuse.x * light.x) * tr, (diffuse.y * light.y) * tr,
+                       (diffuse.z * light.z) * tr, (diffuse.w * light.w) * tr);
+}
+VPT_DEV float4 mcs_mix(float4 acc, float4 frame, float inv) {   // MCSRenderer.glsl:173-177
+    return make_float4(fmaf(frame.x - acc.x, inv, acc.x), fmaf(frame.y - acc.y, inv, acc.y),
+                       fmaf(frame.z - acc.z, inv, acc.z), fmaf(frame.w - acc.w, inv, acc.w));
+}
+template <int MODE>
+__global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
+    extern __shared__ float4 tf_lds[];
+    stage_tf(tf_lds, a);
+    Pix p = map_pixel(a.pm);
+    uint32_t ns = 0;
+    if (p.valid) {
+        float4 c = mcs_pixel(a, tf_lds, p, ns);
+        float4 *frame = (float4 *)a.frame, *acc = (float4 *)a.acc;
+        if (MODE == 0) {
+            frame[p.k] = c;
+        } else {
+            float4 m = mcs_mix(acc[p.k], c, a.mix);
+            acc[p.k] = m;
+            a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(m.x, m.y, m.z, m.w);
+        }
+    }
+    count_samples(a.samples, ns);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_mcs_integrate(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    float4 *frame = (float4 *)a.frame, *acc = (float4 *)a.acc;
+    acc[p.k] = mcs_mix(acc[p.k], frame[p.k], a.mix);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_mcs_render(PassArgs a) {   // MCSRenderer.glsl:210-213
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    float4 m = ((float4 *)a.acc)[p.k];
+    a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(m.x, m.y, m.z, m.w);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_mcs_reset(PassArgs a) {    // MCSRenderer.glsl:238-240
+    Pix p = map_pixel(a.pm);
+    ((float4 *)a.acc)[p.k] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+}
+
+// =============================================================================================
+// MCM — MCMRenderer.glsl, mixins/Photon.glsl, mixins/unprojectRand.glsl
+// =============================================================================================
+struct Photon {
+    f3 position, direction, transmittance, radiance;
+    uint32_t bounces, samples;
+};
+// mixins/unprojectRand.glsl:3-24
+VPT_DEV void unproject_rand(uint32_t &state, float px, float py, const PassArgs &a, f3 &from, f3 &to) {
+    f2 d = random_disk(state);
+    float ox = d.x * a.blur, oy = d.y * a.blur;
+    float sx = random_uniform(state), sy = random_uniform(state);
+    float ax = fmaf(sx, 2.0f, -1.0f) * a.inv_w;
+    float ay = fmaf(sy, 2.0f, -1.0f) * a.inv_h;
+    float4 n = mat4_mul_point(a.mvp_inv, px + ox, py + oy, -1.0f);
+    float4 f = mat4_mul_point(a.mvp_inv, px + ax, py + ay, 1.0f);
+    from = f3{ n.x / n.w, n.y / n.w, n.z / n.w };
+    to = f3{ f.x / f.w, f.y / f.w, f.z / f.w };
+}
+// resetPhoton: MCMRenderer.glsl:70-78
+VPT_DEV void reset_photon(uint32_t &state, Photon &ph, float px, float py, const PassArgs &a) {
+    f3 from, to;
+    unproject_rand(state, px, py, a, from, to);
+    ph.direction = normalize3(sub3(to, from));
+    ph.bounces = 0u;
+    f2 tb = intersect_cube(from, ph.direction);
+    tb.x = vmax(tb.x, 0.0f);
+    ph.position = madd3(from, tb.x, ph.direction);
+    ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
+}
+// sampleHenyeyGreensteinAngleCosine: MCMRenderer.glsl:91-95
+VPT_DEV float hg_cos(uint32_t &state, float g) {
+    float g2 = g * g;
+    float c = (1.0f - g2) / fmaf(2.0f * g, random_uniform(state), 1.0f - g);
+    return fmaf(-c, c, 1.0f + g2) / (2.0f * g);
+}
+// sampleHenyeyGreenstein: MCMRenderer.glsl:97-106
+VPT_DEV f3 sample_hg(uint32_t &state, float g, f3 dir) {
+    f3 u = random_sphere(state);
+    if (fabsf(g) < 1e-5f) return u;
+    float hgcos = hg_cos(state, g);
+    float ud = dot3(u, dir);
+    f3 c = { fmaf(-ud, dir.x, u.x), fmaf(-ud, dir.y, u.y), fmaf(-ud, dir.z, u.z) };
+    c = normalize3(c);
+    float s = sqrtf(fmaf(-hgcos, hgcos, 1.0f));
+    return f3{ fmaf(s, c.x, hgcos * dir.x), fmaf(s, c.y, hgcos * dir.y), fmaf(s, c.z, hgcos * dir.z) };
+}
+// radiance += (rad - radiance) / float(samples)   (MCMRenderer.glsl:147-150,154-157)
+VPT_DEV void photon_deposit(Photon &ph, f3 rad) {
+    ph.samples++;
+    float n = (float)ph.samples;
+    ph.radiance.x += (rad.x - ph.radiance.x) / n;
+    ph.radiance.y += (rad.y - ph.radiance.y) / n;
+    ph.radiance.z += (rad.z - ph.radiance.z) / n;
+}
+
+// reset/fragment main(): MCMRenderer.glsl:259-275 (seeded from the NDC position)
+__global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    Photon ph;
+    if (p.valid) {
+        float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
+        uint32_t state = hash3(__float_as_uint(px), __float_as_uint(py), __float_as_uint(a.seed));
+        f3 from, to;
+        unproject_rand(state, px, py, a, from, to);
+        ph.direction = normalize3(sub3(to, from));
+        f2 tb = intersect_cube(from, ph.direction);
+        tb.x = vmax(tb.x, 0.0f);
+        ph.position = madd3(from, tb.x, ph.direction);
+    } else {
+        ph.position = f3{ 0.0f, 0.0f, 0.0f };
+        ph.direction = f3{ 0.0f, 0.0f, 1.0f };
+    }
+    a.st0[p.k] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
+    a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
+    a.st2[p.k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    a.st3[p.k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+}
+
+// integrate/fragment main(): MCMRenderer.glsl:116-172.  FUSE_RENDER additionally performs
+// _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
+template <bool FUSE_RENDER>
+__global__ void __launch_bounds__(VPT_BLOCK) k_mcm_integrate(PassArgs a) {
+    extern __shared__ float4 tf_lds[];
+    stage_tf(tf_lds, a);
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
+    float4 s0 = a.st0[p.k], s1 = a.st1[p.k], s2 = a.st2[p.k], s3 = a.st3[p.k];
+    Photon ph;
+    ph.position = f3{ s0.x, s0.y, s0.z };
+    ph.direction = f3{ s1.x, s1.y, s1.z };
+    ph.bounces = (uint32_t)(s1.w + 0.5f);
+    ph.transmittance = f3{ s2.x, s2.y, s2.z };
+    ph.radiance = f3{ s3.x, s3.y, s3.z };
+    ph.samples = (uint32_t)(s3.w + 0.5f);
+
+    uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    for (uint32_t s = 0u; s < a.steps; s++) {
+        float dist = random_exponential(state, a.extinction);
+        ph.position = madd3(ph.position, dist, ph.direction);
+        float4 vs = sample_volume_color(a, tf_lds, ph.position);
+        float p_null = 1.0f - vs.w;
+        float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
+        float p_abs = 1.0f - p_null - p_scat;
+        float wheel = random_uniform(state);
+        f3 q = ph.position;
+        if (q.x > 1.0f || q.y > 1.0f || q.z > 1.0f || q.x < 0.0f || q.y < 0.0f || q.z < 0.0f) {
+            float4 env = sample_environment(a.env, ph.direction);
+            photon_deposit(ph, f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z });
+            reset_photon(state, ph, px, py, a);
+        } else if (wheel < p_abs) {
+            photon_deposit(ph, f3{ 0.0f, 0.0f, 0.0f });
+            reset_photon(state, ph, px, py, a);
+        } else if (wheel < p_abs + p_scat) {
+            ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
+            ph.direction = sample_hg(state, a.anisotropy, ph.direction);
+            ph.bounces++;
+        }
+    }
+    a.st0[p.k] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
+    a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
+    a.st2[p.k] = make_float4(ph.transmittance.x, ph.transmittance.y, ph.transmittance.z, 0.0f);
+    a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
+    if (FUSE_RENDER)
+        a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_mcm_render(PassArgs a) {   // MCMRenderer.glsl:204-206
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    float4 r = a.st3[p.k];
+    a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(r.x, r.y, r.z, 1.0f);
+}
+
+// =============================================================================================
+// layout helpers
+// =============================================================================================
+// tile-order per-pixel buffer -> row-major local rows (read-back only); elem = bytes per pixel
+__global__ void __launch_bounds__(VPT_BLOCK) k_detile(PixMap pm, const uint8_t *src, uint8_t *dst, int elem) {
+    Pix p = map_pixel(pm);
+    if (!(p.i < pm.W && p.l < pm.local_h)) return;
+    const uint8_t *s = src + (size_t)p.k * elem;
+    uint8_t *d = dst + ((size_t)p.l * pm.W + p.i) * elem;
+    for (int b = 0; b < elem; b++) d[b] = s[b];
+}
+
+// texSubImage3D: contiguous block (bw x bh x bd) -> linear volume at (x0,y0,z0)
+__global__ void k_blit_block(uint8_t *vol, int nx, int ny, const uint8_t *blk, int x0, int y0, int z0, int bw, int bh, int bd) {
+    size_t n = (size_t)bw * bh * bd;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        int x = (int)(t % bw); size_t r = t / bw; int y = (int)(r % bh); int z = (int)(r / bh);
+        vol[((size_t)(z0 + z) * ny + (y0 + y)) * nx + (x0 + x)] = blk[t];
+    }
+}
+// linear volume -> apron bricks in Morton order; one 128-thread workgroup per brick
+__global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, int nbx, int nby) {
+    size_t b = blockIdx.x;
+    int bx = (int)(b % nbx); size_t r = b / nbx; int by = (int)(r % nby); int bz = (int)(r / nby);
+    int t = (int)threadIdx.x;
+    uint8_t v = 0;
+    if (t < 125) {
+        int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
+        int x = min(bx * VPT_BRICK + lx, nx - 1), y = min(by * VPT_BRICK + ly, ny - 1), z = min(bz * VPT_BRICK + lz, nz - 1);
+        v = lin[((size_t)z * ny + y) * nx + x];
+    }
+    bricks[((size_t)morton3((uint32_t)bx, (uint32_t)by, (uint32_t)bz) << 7) + t] = v;
+}
+
+// probes (tests)
+__global__ void k_probe_math(int which, const float *in, float *out, size_t n) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float r = 0.0f, s, c;
+    switch (which) {
+        case 0: r = vpt_logf(in[t]); break;
+        case 1: vpt_sincosf(in[t], s, c); r = s; break;
+        case 2: vpt_sincosf(in[t], s, c); r = c; break;
+        case 3: r = vpt_asinf(in[t]); break;
+        case 4: r = vpt_atan2f(in[2 * t], in[2 * t + 1]); break;
+        case 5: r = __uint_as_float(pcg(__float_as_uint(in[t]))); break;
+        case 6: { uint32_t st = __float_as_uint(in[t]); r = random_uniform(st); } break;
+        case 7: r = __uint_as_float((uint32_t)to_half_bits(in[t])); break;
+    }
+    out[t] = r;
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_probe_sample(PassArgs a, const float *xyz, float4 *out, size_t n) {
+    extern __shared__ float4 tf_lds[];
+    stage_tf(tf_lds, a);
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    out[t] = sample_volume_color(a, tf_lds, f3{ xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2] });
+}

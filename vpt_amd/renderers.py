@@ -1,0 +1,413 @@
+"""Renderer plugin surface — AbstractRenderer + MIP / EAM / MCS / MCM + RendererFactory.
+
+Host-side mirror of src/js/renderers/{Abstract,MIP,EAM,MCS,MCM}Renderer.js and RendererFactory.js:
+same constructor signature, methods, hook names, property names/defaults and 'change' behaviour.
+Every hook is a thin call into the C-ABI (include/vpt.h); the WebGL framebuffers of the reference
+(SingleBuffer.js / DoubleBuffer.js) are HIP device buffers owned by the native renderer.
+
+Differences that are part of the contract:
+  * ``gl`` is a vpt_amd.Context; ``environmentTexture`` is an RGBA8 array [h][w][4] or None (1x1 white,
+    RenderingContext.js:90-101).
+  * ``options['resolution']`` is an int (square, the reference's behaviour) or (width, height).
+  * the values the reference draws with Math.random() come from ``self.rng`` (option 'rng', default random.random);
+    install a seeded callable for reproducible runs.
+  * ``render()`` launches one fused kernel (generate -> integrate -> renderFrame) unless a subclass
+    overrides a hook or ``self.fused`` is False; the two forms give identical buffers.
+"""
+import ctypes as C
+import math
+import random as _random
+
+import numpy as np
+
+from . import _native as N
+from .property_bag import PropertyBag
+from .scene import Transform, mvp_inverse_matrix
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+class AbstractRenderer(PropertyBag):
+    _KIND = None
+
+    def __init__(self, gl, volume, camera, environmentTexture, options=None):
+        super().__init__()
+        options = options or {}
+        res = options.get('resolution', 512)                       # AbstractRenderer.js:20
+        self._resolution = res
+        self._gl = gl
+        self._volume = volume
+        self._camera = camera
+        self._environmentTexture = environmentTexture
+        self._volumeTransform = options.get('transform') or Transform()   # AbstractRenderer.js:27
+        self.rng = options.get('rng', _random.random)
+        self.fused = options.get('fused', True)
+        self._shard = options.get('shard')                         # (rank, world, rows_per_block) or None
+        self._h = None
+        self._rebuildBuffers()
+        if environmentTexture is not None:
+            self._upload_environment(environmentTexture)
+        self._bound_volume = None
+
+    # ---- native plumbing ------------------------------------------------------------------
+    def _size(self):
+        r = self._resolution
+        if isinstance(r, (tuple, list)):
+            return int(r[0]), int(r[1])
+        if isinstance(r, dict):
+            return int(r['width']), int(r['height'])
+        return int(r), int(r)
+
+    def _rebuildBuffers(self):                                     # AbstractRenderer.js:78-92
+        L = N.lib()
+        w, h = self._size()
+        if self._h is None:
+            hnd = C.c_void_p()
+            N.check(L.vpt_renderer_create(self._gl._h, self._KIND, w, h, C.byref(hnd)))
+            self._h = hnd
+            if self._shard:
+                N.check(L.vpt_renderer_set_shard(self._h, *self._shard))
+        else:
+            N.check(L.vpt_renderer_resize(self._h, w, h))
+
+    def _upload_environment(self, tex):
+        tex = np.ascontiguousarray(tex, dtype=np.uint8)
+        assert tex.ndim == 3 and tex.shape[2] == 4, 'environment texture is [h][w][4] RGBA8'
+        N.check(N.lib().vpt_renderer_set_environment(self._h, tex.ctypes.data_as(C.c_void_p), tex.shape[1], tex.shape[0]))
+
+    def _bind_volume(self):
+        tex = self._volume.getTexture() if self._volume is not None else None
+        if tex is not self._bound_volume:
+            N.check(N.lib().vpt_renderer_set_volume(self._h, tex))
+            self._bound_volume = tex
+
+    def _matrix(self):
+        return mvp_inverse_matrix(self._camera, self._volumeTransform)
+
+    def _new_uniforms(self):
+        u = N.Uniforms()
+        m = self._matrix()
+        for i in range(16):
+            u.mvp_inverse[i] = float(m[i])
+        return u
+
+    def _hooks_overridden(self):
+        base = type(self)._BASE
+        return any(getattr(type(self), n) is not getattr(base, n)
+                   for n in ('_generateFrame', '_integrateFrame', '_renderFrame'))
+
+    # ---- AbstractRenderer.js public surface ---------------------------------------------------
+    def destroy(self):                                             # :51-58
+        if self._h:
+            N.lib().vpt_renderer_destroy(self._h)
+            self._h = None
+
+    def render(self):                                              # :60-70
+        if self.fused and not self._hooks_overridden():
+            self._renderFused()
+            return
+        self._generateFrame()
+        self._integrateFrame()
+        self._renderFrame()
+
+    def reset(self):                                               # :72-76
+        self._resetFrame()
+
+    def setVolume(self, volume):                                   # :94-97
+        self._volume = volume
+        self.reset()
+
+    def setTransferFunction(self, transferFunction):               # :99-104 (texImage2D SRGB8_ALPHA8)
+        tf = np.ascontiguousarray(transferFunction, dtype=np.uint8)
+        if tf.ndim != 3 or tf.shape[2] != 4:
+            raise TypeError('transfer function is an RGBA8 image [h][w][4]')
+        N.check(N.lib().vpt_renderer_set_transfer_function(self._h, tf.ctypes.data_as(C.c_void_p), tf.shape[1], tf.shape[0]))
+
+    def setResolution(self, resolution):                           # :106-112
+        if resolution != self._resolution:
+            self._resolution = resolution
+            self._rebuildBuffers()
+            self.reset()
+
+    def getTexture(self):                                          # :114-116 -> RGBA16F image [rows][w][4]
+        return self.read(N.BUFFER_RENDER)
+
+    # ---- hooks (IMPLEMENT in subclasses, AbstractRenderer.js:118-140) ---------------------------
+    def _resetFrame(self): pass
+    def _generateFrame(self): pass
+    def _integrateFrame(self): pass
+    def _renderFrame(self): pass
+    def _renderFused(self): pass
+
+    # ---- extensions: read-back and counters -----------------------------------------------------
+    def local_rows(self):
+        n = C.c_int(0)
+        N.check(N.lib().vpt_renderer_local_rows(self._h, C.byref(n)))
+        return n.value
+
+    def global_rows(self):
+        """global row index of every local row (-1 = padding row of a shard)"""
+        out = []
+        g = C.c_int(0)
+        for l in range(self.local_rows()):
+            N.check(N.lib().vpt_renderer_global_row(self._h, l, C.byref(g)))
+            out.append(g.value)
+        return np.array(out, dtype=np.int64)
+
+    def read(self, buffer):
+        w, _ = self._size()
+        rows = self.local_rows()
+        if buffer == N.BUFFER_RENDER:
+            arr = np.empty((rows, w, 4), dtype=np.float16)
+        elif buffer in (N.BUFFER_FRAME, N.BUFFER_ACCUM):
+            if self._KIND == N.RENDERER_MIP:
+                arr = np.empty((rows, w), dtype=np.uint8)
+            elif self._KIND == N.RENDERER_EAM:
+                arr = np.empty((rows, w, 4), dtype=np.uint8)
+            else:
+                arr = np.empty((rows, w, 4), dtype=np.float32)
+        else:
+            arr = np.empty((rows, w, 4), dtype=np.float32)
+        N.check(N.lib().vpt_renderer_read(self._h, buffer, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return arr
+
+    def sample_count(self):
+        n = C.c_uint64(0)
+        N.check(N.lib().vpt_renderer_sample_count(self._h, C.byref(n)))
+        return n.value
+
+    def clear_sample_count(self):
+        N.check(N.lib().vpt_renderer_clear_sample_count(self._h))
+
+    def set_profiling(self, enabled):
+        N.check(N.lib().vpt_renderer_set_profiling(self._h, 1 if enabled else 0))
+
+    def profile(self):
+        ms, n = C.c_double(0), C.c_uint32(0)
+        N.check(N.lib().vpt_renderer_profile(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def render_buffer_device(self):
+        p, n = C.c_void_p(), C.c_size_t(0)
+        N.check(N.lib().vpt_renderer_render_buffer_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def probe_sample(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        out = np.empty((xyz.shape[0], 4), dtype=np.float32)
+        self._bind_volume()
+        N.check(N.lib().vpt_probe_sample(self._h, xyz.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), xyz.shape[0]))
+        return out
+
+
+AbstractRenderer._BASE = AbstractRenderer
+
+_TF_PROPERTY = {'name': 'transferFunction', 'label': 'Transfer function', 'type': 'transfer-function',
+                'value': np.zeros(256, dtype=np.uint8)}
+
+
+def _install_change_handler(renderer, reset_on):
+    def on_change(e):
+        name = e.detail['name']
+        if name == 'transferFunction':
+            renderer.setTransferFunction(renderer.transferFunction)
+        if name in reset_on:
+            renderer.reset()
+    renderer.addEventListener('change', on_change)
+
+
+class MIPRenderer(AbstractRenderer):
+    """src/js/renderers/MIPRenderer.js:13-159"""
+    _KIND = N.RENDERER_MIP
+
+    def __init__(self, gl, volume, camera, environmentTexture, options=None):
+        super().__init__(gl, volume, camera, environmentTexture, options)
+        self.registerProperties([
+            {'name': 'steps', 'label': 'Steps', 'type': 'spinner', 'value': 64, 'min': 1},
+            dict(_TF_PROPERTY),
+        ])
+        _install_change_handler(self, ('transferFunction',))      # :34-46 (steps does NOT reset)
+
+    def _resetFrame(self):                                         # :61-68
+        N.check(N.lib().vpt_renderer_reset(self._h, None))
+
+    def _prepare_generate(self):                                   # :82-97
+        u = self._new_uniforms()
+        u.step_size = _f32(1 / self.steps)
+        u.offset = _f32(self.rng())
+        self._u = u
+        return u
+
+    def _generateFrame(self):                                      # :69-100
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_generate(self._h, C.byref(self._prepare_generate())))
+
+    def _integrateFrame(self):                                     # :102-117
+        N.check(N.lib().vpt_renderer_integrate(self._h, C.byref(self._u)))
+
+    def _renderFrame(self):                                        # :119-131
+        N.check(N.lib().vpt_renderer_render_frame(self._h, None))
+
+    def _renderFused(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_generate())))
+
+
+class EAMRenderer(AbstractRenderer):
+    """src/js/renderers/EAMRenderer.js:13-181"""
+    _KIND = N.RENDERER_EAM
+
+    def __init__(self, gl, volume, camera, environmentTexture, options=None):
+        super().__init__(gl, volume, camera, environmentTexture, options)
+        self.registerProperties([
+            {'name': 'extinction', 'label': 'Extinction', 'type': 'spinner', 'value': 100, 'min': 0},
+            {'name': 'slices', 'label': 'Slices', 'type': 'spinner', 'value': 64, 'min': 1},
+            {'name': 'random', 'label': 'Random', 'type': 'checkbox', 'value': True},
+            dict(_TF_PROPERTY),
+        ])
+        _install_change_handler(self, ('extinction', 'slices', 'random', 'transferFunction'))   # :47-61
+        self._frameNumber = 0
+
+    def _resetFrame(self):                                         # :76-86
+        N.check(N.lib().vpt_renderer_reset(self._h, None))
+        self._frameNumber = 0
+
+    def _prepare_generate(self):                                   # :99-116,120
+        u = self._new_uniforms()
+        u.step_size = _f32(1 / self.slices)
+        u.extinction = _f32(self.extinction)
+        u.offset = _f32(self.rng()) if self.random else 0.0
+        self._frameNumber += 1
+        self._u = u
+        return u
+
+    def _prepare_integrate(self):                                  # :135
+        self._u.mix = _f32(1 / self._frameNumber)
+        return self._u
+
+    def _generateFrame(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_generate(self._h, C.byref(self._prepare_generate())))
+
+    def _integrateFrame(self):
+        N.check(N.lib().vpt_renderer_integrate(self._h, C.byref(self._prepare_integrate())))
+
+    def _renderFrame(self):
+        N.check(N.lib().vpt_renderer_render_frame(self._h, None))
+
+    def _renderFused(self):
+        self._bind_volume()
+        self._prepare_generate()
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_integrate())))
+
+
+class MCSRenderer(AbstractRenderer):
+    """src/js/renderers/MCSRenderer.js:13-182"""
+    _KIND = N.RENDERER_MCS
+
+    def __init__(self, gl, volume, camera, environmentTexture, options=None):
+        super().__init__(gl, volume, camera, environmentTexture, options)
+        self.registerProperties([
+            {'name': 'extinction', 'label': 'Extinction', 'type': 'spinner', 'value': 1, 'min': 0},
+            dict(_TF_PROPERTY),
+        ])
+        _install_change_handler(self, ('extinction', 'transferFunction'))   # :34-47
+        self._frameNumber = 1
+
+    def _resetFrame(self):                                         # :62-72
+        N.check(N.lib().vpt_renderer_reset(self._h, None))
+        self._frameNumber = 1
+
+    def _prepare_generate(self):                                   # :88-117
+        u = self._new_uniforms()
+        u.rand_seed = _f32(self.rng())
+        u.extinction = _f32(self.extinction)
+        while True:                                                # scattering direction: rejection-sampled unit vector
+            x = self.rng() * 2 - 1
+            y = self.rng() * 2 - 1
+            z = self.rng() * 2 - 1
+            length = math.sqrt(x * x + y * y + z * z)
+            if not length > 1:
+                break
+        u.light_direction[0] = _f32(x / length)
+        u.light_direction[1] = _f32(y / length)
+        u.light_direction[2] = _f32(z / length)
+        self._u = u
+        return u
+
+    def _prepare_integrate(self):                                  # :137-139
+        self._u.mix = _f32(1 / self._frameNumber)
+        self._frameNumber += 1
+        return self._u
+
+    def _generateFrame(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_generate(self._h, C.byref(self._prepare_generate())))
+
+    def _integrateFrame(self):
+        N.check(N.lib().vpt_renderer_integrate(self._h, C.byref(self._prepare_integrate())))
+
+    def _renderFrame(self):
+        N.check(N.lib().vpt_renderer_render_frame(self._h, None))
+
+    def _renderFused(self):
+        self._bind_volume()
+        self._prepare_generate()
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_integrate())))
+
+
+class MCMRenderer(AbstractRenderer):
+    """src/js/renderers/MCMRenderer.js:13-265"""
+    _KIND = N.RENDERER_MCM
+
+    def __init__(self, gl, volume, camera, environmentTexture, options=None):
+        super().__init__(gl, volume, camera, environmentTexture, options)
+        self.registerProperties([
+            {'name': 'extinction', 'label': 'Extinction', 'type': 'spinner', 'value': 1, 'min': 0},
+            {'name': 'anisotropy', 'label': 'Anisotropy', 'type': 'slider', 'value': 0, 'min': -1, 'max': 1},
+            {'name': 'bounces', 'label': 'Max bounces', 'type': 'spinner', 'value': 8, 'min': 0},
+            {'name': 'steps', 'label': 'Steps', 'type': 'spinner', 'value': 8, 'min': 0},
+            dict(_TF_PROPERTY),
+        ])
+        _install_change_handler(self, ('extinction', 'anisotropy', 'bounces', 'transferFunction'))   # :56-71 (not 'steps')
+
+    def _resetFrame(self):                                         # :85-116
+        u = self._new_uniforms()
+        u.rand_seed = _f32(self.rng())
+        u.blur = 0.0
+        N.check(N.lib().vpt_renderer_reset(self._h, C.byref(u)))
+
+    def _generateFrame(self):                                      # :118-119 (empty)
+        pass
+
+    def _prepare_integrate(self):                                  # :155-175
+        u = self._new_uniforms()
+        u.rand_seed = _f32(self.rng())
+        u.blur = 0.0
+        u.extinction = _f32(self.extinction)
+        u.anisotropy = _f32(self.anisotropy)
+        u.max_bounces = int(self.bounces)
+        u.steps = int(self.steps)
+        self._u = u
+        return u
+
+    def _integrateFrame(self):                                     # :121-185
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_integrate(self._h, C.byref(self._prepare_integrate())))
+
+    def _renderFrame(self):                                        # :187-199
+        N.check(N.lib().vpt_renderer_render_frame(self._h, None))
+
+    def _renderFused(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_integrate())))
+
+
+def RendererFactory(which):
+    """src/js/renderers/RendererFactory.js:10-23 ('iso', 'lao', 'dos', 'depth' are outside this path)."""
+    classes = {'mip': MIPRenderer, 'eam': EAMRenderer, 'mcs': MCSRenderer, 'mcm': MCMRenderer}
+    if which not in classes:
+        raise RuntimeError('No suitable class')
+    return classes[which]

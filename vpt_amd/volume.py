@@ -1,0 +1,141 @@
+"""Volume — src/js/Volume.js:3-127 re-hosted on HIP device memory, plus the RAW reader
+(src/js/readers/RAWReader.js:15-70) in its in-memory form so that the upload path can be driven the
+way RenderingContext.setVolume does (RenderingContext.js:124-134)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .property_bag import EventTarget, CustomEvent
+
+# WebGL2 enums carried by reader metadata (RAWReader.js:36-38)
+GL_RED, GL_R8, GL_UNSIGNED_BYTE = 6403, 33321, 5121
+
+
+class RAWReader:
+    """RAWReader.js:3-70: a raw u8 volume exposed as one placement per z slice.  ``data`` is any bytes-like
+    or uint8 array of width*height*depth bytes (the reference reads it through a loader's byte ranges)."""
+
+    def __init__(self, data, options=None):
+        options = options or {}
+        self.width = options.get('width', 0)
+        self.height = options.get('height', 0)
+        self.depth = options.get('depth', 0)
+        self._data = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.reshape(-1)
+        if self._data.dtype != np.uint8:
+            raise TypeError('RAWReader expects uint8 data')
+
+    def readMetadata(self):
+        modality = {
+            'name': 'default',
+            'dimensions': {'width': self.width, 'height': self.height, 'depth': self.depth},
+            'transform': {'matrix': [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]},
+            'format': GL_RED, 'internalFormat': GL_R8, 'type': GL_UNSIGNED_BYTE,
+            'placements': [],
+        }
+        blocks = []
+        for i in range(self.depth):
+            modality['placements'].append({'index': i, 'position': {'x': 0, 'y': 0, 'z': i}})
+            blocks.append({'url': 'default', 'format': 'raw',
+                           'dimensions': {'width': self.width, 'height': self.height, 'depth': 1}})
+        return {'meta': {'version': 1}, 'modalities': [modality], 'blocks': blocks}
+
+    def readBlock(self, block):
+        slice_bytes = self.width * self.height
+        return self._data[block * slice_bytes:(block + 1) * slice_bytes]
+
+
+class Volume(EventTarget):
+    """Volume.js:3-127.  ``gl`` is a vpt_amd.Context.  ``getTexture()`` returns the native volume handle
+    once ``ready`` (the reference returns the WebGLTexture), else None."""
+
+    def __init__(self, gl, reader=None, options=None):
+        super().__init__()
+        self._gl = gl
+        self._reader = reader
+        self.metadata = None
+        self.ready = False
+        self.texture = None
+        self.modality = None
+
+    def destroy(self):
+        if self.texture:
+            N.lib().vpt_volume_destroy(self.texture)
+            self.texture = None
+            self.ready = False
+
+    def readMetadata(self):
+        if not self.metadata:
+            self.metadata = self._reader.readMetadata()
+        return self.metadata
+
+    def readModality(self, modalityName):
+        L = N.lib()
+        self.ready = False
+        if not self.metadata:
+            self.readMetadata()
+        modality = next((m for m in self.metadata['modalities'] if m['name'] == modalityName), None)
+        if modality is None:
+            raise RuntimeError("Modality '%s' does not exist" % modalityName)      # Volume.js:40
+        self.modality = modality
+        if self.texture:
+            L.vpt_volume_destroy(self.texture)
+            self.texture = None
+        dims = modality['dimensions']
+        if modality['type'] != GL_UNSIGNED_BYTE or modality['format'] != GL_RED:
+            raise RuntimeError('Unknown volume datatype: %s' % modality['type'])    # Volume.js:103
+        h = C.c_void_p()
+        N.check(L.vpt_volume_create(self._gl._h, dims['width'], dims['height'], dims['depth'], N.FORMAT_R8, C.byref(h)))
+        self.texture = h
+        placements = modality['placements']
+        for placement in placements:
+            index, position = placement['index'], placement['position']
+            data = np.ascontiguousarray(self._reader.readBlock(index), dtype=np.uint8)
+            bd = self.metadata['blocks'][index]['dimensions']
+            N.check(L.vpt_volume_upload_block(self.texture, position['x'], position['y'], position['z'],
+                                              bd['width'], bd['height'], bd['depth'],
+                                              data.ctypes.data_as(C.c_void_p), data.size))
+            progress = (index + 1) / len(placements)
+            self.dispatchEvent(CustomEvent('progress', {'detail': progress}))
+        N.check(L.vpt_volume_finalize(self.texture))
+        self.ready = True
+
+    def load(self):
+        self.readModality('default')
+
+    def getTexture(self):
+        return self.texture if self.ready else None
+
+    def setFilter(self, filter):
+        if not self.texture:
+            return
+        N.check(N.lib().vpt_volume_set_filter(self.texture, N.FILTER_LINEAR if filter == 'linear' else N.FILTER_NEAREST))
+
+    # ---- extension: whole-array upload (one block) for synthetic volumes ----
+    @classmethod
+    def from_array(cls, gl, array, filter='linear'):
+        """Upload a [depth][height][width] uint8 array as a single block (host -> HBM once)."""
+        array = np.ascontiguousarray(array, dtype=np.uint8)
+        d, h, w = array.shape
+        vol = cls(gl, RAWReader(array, {'width': w, 'height': h, 'depth': d}))
+        L = N.lib()
+        hnd = C.c_void_p()
+        N.check(L.vpt_volume_create(gl._h, w, h, d, N.FORMAT_R8, C.byref(hnd)))
+        vol.texture = hnd
+        # chunk along z so one call stays < 2 GiB
+        zs = max(1, (1 << 30) // (w * h))
+        for z0 in range(0, d, zs):
+            z1 = min(d, z0 + zs)
+            chunk = array[z0:z1]
+            N.check(L.vpt_volume_upload_block(hnd, 0, 0, z0, w, h, z1 - z0, chunk.ctypes.data_as(C.c_void_p), chunk.size))
+        N.check(L.vpt_volume_finalize(hnd))
+        vol.metadata = vol._reader.readMetadata()
+        vol.modality = vol.metadata['modalities'][0]
+        vol.ready = True
+        vol.setFilter(filter)
+        return vol
+
+    def bricked_bytes(self):
+        n = C.c_uint64(0)
+        N.check(N.lib().vpt_volume_bricked_bytes(self.texture, C.byref(n)))
+        return n.value
