@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — headline metric: volume samples/s (+ ms/frame) of the MCM renderer, synthetic 512^3 volume at
+1920x1080, on N MI355X of one node (BASELINE.json).  One "step" = one AbstractRenderer.render() of the MCM
+renderer = one integrate pass of `steps`=8 delta-tracking events per pixel + _renderFrame (fused in one launch),
+inputs resident in HBM.  For N > 1 the image plane is sharded into interleaved row blocks (total work fixed =
+strong scaling) and every frame is gathered over RCCL (all_gather, overlapped with the next frame's kernel).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG_MCM = 24.0          # algorithmic bytes per volume sample: 8 * sizeof(u8) + (64 B read + 64 B write) / steps(8)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--volume", type=int, default=512)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--renderer", default="mcm", choices=["mcm", "mcs", "eam", "mip"])
+    ap.add_argument("--extinction", type=float, default=None)
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--check", type=int, default=1, help="verify the gathered frame against rank-local rows")
+    return ap.parse_args()
+
+
+def cpu_baseline(vol, args, matrix, tf):
+    """The CPU oracle (C restatement, "port") timed on this host on a bounded sample of the same workload:
+    MCM reset + P full-frame integrate passes of the same scene, OpenMP over rows."""
+    from oracle import oracle as O
+    import numpy as np
+    threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+    sc = O.OracleScene(vol, 'linear', tf=tf)
+    w, h = args.width, args.height
+    o = O.OracleRenderer('mcm', sc, w, h)
+    fr = O.make_frame(w, h, matrix, seed=0.5, extinction=1.0, anisotropy=0.0, max_bounces=8, mcm_steps=8, nthreads=threads)
+    o.reset(fr)
+    fr.seed = 0.25
+    o.integrate(fr)                       # untimed: page in the volume
+    passes = 8
+    t0 = time.perf_counter()
+    n = 0
+    for k in range(passes):
+        fr.seed = float(np.float32((k + 1) * 0.61803398875 % 1.0))
+        n += o.integrate(fr)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "volume samples/s", "cores": threads, "kind": "port",
+            "sample": "%d MCM integrate passes (steps=8) of the full %dx%d frame on the same %d^3 volume, "
+                      "oracle/vpt_oracle.c with OpenMP over rows, %.2f s wall" % (passes, w, h, args.volume, dt)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch                       # first: its libamdhip64 is the one libvpt_hip.so binds to
+    import torch.distributed as dist
+    import vpt_amd
+    from vpt_amd import _native as N
+    from vpt_amd.scene import default_camera, Transform, Node
+    from vpt_amd.synthetic import sphere_volume, GoldenRatioRng
+    from vpt_amd.tiles import FrameGather
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    W, H = args.width, args.height
+    vol = sphere_volume(args.volume, noise=48.0)
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        ctx = vpt_amd.Context(local_rank, stream=stream.cuda_stream)
+        gvol = vpt_amd.Volume.from_array(ctx, vol, 'linear')
+        gather = FrameGather(dist, torch, W, H, device)
+        camera = default_camera(W / H)
+        transform = Transform(Node())
+        opts = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng()}
+        if world > 1:
+            opts['shard'] = gather.shard()
+        r = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, opts)
+        if args.extinction is not None:
+            r.extinction = args.extinction
+        assert r.local_rows() == gather.rows
+        nbytes = gather.send[0].numel() * 2
+        r.reset()
+
+        def step(k):
+            b = k & 1
+            gather.wait(b)
+            r.set_render_target(gather.send[b].data_ptr(), nbytes)
+            r.render()
+            gather.gather(b)
+
+        for k in range(args.warmup):
+            step(k)
+        gather.wait(0); gather.wait(1)
+        torch.cuda.synchronize()
+        r.clear_sample_count()
+        r.set_profiling(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        gather.wait(0); gather.wait(1)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kernel_ms, launches = r.profile()
+        r.set_profiling(False)
+        samples_local = r.sample_count()
+
+        tt = torch.tensor([dt, float(samples_local)], dtype=torch.float64, device=device)
+        if world > 1:
+            tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            dt_max, samples = float(tmax[0]), float(tsum[1])
+        else:
+            dt_max, samples = dt, float(samples_local)
+
+        ok = True
+        if args.check and world > 1:
+            # the gathered frame must hold this rank's own rows unchanged
+            b = (args.steps - 1) & 1
+            frame = gather.frame(b)
+            rows = torch.as_tensor(r.global_rows(), device=device)
+            valid = rows >= 0
+            ok = bool(torch.equal(frame.index_select(0, rows[valid]), gather.send[b][valid]))
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        per_launch_samples = samples_local / max(launches, 1)
+        avg_ms = kernel_ms / max(launches, 1)
+        achieved = (B_ALG_MCM if args.renderer == "mcm" else 8.0) * per_launch_samples / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath))
+                key = "%s_%d_%dx%d_n%d" % (args.renderer, args.volume, W, H, world)
+                traffic = t.get(key)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "volume samples/s, MCM %d^3 @ %dx%d" % (args.volume, W, H) if args.renderer == "mcm"
+                      else "volume samples/s, %s %d^3 @ %dx%d" % (args.renderer.upper(), args.volume, W, H),
+            "value": samples / dt_max, "unit": "volume samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s renderer, synthetic %d^3 u8 volume (radial sphere + lattice noise), %dx%d, "
+                                   "default camera, default 2x1 transfer function, extinction %g, anisotropy 0, bounces 8, "
+                                   "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
+                       "parallelism": "image rows sharded over %d GPU(s), per-frame RCCL all_gather" % world if world > 1 else "single GPU",
+                       "samples_per_step": samples / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_mcm_integrate<fused render>" if args.renderer == "mcm" else "k_%s<fused>" % args.renderer,
+                         "kernel_avg_ms": avg_ms, "launches": launches,
+                         "bytes_per_sample": B_ALG_MCM if args.renderer == "mcm" else 8.0},
+            "frame_check": ok,
+        }
+        if world == 1 and args.cpu_baseline and args.renderer == "mcm":
+            try:
+                out["cpu_baseline"] = cpu_baseline(vol, args, r._matrix(), None)
+            except Exception as e:                                      # the baseline is reporting only
+                out["cpu_baseline"] = {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    r.destroy(); gvol.destroy(); ctx.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("gathered frame does not match the rank-local rows")
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,9 @@ typedef struct vpt_uniforms {
 /* ---- context: replaces the WebGL2RenderingContext the reference passes as `gl` (RenderingContext.js:66-106) */
 VPT_API int vpt_device_count(int *count);
 VPT_API int vpt_context_create(int device_ordinal, vpt_context **out);
+/* same, but work is enqueued on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream) so that
+ * it orders with the caller's other work (RCCL collectives) without host synchronisation; the stream is not destroyed */
+VPT_API int vpt_context_create_on_stream(int device_ordinal, void *hip_stream, vpt_context **out);
 VPT_API int vpt_context_destroy(vpt_context *ctx);
 VPT_API int vpt_context_synchronize(vpt_context *ctx);
 VPT_API const char *vpt_last_error(void);
@@ -129,6 +132,9 @@ VPT_API int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u);
 VPT_API int vpt_renderer_read(vpt_renderer *r, int buffer, void *host_dst, size_t nbytes);
 /* device pointer of the row-major RGBA16F render buffer (for the RCCL frame gather) */
 VPT_API int vpt_renderer_render_buffer_device(vpt_renderer *r, void **device_ptr, size_t *nbytes);
+/* redirect _renderFrame output into caller-owned device memory (>= width*local_rows*8 bytes), e.g. the send buffer of
+ * the frame gather; NULL restores the renderer's own render buffer (gl.bindFramebuffer analogue, SingleBuffer.js:28-32) */
+VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, size_t nbytes);
 /* volume samples executed since creation / last clear (SURVEY §8d metric) */
 VPT_API int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count);
 VPT_API int vpt_renderer_clear_sample_count(vpt_renderer *r);

@@ -16,7 +16,7 @@ PROBE_LOG, PROBE_SIN, PROBE_COS, PROBE_ASIN, PROBE_ATAN2, PROBE_PCG, PROBE_UNIFO
 
 # every symbol include/vpt.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "vpt_device_count", "vpt_context_create", "vpt_context_destroy", "vpt_context_synchronize",
+    "vpt_device_count", "vpt_context_create", "vpt_context_create_on_stream", "vpt_context_destroy", "vpt_context_synchronize",
     "vpt_last_error", "vpt_version",
     "vpt_volume_create", "vpt_volume_upload_block", "vpt_volume_upload_block_device", "vpt_volume_finalize",
     "vpt_volume_set_filter", "vpt_volume_destroy", "vpt_volume_bricked_bytes",
@@ -25,6 +25,7 @@ SYMBOLS = [
     "vpt_renderer_set_environment", "vpt_renderer_resize",
     "vpt_renderer_reset", "vpt_renderer_generate", "vpt_renderer_integrate", "vpt_renderer_render_frame",
     "vpt_renderer_render", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
+    "vpt_renderer_set_render_target",
     "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile",
     "vpt_probe_math", "vpt_probe_sample",
@@ -68,7 +69,7 @@ def lib():
     UP = C.POINTER(Uniforms)
     sig = {
         "vpt_device_count": [C.POINTER(I)],
-        "vpt_context_create": [I, PP], "vpt_context_destroy": [P], "vpt_context_synchronize": [P],
+        "vpt_context_create": [I, PP], "vpt_context_create_on_stream": [I, P, PP], "vpt_context_destroy": [P], "vpt_context_synchronize": [P],
         "vpt_volume_create": [P, I, I, I, I, PP],
         "vpt_volume_upload_block": [P, I, I, I, I, I, I, P, SZ],
         "vpt_volume_upload_block_device": [P, I, I, I, I, I, I, P, SZ],
@@ -84,6 +85,7 @@ def lib():
         "vpt_renderer_render_frame": [P, UP], "vpt_renderer_render": [P, UP],
         "vpt_renderer_read": [P, I, P, SZ],
         "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
+        "vpt_renderer_set_render_target": [P, P, SZ],
         "vpt_renderer_sample_count": [P, C.POINTER(C.c_uint64)], "vpt_renderer_clear_sample_count": [P],
         "vpt_renderer_set_profiling": [P, I],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],

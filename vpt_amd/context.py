@@ -8,10 +8,15 @@ class Context:
     """One HIP device + stream (vpt_context).  RenderingContext.js:66-106 creates the GL context the
     reference's Volume / renderers receive as ``gl``; this is its replacement."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
+        """stream: optional raw hipStream_t handle (int) owned by the caller, e.g.
+        torch.cuda.current_stream().cuda_stream; default = a private non-blocking stream."""
         L = N.lib()
         h = C.c_void_p()
-        N.check(L.vpt_context_create(int(device), C.byref(h)))
+        if stream is None:
+            N.check(L.vpt_context_create(int(device), C.byref(h)))
+        else:
+            N.check(L.vpt_context_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h)))
         self._h = h
         self.device = int(device)
 

@@ -36,6 +36,7 @@ extern "C" const char *vpt_version(void) { return "vpt-mi355x 0.1 (gfx950)"; }
 struct vpt_context {
     int device;
     hipStream_t stream;
+    bool owns_stream;
 };
 
 struct vpt_volume {
@@ -65,6 +66,7 @@ struct vpt_renderer {
     void *frame, *acc;
     float4 *st[4];
     uint2 *render;
+    uint2 *render_target;          // caller-owned redirect of the render buffer (or null)
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
     void *scratch; size_t scratch_bytes;
@@ -100,6 +102,20 @@ extern "C" int vpt_context_create(int device, vpt_context **out) {
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(VPT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->owns_stream = true;
+    *out = c;
+    return VPT_OK;
+}
+extern "C" int vpt_context_create_on_stream(int device, void *hip_stream, vpt_context **out) {
+    if (!out) return fail(VPT_ERR_INVALID, "out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(VPT_ERR_INVALID, "device %d out of range (%d devices)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    vpt_context *c = new vpt_context();
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    c->owns_stream = false;
     *out = c;
     return VPT_OK;
 }
@@ -107,7 +123,7 @@ extern "C" int vpt_context_destroy(vpt_context *c) {
     if (!c) return VPT_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    hipStreamDestroy(c->stream);
+    if (c->owns_stream) hipStreamDestroy(c->stream);
     delete c;
     return VPT_OK;
 }
@@ -239,6 +255,7 @@ static void renderer_free_buffers(vpt_renderer *r) {
 // _rebuildBuffers: AbstractRenderer.js:78-92 (+ the per-renderer buffer specs)
 static int renderer_alloc_buffers(vpt_renderer *r) {
     vpt_context *c = r->ctx;
+    r->render_target = nullptr;   // an external target was sized for the old geometry
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     renderer_free_buffers(r);
@@ -318,6 +335,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
     for (int i = 0; i < 4; i++) r->st[i] = nullptr;
     r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0;
+    r->render_target = nullptr;
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
         hipError_t e = hipMalloc(&r->samples, sizeof(unsigned long long));
@@ -403,7 +421,7 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
     a->inv_h = (float)(1.0 / (double)r->H);
     a->frame = r->frame; a->acc = r->acc;
     a->st0 = r->st[0]; a->st1 = r->st[1]; a->st2 = r->st[2]; a->st3 = r->st[3];
-    a->render = r->render;
+    a->render = r->render_target ? r->render_target : r->render;
     a->samples = r->samples;
     return VPT_OK;
 }
@@ -530,7 +548,7 @@ extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t 
     size_t npix = (size_t)r->W * r->local_h;
     if (buffer == VPT_BUFFER_RENDER) {
         if (nbytes < npix * 8) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, npix * 8);
-        HIP_TRY(hipMemcpyAsync(dst, r->render, npix * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(dst, r->render_target ? r->render_target : r->render, npix * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return VPT_OK;
     }
@@ -561,7 +579,14 @@ extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t 
 }
 extern "C" int vpt_renderer_render_buffer_device(vpt_renderer *r, void **ptr, size_t *nbytes) {
     if (!r || !ptr || !nbytes) return fail(VPT_ERR_INVALID, "null argument");
-    *ptr = r->render; *nbytes = (size_t)r->W * r->local_h * 8;
+    *ptr = r->render_target ? r->render_target : r->render; *nbytes = (size_t)r->W * r->local_h * 8;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t nbytes) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    size_t need = (size_t)r->W * r->local_h * 8;
+    if (ptr && nbytes < need) return fail(VPT_ERR_INVALID, "render target too small: %zu < %zu", nbytes, need);
+    r->render_target = (uint2 *)ptr;
     return VPT_OK;
 }
 extern "C" int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count) {

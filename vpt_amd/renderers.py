@@ -84,13 +84,22 @@ class AbstractRenderer(PropertyBag):
             self._bound_volume = tex
 
     def _matrix(self):
-        return mvp_inverse_matrix(self._camera, self._volumeTransform)
+        # the reference rebuilds the matrix every frame (MIPRenderer.js:86-97); the result only depends on these
+        # inputs, so it is cached until one of them changes
+        from .scene import PerspectiveCamera
+        pc = self._camera.getComponent(PerspectiveCamera)
+        key = (self._camera.transform.version, self._volumeTransform.version, id(self._camera), id(self._volumeTransform),
+               pc.fovy, pc.aspect, pc.near, pc.far,
+               getattr(self._camera, 'parent', None) is None, getattr(self._volumeTransform.node, 'parent', None) is None)
+        if getattr(self, '_matrix_key', None) != key or not key[-1] or not key[-2]:
+            self._matrix_cache = mvp_inverse_matrix(self._camera, self._volumeTransform)
+            self._matrix_key = key
+        return self._matrix_cache
 
     def _new_uniforms(self):
         u = N.Uniforms()
         m = self._matrix()
-        for i in range(16):
-            u.mvp_inverse[i] = float(m[i])
+        C.memmove(u.mvp_inverse, m.ctypes.data, 64)
         return u
 
     def _hooks_overridden(self):
@@ -193,6 +202,10 @@ class AbstractRenderer(PropertyBag):
         p, n = C.c_void_p(), C.c_size_t(0)
         N.check(N.lib().vpt_renderer_render_buffer_device(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def set_render_target(self, device_ptr, nbytes):
+        """redirect _renderFrame output into caller-owned device memory (None restores the own buffer)"""
+        N.check(N.lib().vpt_renderer_set_render_target(self._h, C.c_void_p(device_ptr) if device_ptr else None, nbytes))
 
     def probe_sample(self, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)

@@ -242,6 +242,7 @@ class Transform(Component):
 
     def __init__(self, node=None):
         super().__init__(node)
+        self.version = 0                      # bumped by every setter (lets callers cache derived matrices)
         self._localRotation = _f32([0, 0, 0, 1])
         self._localTranslation = _f32([0, 0, 0])
         self._localScale = _f32([1, 1, 1])
@@ -253,6 +254,7 @@ class Transform(Component):
     @localRotation.setter
     def localRotation(self, value):
         self._localRotation = quat.clone(value)
+        self.version += 1
         self.dispatchEvent(Event('change'))
 
     @property
@@ -262,6 +264,7 @@ class Transform(Component):
     @localTranslation.setter
     def localTranslation(self, value):
         self._localTranslation = vec3.clone(value)
+        self.version += 1
         self.dispatchEvent(Event('change'))
 
     @property
@@ -271,6 +274,7 @@ class Transform(Component):
     @localScale.setter
     def localScale(self, value):
         self._localScale = vec3.clone(value)
+        self.version += 1
         self.dispatchEvent(Event('change'))
 
     @property

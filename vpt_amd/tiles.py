@@ -1,0 +1,75 @@
+"""Image-plane sharding across the GPUs of one node + the per-frame gather (no reference counterpart).
+
+Rank g of G owns the row blocks b (rows_per_block rows each) with b % G == g.  Blocks are interleaved so that
+cube-hitting and cube-missing rows balance; per-pixel seeds depend on GLOBAL pixel coordinates only, so the
+gathered image is bit-identical to a single-GPU render.  Every rank pads its local buffer to the same number of
+rows, so the frame gather is ONE equal-sized all_gather over RCCL (xGMI is fully connected: each peer's slice
+arrives on its own link); rows are put back in order with one index_select.
+"""
+import numpy as np
+
+ROWS_PER_BLOCK = 8
+
+
+def local_rows(height, world, rows_per_block=ROWS_PER_BLOCK):
+    """rows in every rank's (padded) local buffer — must match vpt_renderer_local_rows"""
+    if world == 1:
+        return height
+    nblocks = (height + rows_per_block - 1) // rows_per_block
+    return ((nblocks + world - 1) // world) * rows_per_block
+
+
+def row_owner(height, world, rows_per_block=ROWS_PER_BLOCK):
+    """for every global row j: (rank, local_row) holding it"""
+    j = np.arange(height)
+    if world == 1:
+        return np.zeros(height, dtype=np.int64), j.astype(np.int64)
+    b = j // rows_per_block
+    return (b % world).astype(np.int64), ((b // world) * rows_per_block + j % rows_per_block).astype(np.int64)
+
+
+def gather_index(height, world, rows_per_block=ROWS_PER_BLOCK):
+    """flat row index into the gathered [world * local_rows] buffer for every global row"""
+    rank, lrow = row_owner(height, world, rows_per_block)
+    return rank * local_rows(height, world, rows_per_block) + lrow
+
+
+class FrameGather:
+    """all_gather of the per-rank RGBA16F render buffers and reassembly into the [H][W][4] frame.
+
+    ``dist`` is torch.distributed (backend nccl == RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, dist, torch, width, height, device, rows_per_block=ROWS_PER_BLOCK, nbuf=2):
+        self.dist, self.torch = dist, torch
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.W, self.H = width, height
+        self.rows = local_rows(height, self.world, rows_per_block)
+        self.rows_per_block = rows_per_block
+        self.send = [torch.zeros((self.rows, width, 4), dtype=torch.float16, device=device) for _ in range(nbuf)]
+        self.recv = [torch.zeros((self.world * self.rows, width, 4), dtype=torch.float16, device=device) for _ in range(nbuf)]
+        self.index = torch.as_tensor(gather_index(height, self.world, rows_per_block), device=device)
+        self.work = [None] * nbuf
+
+    def shard(self):
+        return (self.rank, self.world, self.rows_per_block)
+
+    def wait(self, k):
+        """make the current stream wait for the gather that last used buffer k (before it is overwritten)"""
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+
+    def gather(self, k):
+        """enqueue the all_gather of send[k] into recv[k]; overlaps with whatever is launched next"""
+        if self.world == 1:
+            self.recv[k] = self.send[k]
+            return
+        self.work[k] = self.dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), async_op=True)
+
+    def frame(self, k):
+        """the assembled [H][W][4] frame of buffer k (waits for its gather)"""
+        self.wait(k)
+        if self.world == 1:
+            return self.recv[k][:self.H]
+        return self.recv[k].index_select(0, self.index)
