@@ -153,6 +153,11 @@ VPT_API int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t *la
 #define VPT_PROBE_PCG     5   /* bit patterns: out[i] = pcg(in[i]) */
 #define VPT_PROBE_UNIFORM 6   /* bit pattern state in -> float uniform out */
 #define VPT_PROBE_F16     7   /* out[i] (low 16 bits) = half(in[i]) */
+#define VPT_PROBE_RCP     8   /* software reciprocal rcp_nr */
+#define VPT_PROBE_RSQRT   9   /* software reciprocal square root rsqrt_nr */
+#define VPT_PROBE_MIN     10  /* in = pairs (a, b) ; n outputs */
+#define VPT_PROBE_MAX     11
+#define VPT_PROBE_LOG_UNIFORM 12  /* log on the range of random_uniform */
 VPT_API int vpt_probe_math(vpt_context *ctx, int which, const float *in, float *out, size_t n);
 /* samples texture(uVolume, p) -> transfer function at n positions (xyz triples); out = n RGBA float4 */
 VPT_API int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n);

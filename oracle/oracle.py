@@ -54,6 +54,10 @@ def lib():
         L.vpo_sincosf.restype = None; L.vpo_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.vpo_atan2f.restype = C.c_float; L.vpo_atan2f.argtypes = [C.c_float, C.c_float]
         L.vpo_asinf.restype = C.c_float; L.vpo_asinf.argtypes = [C.c_float]
+        L.vpo_rcp_nr.restype = C.c_float; L.vpo_rcp_nr.argtypes = [C.c_float]
+        L.vpo_rsqrt_nr.restype = C.c_float; L.vpo_rsqrt_nr.argtypes = [C.c_float]
+        L.vpo_min.restype = C.c_float; L.vpo_min.argtypes = [C.c_float, C.c_float]
+        L.vpo_max.restype = C.c_float; L.vpo_max.argtypes = [C.c_float, C.c_float]
         L.vpo_pcg.restype = C.c_uint32; L.vpo_pcg.argtypes = [C.c_uint32]
         L.vpo_hash3.restype = C.c_uint32; L.vpo_hash3.argtypes = [C.c_uint32] * 3
         L.vpo_random_uniform.restype = C.c_float; L.vpo_random_uniform.argtypes = [C.POINTER(C.c_uint32)]

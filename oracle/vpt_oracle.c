@@ -73,8 +73,22 @@ typedef struct {
 /* ------------------------------------------------------------------------------------------
  * GLSL built-ins restated
  * ---------------------------------------------------------------------------------------- */
-static inline float vmin(float a, float b) { return (b < a) ? b : a; }  /* GLSL min(x,y): y<x?y:x */
-static inline float vmax(float a, float b) { return (a < b) ? b : a; }  /* GLSL max(x,y): x<y?y:x */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+/* GLSL min / max (ES 3.00 §8.3: undefined for NaN operands).  Contract: IEEE-754 minNum / maxNum — a NaN operand
+ * yields the other operand, and -0 orders below +0 (what v_min_f32 / v_max_f32 compute on gfx950). */
+static inline float vmin(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == 0.0f && b == 0.0f) return (f2u(a) >> 31) ? a : b;
+    return (b < a) ? b : a;
+}
+static inline float vmax(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == 0.0f && b == 0.0f) return (f2u(a) >> 31) ? b : a;
+    return (a < b) ? b : a;
+}
 static inline float vclamp01(float x) { return vmin(vmax(x, 0.0f), 1.0f); }
 /* GLSL mix(x,y,a) = x*(1-a) + y*a */
 static inline float mixf(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }
@@ -85,8 +99,28 @@ static inline v3 mix3(v3 a, v3 b, float t) {
 static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
 static inline v3 sub3(v3 a, v3 b) { v3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }
+/* software reciprocal: integer seed + 3 Newton-Raphson steps; <= 2 ulp for normal x in [2^-125, 2^125]
+ * (GLSL ES 3.00 §4.5.1 allows 2.5 ULP for a/b).  x = 0, inf, NaN -> NaN.  Used for divisors that cannot be 0 in a
+ * sane scene (homogeneous w, sample counts, segment lengths); slab tests keep IEEE 1/d. */
+VPO_API float vpo_rcp_nr(float x) {
+    float r = u2f(0x7EF311C7u - f2u(x));
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
+/* software reciprocal square root: integer seed + 3 Newton-Raphson steps (normal x > 0) */
+VPO_API float vpo_rsqrt_nr(float x) {
+    float y = u2f(0x5F375A86u - (f2u(x) >> 1));
+    float h = 0.5f * x;
+    y = y * fmaf(-h * y, y, 1.5f);
+    y = y * fmaf(-h * y, y, 1.5f);
+    y = y * fmaf(-h * y, y, 1.5f);
+    return y;
+}
+/* GLSL normalize(v) = v * inversesqrt(dot(v, v)) */
 static inline v3 normalize3(v3 a) {
-    float inv = 1.0f / length3(a);
+    float inv = vpo_rsqrt_nr(dot3(a, a));
     v3 r = { a.x * inv, a.y * inv, a.z * inv };
     return r;
 }
@@ -95,8 +129,6 @@ static inline v3 madd3(v3 p, float t, v3 d) {
     v3 r = { fmaf(t, d.x, p.x), fmaf(t, d.y, p.y), fmaf(t, d.z, p.z) };
     return r;
 }
-static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 /* ------------------------------------------------------------------------------------------
  * deterministic transcendental routines (the contract's log / sin / cos / atan2 / asin)
@@ -211,9 +243,11 @@ VPO_API float vpo_random_uniform(uint32_t *state) {
     *state = vpo_pcg(*state);
     return (float)(*state) * 0x1p-32f;
 }
-/* distribution/exponential.glsl:3-5 */
-static inline float random_exponential(uint32_t *state, float rate) {
-    return -vpo_logf(vpo_random_uniform(state)) / rate;
+/* distribution/exponential.glsl:3-5: -log(u)/rate, evaluated as -log(u) * inv_rate with inv_rate = 1/rate
+ * computed once per pass (contract, DESIGN.md §3: a division by a pass-uniform value is one IEEE reciprocal + multiply;
+ * GLSL ES 3.00 §4.5.1 allows 2.5 ULP for a/b) */
+static inline float random_exponential(uint32_t *state, float inv_rate) {
+    return -vpo_logf(vpo_random_uniform(state)) * inv_rate;
 }
 /* distribution/square.glsl:3-7 */
 static inline v2 random_square(uint32_t *state) {
@@ -300,15 +334,17 @@ static inline int32_t nearest_coord(float s, int32_t n) {
     return (int32_t)floorf(u);
 }
 static inline float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
+/* texel normalisation: one multiply by fl32(1/255) (255 * VPO_INV255 == 1.0f exactly) */
+#define VPO_INV255 0.00392156862745098f
 
 /* texture(uVolume, p).r — R8 normalised, CLAMP_TO_EDGE (Volume.js:49-60).  Interpolates the integer
- * texel values (x, then y, then z) and normalises once by /255. */
+ * texel values (x, then y, then z) and normalises once by * fl32(1/255). */
 static float sample_volume(const vpo_scene *sc, v3 p) {
     const uint8_t *v = sc->volume;
     size_t sx = 1, sy = (size_t)sc->nx, sz = (size_t)sc->nx * (size_t)sc->ny;
     if (sc->filter == 0) {
         int32_t x = nearest_coord(p.x, sc->nx), y = nearest_coord(p.y, sc->ny), z = nearest_coord(p.z, sc->nz);
-        return (float)v[x * sx + y * sy + z * sz] / 255.0f;
+        return (float)v[x * sx + y * sy + z * sz] * VPO_INV255;
     }
     int32_t x0, x1, y0, y1, z0, z1; float fx, fy, fz;
     linear_coord(p.x, sc->nx, &x0, &x1, &fx);
@@ -321,7 +357,7 @@ static float sample_volume(const vpo_scene *sc, v3 p) {
     float c00 = lerpf(c000, c100, fx), c10 = lerpf(c010, c110, fx);
     float c01 = lerpf(c001, c101, fx), c11 = lerpf(c011, c111, fx);
     float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
-    return lerpf(c0, c1, fz) / 255.0f;
+    return lerpf(c0, c1, fz) * VPO_INV255;
 }
 
 /* decoded float4 tables, built once per call */
@@ -400,8 +436,9 @@ static inline v4 mat4_mul_point(const float *m, float x, float y, float z) {
 static inline void unproject(float px, float py, const float *m, v3 *from, v3 *to) {
     v4 n = mat4_mul_point(m, px, py, -1.0f);
     v4 f = mat4_mul_point(m, px, py, 1.0f);
-    from->x = n.x / n.w; from->y = n.y / n.w; from->z = n.z / n.w;
-    to->x = f.x / f.w; to->y = f.y / f.w; to->z = f.z / f.w;
+    float in = vpo_rcp_nr(n.w), jf = vpo_rcp_nr(f.w);   /* xyz / w as xyz * rcp(w) */
+    from->x = n.x * in; from->y = n.y * in; from->z = n.z * in;
+    to->x = f.x * jf; to->y = f.y * jf; to->z = f.z * jf;
 }
 /* pixel centre in NDC: 2*(i+0.5)/W - 1, written (2i+1)/W - 1 */
 static inline float pixel_ndc(int32_t i, int32_t n) { return (float)(2 * i + 1) / (float)n - 1.0f; }
@@ -410,8 +447,9 @@ static inline float ndc_to_uv(float p) { return fmaf(p, 0.5f, 0.5f); }
 
 /* mixins/intersectCube.glsl:3-11 */
 static inline v2 intersect_cube(v3 o, v3 d) {
-    v3 tmin = { (0.0f - o.x) / d.x, (0.0f - o.y) / d.y, (0.0f - o.z) / d.z };
-    v3 tmax = { (1.0f - o.x) / d.x, (1.0f - o.y) / d.y, (1.0f - o.z) / d.z };
+    v3 inv = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };     /* (a - o) / d as (a - o) * (1/d) */
+    v3 tmin = { (0.0f - o.x) * inv.x, (0.0f - o.y) * inv.y, (0.0f - o.z) * inv.z };
+    v3 tmax = { (1.0f - o.x) * inv.x, (1.0f - o.y) * inv.y, (1.0f - o.z) * inv.z };
     v3 t1 = { vmin(tmin.x, tmax.x), vmin(tmin.y, tmax.y), vmin(tmin.z, tmax.z) };
     v3 t2 = { vmax(tmin.x, tmax.x), vmax(tmin.y, tmax.y), vmax(tmin.z, tmax.z) };
     v2 r = { vmax(vmax(t1.x, t1.y), t1.z), vmin(vmin(t2.x, t2.y), t2.z) };
@@ -513,7 +551,7 @@ VPO_API uint64_t vpo_eam_generate(const vpo_scene *sc, const vpo_frame *fr, uint
                     acc.z = fmaf(w, c.z, acc.z); acc.w = fmaf(w, c.w, acc.w);
                     tt += fr->step;
                 }
-                if (acc.w > 1.0f) { acc.x /= acc.w; acc.y /= acc.w; acc.z /= acc.w; }
+                if (acc.w > 1.0f) { float ia = vpo_rcp_nr(acc.w); acc.x *= ia; acc.y *= ia; acc.z *= ia; }
                 o.x = acc.x; o.y = acc.y; o.z = acc.z;
             }
             uint8_t *px = frame + 4 * ((size_t)j * fr->width + i);
@@ -555,26 +593,28 @@ VPO_API void vpo_eam_reset(const vpo_frame *fr, uint8_t *acc) {
 
 /* sampleDistance: MCSRenderer.glsl:70-87.  "dist > maxDistance" is written !(dist <= max) so a NaN
  * segment terminates. */
-static float mcs_sample_distance(const scene_tables *t, uint32_t *state, v3 from, v3 to, float ext, uint64_t *ns) {
+static float mcs_sample_distance(const scene_tables *t, uint32_t *state, v3 from, v3 to, float inv_ext, uint64_t *ns) {
     float max_distance = length3(sub3(from, to));
+    float inv_max = vpo_rcp_nr(max_distance);         /* dist / maxDistance as dist * rcp(maxDistance) */
     float dist = 0.0f;
     for (uint32_t it = 0; it < VPO_MAX_TRACK_ITERS; it++) {
-        dist += random_exponential(state, ext);
+        dist += random_exponential(state, inv_ext);
         if (!(dist <= max_distance)) break;
-        v3 p = mix3(from, to, dist / max_distance);
+        v3 p = mix3(from, to, dist * inv_max);
         v4 ts = sample_volume_color(t, p, ns);
         if (vpo_random_uniform(state) < ts.w) break;
     }
     return dist;
 }
 /* sampleTransmittance: MCSRenderer.glsl:89-105 */
-static float mcs_sample_transmittance(const scene_tables *t, uint32_t *state, v3 from, v3 to, float ext, uint64_t *ns) {
+static float mcs_sample_transmittance(const scene_tables *t, uint32_t *state, v3 from, v3 to, float inv_ext, uint64_t *ns) {
     float max_distance = length3(sub3(from, to));
+    float inv_max = vpo_rcp_nr(max_distance);
     float dist = 0.0f, tr = 1.0f;
     for (uint32_t it = 0; it < VPO_MAX_TRACK_ITERS; it++) {
-        dist += random_exponential(state, ext);
+        dist += random_exponential(state, inv_ext);
         if (!(dist <= max_distance)) break;
-        v3 p = mix3(from, to, dist / max_distance);
+        v3 p = mix3(from, to, dist * inv_max);
         v4 ts = sample_volume_color(t, p, ns);
         tr *= 1.0f - ts.w;
     }
@@ -585,6 +625,7 @@ VPO_API uint64_t vpo_mcs_generate(const vpo_scene *sc, const vpo_frame *fr, floa
     scene_tables t; tables_init(&t, sc);
     uint64_t ns = 0; int nth = clamp_threads(fr);
     v3 L = { fr->light_dir[0], fr->light_dir[1], fr->light_dir[2] };
+    const float inv_ext = 1.0f / fr->extinction;
     FOR_ROWS(fr) {
         for (int32_t i = 0; i < fr->width; i++) {
             float px = pixel_ndc(i, fr->width), py = pixel_ndc(j, fr->height);
@@ -601,17 +642,17 @@ VPO_API uint64_t vpo_mcs_generate(const vpo_scene *sc, const vpo_frame *fr, floa
                 v3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
                 float max_distance = length3(sub3(from, to));
                 uint32_t state = vpo_hash3(f2u(ndc_to_uv(px)), f2u(ndc_to_uv(py)), f2u(fr->seed));
-                float dist = mcs_sample_distance(&t, &state, from, to, fr->extinction, &ns);
+                float dist = mcs_sample_distance(&t, &state, from, to, inv_ext, &ns);
                 if (!(dist <= max_distance)) {
                     o = sample_environment(&t, dir_unit);
                 } else {
-                    from = mix3(from, to, dist / max_distance);
+                    from = mix3(from, to, dist * vpo_rcp_nr(max_distance));
                     v2 tb2 = intersect_cube(from, L);
                     tb2.y = vmax(tb2.y, 0.0f);
                     to = madd3(from, tb2.y, L);
                     v4 diffuse = sample_volume_color(&t, from, &ns);
                     v4 light = sample_environment(&t, L);
-                    float tr = mcs_sample_transmittance(&t, &state, from, to, fr->extinction, &ns);
+                    float tr = mcs_sample_transmittance(&t, &state, from, to, inv_ext, &ns);
                     o.x = (diffuse.x * light.x) * tr; o.y = (diffuse.y * light.y) * tr;
                     o.z = (diffuse.z * light.z) * tr; o.w = (diffuse.w * light.w) * tr;
                 }
@@ -660,15 +701,18 @@ typedef struct {
 
 /* mixins/unprojectRand.glsl:3-24 */
 static void unproject_rand(uint32_t *state, float px, float py, const vpo_frame *fr, v3 *from, v3 *to) {
-    v2 d = random_disk(state);
-    float ox = d.x * fr->blur, oy = d.y * fr->blur;
+    /* random_disk(state) * blur: with blur == 0 the two uniforms are still drawn, and the product is an exact zero */
+    float ox = 0.0f, oy = 0.0f;
+    if (fr->blur == 0.0f) { vpo_random_uniform(state); vpo_random_uniform(state); }
+    else { v2 d = random_disk(state); ox = d.x * fr->blur; oy = d.y * fr->blur; }
     v2 sq = random_square(state);
     float ax = fmaf(sq.x, 2.0f, -1.0f) * fr->inv_res[0];
     float ay = fmaf(sq.y, 2.0f, -1.0f) * fr->inv_res[1];
     v4 n = mat4_mul_point(fr->mvp_inv, px + ox, py + oy, -1.0f);
     v4 f = mat4_mul_point(fr->mvp_inv, px + ax, py + ay, 1.0f);
-    from->x = n.x / n.w; from->y = n.y / n.w; from->z = n.z / n.w;
-    to->x = f.x / f.w; to->y = f.y / f.w; to->z = f.z / f.w;
+    float in = vpo_rcp_nr(n.w), jf = vpo_rcp_nr(f.w);
+    from->x = n.x * in; from->y = n.y * in; from->z = n.z * in;
+    to->x = f.x * jf; to->y = f.y * jf; to->z = f.z * jf;
 }
 /* resetPhoton: MCMRenderer.glsl:70-78 */
 static void reset_photon(uint32_t *state, photon *ph, float px, float py, const vpo_frame *fr) {
@@ -684,8 +728,8 @@ static void reset_photon(uint32_t *state, photon *ph, float px, float py, const 
 /* sampleHenyeyGreensteinAngleCosine: MCMRenderer.glsl:91-95 */
 static float hg_cos(uint32_t *state, float g) {
     float g2 = g * g;
-    float c = (1.0f - g2) / fmaf(2.0f * g, vpo_random_uniform(state), 1.0f - g);
-    return fmaf(-c, c, 1.0f + g2) / (2.0f * g);
+    float c = (1.0f - g2) * vpo_rcp_nr(fmaf(2.0f * g, vpo_random_uniform(state), 1.0f - g));
+    return fmaf(-c, c, 1.0f + g2) * vpo_rcp_nr(2.0f * g);
 }
 /* sampleHenyeyGreenstein: MCMRenderer.glsl:97-106 (EPS 1e-5) */
 static v3 sample_hg(uint32_t *state, float g, v3 dir) {
@@ -743,6 +787,7 @@ VPO_API uint64_t vpo_mcm_integrate(const vpo_scene *sc, const vpo_frame *fr, flo
     float *const st[4] = { s0, s1, s2, s3 };
     const float *const cst[4] = { s0, s1, s2, s3 };
     uint64_t ns = 0; int nth = clamp_threads(fr);
+    const float inv_ext = 1.0f / fr->extinction;
     FOR_ROWS(fr) {
         for (int32_t i = 0; i < fr->width; i++) {
             size_t k = (size_t)j * fr->width + i;
@@ -751,7 +796,7 @@ VPO_API uint64_t vpo_mcm_integrate(const vpo_scene *sc, const vpo_frame *fr, flo
             photon_load(&ph, cst, k);
             uint32_t state = vpo_hash3(f2u(ndc_to_uv(px)), f2u(ndc_to_uv(py)), f2u(fr->seed));
             for (uint32_t s = 0u; s < fr->steps; s++) {
-                float dist = random_exponential(&state, fr->extinction);
+                float dist = random_exponential(&state, inv_ext);
                 ph.position = madd3(ph.position, dist, ph.direction);
                 v4 vs = sample_volume_color(&t, ph.position, &ns);
                 float p_null = 1.0f - vs.w;
@@ -761,21 +806,19 @@ VPO_API uint64_t vpo_mcm_integrate(const vpo_scene *sc, const vpo_frame *fr, flo
                 float p_abs = 1.0f - p_null - p_scat;
                 float wheel = vpo_random_uniform(&state);
                 v3 p = ph.position;
-                if (p.x > 1.0f || p.y > 1.0f || p.z > 1.0f || p.x < 0.0f || p.y < 0.0f || p.z < 0.0f) {
-                    v4 env = sample_environment(&t, ph.direction);
-                    v3 rad = { ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z };
+                int oob = (p.x > 1.0f || p.y > 1.0f || p.z > 1.0f || p.x < 0.0f || p.y < 0.0f || p.z < 0.0f);
+                if (oob || wheel < p_abs) {
+                    /* out of bounds: radiance = transmittance * env ; absorption: radiance = 0 (MCMRenderer.glsl:143-157) */
+                    v3 rad = { 0.0f, 0.0f, 0.0f };
+                    if (oob) {
+                        v4 env = sample_environment(&t, ph.direction);
+                        rad.x = ph.transmittance.x * env.x; rad.y = ph.transmittance.y * env.y; rad.z = ph.transmittance.z * env.z;
+                    }
                     ph.samples++;
-                    float n = (float)ph.samples;
-                    ph.radiance.x += (rad.x - ph.radiance.x) / n;
-                    ph.radiance.y += (rad.y - ph.radiance.y) / n;
-                    ph.radiance.z += (rad.z - ph.radiance.z) / n;
-                    reset_photon(&state, &ph, px, py, fr);
-                } else if (wheel < p_abs) {
-                    ph.samples++;
-                    float n = (float)ph.samples;
-                    ph.radiance.x += (0.0f - ph.radiance.x) / n;
-                    ph.radiance.y += (0.0f - ph.radiance.y) / n;
-                    ph.radiance.z += (0.0f - ph.radiance.z) / n;
+                    float inv_n = vpo_rcp_nr((float)ph.samples);    /* (rad - radiance) / n as * rcp(n) */
+                    ph.radiance.x += (rad.x - ph.radiance.x) * inv_n;
+                    ph.radiance.y += (rad.y - ph.radiance.y) * inv_n;
+                    ph.radiance.z += (rad.z - ph.radiance.z) * inv_n;
                     reset_photon(&state, &ph, px, py, fr);
                 } else if (wheel < p_abs + p_scat) {
                     ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
@@ -827,6 +870,8 @@ VPO_API void vpo_intersect_cube(const float *o3, const float *d3, float *out2) {
     v3 o = { o3[0], o3[1], o3[2] }, d = { d3[0], d3[1], d3[2] };
     v2 r = intersect_cube(o, d); out2[0] = r.x; out2[1] = r.y;
 }
+VPO_API float vpo_min(float a, float b) { return vmin(a, b); }
+VPO_API float vpo_max(float a, float b) { return vmax(a, b); }
 VPO_API int vpo_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -1,10 +1,17 @@
 // vpt_device.h — device-side building blocks of the renderer kernels (gfx950).
 //
 // Numeric contract: IEEE binary32, round-to-nearest-even, contraction OFF
-// (-ffp-contract=off) — every fused multiply-add is an explicit fmaf(); correctly rounded
-// division and sqrt (-fhip-fp32-correctly-rounded-divide-sqrt); denormals kept.
-// log / sin / cos / atan2 / asin are the polynomial routines below, not OCML, so results do not
-// depend on a vendor math library.
+// (-ffp-contract=off) — every fused multiply-add is an explicit fmaf(); IEEE division and sqrt where
+// `/` and sqrtf() are written (-fhip-fp32-correctly-rounded-divide-sqrt); denormals kept.
+// log / sin / cos / atan2 / asin / rcp_nr / rsqrt_nr are the routines below (plain +,*,fma and bit
+// operations), not OCML or the hardware approximations, so results do not depend on a vendor library
+// and the CPU oracle reproduces them bit for bit.
+//
+// Cost model these routines are shaped for (tools/valu_rates.hip, measured on MI355X, >= 4 waves/SIMD):
+// v_fma/v_mul/v_add_f32 ~2.6 cycles per wave64 instruction, every other VALU op (integer, compare,
+// select, convert, min/max) ~4, transcendental (v_rcp, v_sqrt) ~8; an IEEE division expands to ~10
+// instructions (~38 cycles).  The MCM pass is VALU-issue bound, so the rules are: keep float work in
+// fma form, avoid compare+select pairs, move table lookups to LDS (its own issue port).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,20 +22,45 @@ struct f3 { float x, y, z; };
 struct f2 { float x, y; };
 
 // ---- GLSL built-ins ------------------------------------------------------------------------
-VPT_DEV float vmin(float a, float b) { return (b < a) ? b : a; }   // min(x,y) = y<x ? y : x
-VPT_DEV float vmax(float a, float b) { return (a < b) ? b : a; }   // max(x,y) = x<y ? y : x
+// min / max: IEEE minNum / maxNum (a NaN operand yields the other one; -0 < +0) == v_min_f32 / v_max_f32.
+// GLSL leaves NaN operands undefined (ES 3.00 §8.3), so any consistent choice is within the language.
+VPT_DEV float vmin(float a, float b) { return fminf(a, b); }
+VPT_DEV float vmax(float a, float b) { return fmaxf(a, b); }
 VPT_DEV float vclamp01(float x) { return vmin(vmax(x, 0.0f), 1.0f); }
 VPT_DEV float mixf(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }  // x*(1-a)+y*a
 VPT_DEV f3 mix3(f3 a, f3 b, float t) { return f3{ mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t) }; }
 VPT_DEV float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 VPT_DEV float length3(f3 a) { return sqrtf(dot3(a, a)); }
 VPT_DEV f3 sub3(f3 a, f3 b) { return f3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
-VPT_DEV f3 normalize3(f3 a) { float inv = 1.0f / length3(a); return f3{ a.x * inv, a.y * inv, a.z * inv }; }
 VPT_DEV f3 madd3(f3 p, float t, f3 d) { return f3{ fmaf(t, d.x, p.x), fmaf(t, d.y, p.y), fmaf(t, d.z, p.z) }; }
 VPT_DEV float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
 VPT_DEV float4 lerp4(float4 a, float4 b, float f) {
     return make_float4(lerpf(a.x, b.x, f), lerpf(a.y, b.y, f), lerpf(a.z, b.z, f), lerpf(a.w, b.w, f));
 }
+
+// ---- software reciprocal / reciprocal square root ---------------------------------------------
+// rcp_nr(x) ~ 1/x: integer seed + 3 Newton-Raphson steps (7 instructions, ~16 cycles vs ~38 for IEEE `/`);
+// |relative error| < 2.5e-7 (<= 2 ulp) for normal x with 2^-125 <= |x| <= 2^125, within the 2.5 ULP GLSL ES 3.00
+// §4.5.1 allows for a/b.  Used where the divisor cannot be 0/inf in a sane scene (homogeneous w, sample counts,
+// segment lengths); x = 0, inf, NaN give NaN.  Slab tests keep IEEE `/` because 1/0 = +-inf is semantic there.
+VPT_DEV float rcp_nr(float x) {
+    float r = __uint_as_float(0x7EF311C7u - __float_as_uint(x));
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
+// rsqrt_nr(x) ~ 1/sqrt(x) for normal x > 0: integer seed + 3 Newton-Raphson steps; relative error < 3e-7.
+// GLSL normalize(v) = v * inversesqrt(dot(v,v)) (inversesqrt: 2 ULP, ES 3.00 §4.5.1).
+VPT_DEV float rsqrt_nr(float x) {
+    float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
+    float h = 0.5f * x;
+    y = y * fmaf(-h * y, y, 1.5f);
+    y = y * fmaf(-h * y, y, 1.5f);
+    y = y * fmaf(-h * y, y, 1.5f);
+    return y;
+}
+VPT_DEV f3 normalize3(f3 a) { float inv = rsqrt_nr(dot3(a, a)); return f3{ a.x * inv, a.y * inv, a.z * inv }; }
 
 // ---- transcendental routines ---------------------------------------------------------------
 // natural log on {0} U [2^-126, inf]
@@ -56,6 +88,31 @@ VPT_DEV float vpt_logf(float x) {
     if (x == 0.0f) r = -__builtin_inff();
     if (!(x >= 0.0f)) r = __builtin_nanf("");
     if (x == __builtin_inff()) r = __builtin_inff();
+    return r;
+}
+// the same for x = k * 2^-32 (k = 1 .. 2^32, the range of random_uniform except 0): no NaN / inf / negative cases
+VPT_DEV float vpt_logf_uniform(float x) {
+    uint32_t b = __float_as_uint(x);
+    int32_t e = (int32_t)(b >> 23) - 126;
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.70710678118654752440f) { e -= 1; m = m + m - 1.0f; } else { m = m - 1.0f; }
+    float fe = (float)e;
+    float z = m * m;
+    float p = 7.0376836292E-2f;
+    p = fmaf(p, m, -1.1514610310E-1f);
+    p = fmaf(p, m, 1.1676998740E-1f);
+    p = fmaf(p, m, -1.2420140846E-1f);
+    p = fmaf(p, m, 1.4249322787E-1f);
+    p = fmaf(p, m, -1.6668057665E-1f);
+    p = fmaf(p, m, 2.0000714765E-1f);
+    p = fmaf(p, m, -2.4999993993E-1f);
+    p = fmaf(p, m, 3.3333331174E-1f);
+    float y = (p * m) * z;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = fmaf(0.693359375f, fe, r);
+    if (x == 0.0f) r = -__builtin_inff();
     return r;
 }
 
@@ -129,7 +186,8 @@ VPT_DEV uint32_t pcg(uint32_t x) {
 VPT_DEV uint32_t hash3(uint32_t x, uint32_t y, uint32_t z) { return pcg(19u * x + 47u * y + 101u * z + 131u); }
 // float(state)/float(~0u): the divisor rounds to 2^32, the quotient is exact
 VPT_DEV float random_uniform(uint32_t &state) { state = pcg(state); return (float)state * 0x1p-32f; }
-VPT_DEV float random_exponential(uint32_t &state, float rate) { return -vpt_logf(random_uniform(state)) / rate; }
+// -log(u)/rate as -log(u) * inv_rate, inv_rate = 1/rate once per pass (contract)
+VPT_DEV float random_exponential(uint32_t &state, float inv_rate) { return -vpt_logf_uniform(random_uniform(state)) * inv_rate; }
 VPT_DEV f2 random_disk(uint32_t &state) {
     float radius = sqrtf(random_uniform(state));
     float angle = 6.28318530718f * random_uniform(state);
@@ -145,11 +203,7 @@ VPT_DEV f3 random_sphere(uint32_t &state) {
 }
 
 // ---- render-target conversions --------------------------------------------------------------
-VPT_DEV uint32_t to_unorm8(float f) {
-    float c = vclamp01(f);
-    if (c != c) c = 0.0f;
-    return (uint32_t)rintf(c * 255.0f);
-}
+VPT_DEV uint32_t to_unorm8(float f) { return (uint32_t)rintf(vclamp01(f) * 255.0f); }   // NaN -> 0 (maxNum)
 VPT_DEV float from_unorm8(uint32_t c) { return (float)c / 255.0f; }
 VPT_DEV uint16_t to_half_bits(float f) { return __half_as_ushort(__float2half_rn(f)); }
 
@@ -164,39 +218,49 @@ VPT_DEV float4 mat4_mul_point(const Mat4 &M, float x, float y, float z) {
     r.w = fmaf(m[15], 1.0f, fmaf(m[11], z, fmaf(m[7], y, m[3] * x)));
     return r;
 }
+VPT_DEV f3 dehomogenize(float4 v) { float i = rcp_nr(v.w); return f3{ v.x * i, v.y * i, v.z * i }; }   // xyz / w
 // mixins/unproject.glsl:3-10
 VPT_DEV void unproject(float px, float py, const Mat4 &M, f3 &from, f3 &to) {
-    float4 n = mat4_mul_point(M, px, py, -1.0f);
-    float4 f = mat4_mul_point(M, px, py, 1.0f);
-    from = f3{ n.x / n.w, n.y / n.w, n.z / n.w };
-    to = f3{ f.x / f.w, f.y / f.w, f.z / f.w };
+    from = dehomogenize(mat4_mul_point(M, px, py, -1.0f));
+    to = dehomogenize(mat4_mul_point(M, px, py, 1.0f));
 }
 VPT_DEV float pixel_ndc(int i, int n) { return (float)(2 * i + 1) / (float)n - 1.0f; }
 VPT_DEV float ndc_to_uv(float p) { return fmaf(p, 0.5f, 0.5f); }
 
-// mixins/intersectCube.glsl:3-11
+// mixins/intersectCube.glsl:3-11; (a - o) / d as (a - o) * (1/d) with an IEEE reciprocal (1/0 = +-inf matters)
+VPT_DEV f3 cube_inv_dir(f3 d) { return f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z }; }
 VPT_DEV f2 intersect_cube(f3 o, f3 d) {
-    f3 tmin = { (0.0f - o.x) / d.x, (0.0f - o.y) / d.y, (0.0f - o.z) / d.z };
-    f3 tmax = { (1.0f - o.x) / d.x, (1.0f - o.y) / d.y, (1.0f - o.z) / d.z };
+    f3 inv = cube_inv_dir(d);
+    f3 tmin = { (0.0f - o.x) * inv.x, (0.0f - o.y) * inv.y, (0.0f - o.z) * inv.z };
+    f3 tmax = { (1.0f - o.x) * inv.x, (1.0f - o.y) * inv.y, (1.0f - o.z) * inv.z };
     f3 t1 = { vmin(tmin.x, tmax.x), vmin(tmin.y, tmax.y), vmin(tmin.z, tmax.z) };
     f3 t2 = { vmax(tmin.x, tmax.x), vmax(tmin.y, tmax.y), vmax(tmin.z, tmax.z) };
     return f2{ vmax(vmax(t1.x, t1.y), t1.z), vmin(vmin(t2.x, t2.y), t2.z) };
 }
+// only tnear (resetPhoton, MCMRenderer.glsl:75-76)
+VPT_DEV float intersect_cube_near(f3 o, f3 d) {
+    f3 inv = cube_inv_dir(d);
+    float ax = vmin((0.0f - o.x) * inv.x, (1.0f - o.x) * inv.x);
+    float ay = vmin((0.0f - o.y) * inv.y, (1.0f - o.y) * inv.y);
+    float az = vmin((0.0f - o.z) * inv.z, (1.0f - o.z) * inv.z);
+    return vmax(vmax(ax, ay), az);
+}
 
 // ---- bricked Z-order volume -------------------------------------------------------------------
-// Layout: 4^3-voxel bricks stored with a +1 apron = 5^3 = 125 bytes in a 128-byte
-// slot (one L2 line holds every tap of a trilinear sample); brick (bx,by,bz) sits at slot
-// morton3(bx,by,bz).  Inside a slot the byte of local voxel (lx,ly,lz) in [0,5)^3 is lz*25+ly*5+lx.
+// Layout in HBM: 4^3-voxel bricks stored with a +1 apron = 5^3 = 125 bytes in a 128-byte slot
+// (one L2 line holds every tap of a trilinear sample); brick (bx,by,bz) sits at slot morton3(bx,by,bz).
+// Inside a slot the byte of local voxel (lx,ly,lz) in [0,5)^3 is lz*25 + ly*5 + lx.
+//
+// Addressing: the byte offset of voxel cell (x,y,z) is SEPARABLE:
+//     off(x,y,z) = TX[x] + TY[y] + TZ[z],   TX[i] = (spread3(i>>2) << 7) + (i&3),
+//                                             TY[i] = (spread3(i>>2) << 8) + (i&3)*5,
+//                                             TZ[i] = (spread3(i>>2) << 9) + (i&3)*25
+// The three tables (nx+ny+nz dwords) are staged in LDS once per workgroup, so a sample's address costs three
+// ds_read_b32 and one v_add3_u32 instead of ~30 VALU instructions of bit interleaving, and the 32-bit sum feeds
+// global_load's SGPR-base + VGPR-offset form directly (bricked size <= 4 GiB; WIDE tables are 64-bit otherwise).
 #define VPT_BRICK        4
 #define VPT_BRICK_SHIFT  2
 #define VPT_BRICK_BYTES  128
-
-struct DevVolume {
-    const uint8_t *bricks;
-    int nx, ny, nz;
-    float fnx, fny, fnz;
-    int filter;            // VPT_FILTER_*
-};
 
 VPT_DEV uint32_t spread3(uint32_t x) {   // 10 bits -> every third bit
     x = (x | (x << 16)) & 0x030000FFu;
@@ -208,43 +272,59 @@ VPT_DEV uint32_t spread3(uint32_t x) {   // 10 bits -> every third bit
 VPT_DEV uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
     return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
 }
-VPT_DEV const uint8_t *brick_addr(const DevVolume &v, int x, int y, int z) {
-    uint32_t slot = morton3((uint32_t)x >> VPT_BRICK_SHIFT, (uint32_t)y >> VPT_BRICK_SHIFT, (uint32_t)z >> VPT_BRICK_SHIFT);
-    uint32_t off = (uint32_t)(z & 3) * 25u + (uint32_t)(y & 3) * 5u + (uint32_t)(x & 3);
-    return v.bricks + ((size_t)slot << 7) + off;
-}
-// LINEAR coordinate: u = s*N - 0.5 clamped to [-1, N]; cell index remapped so that both taps live in
-// one apron brick: i = -1 -> (0, f = 0); i = N -> N-1 (both taps equal the edge voxel there).
-VPT_DEV void linear_cell(float s, float fn, int n, int &i, float &f) {
+
+struct DevVolume {
+    const uint8_t *bricks;
+    const uint32_t *tab32;   // TX | TY | TZ (nx + ny + nz entries), 32-bit offsets
+    const uint64_t *tab64;   // same, 64-bit (bricked size > 4 GiB)
+    int nx, ny, nz;
+    float fnx, fny, fnz;     // (float)n
+    float hx, hy, hz;        // (float)(n - 1)
+    int filter;              // VPT_FILTER_*
+};
+// LDS image of the per-workgroup tables: [tf pairs][TX][TY][TZ]
+struct LdsTables {
+    const float4 *tf;        // tf_w pairs: { t[i], t[min(i+1,w-1)] - t[i] }
+    const uint32_t *tx, *ty, *tz;
+};
+
+// LINEAR filter cell: u = s*N - 0.5 clamped to [0, N-1]; i = trunc(u); f = u - i.
+// Equal to the GL definition (taps clamp(i0), clamp(i0+1) of the unclamped u; oracle linear_coord) because every
+// clamped case degenerates to an exact edge value: u < 0 -> (t[0], f = 0); u >= N-1 -> (t[N-1], apron = t[N-1]).
+VPT_DEV void linear_cell(float s, float fn, float hi, uint32_t &i, float &f) {
     float u = fmaf(s, fn, -0.5f);
-    if (!(u > -1.0f)) u = -1.0f;
-    if (u > fn) u = fn;
+    u = vmin(vmax(u, 0.0f), hi);       // NaN -> 0 (maxNum)
     float fl = floorf(u);
     f = u - fl;
-    i = (int)fl;
-    if (i < 0) { i = 0; f = 0.0f; }
-    if (i > n - 1) i = n - 1;
+    i = (uint32_t)fl;
 }
-VPT_DEV int nearest_cell(float s, float fn, int n) {
-    float u = s * fn;
-    if (!(u > 0.0f)) u = 0.0f;
-    float hi = (float)(n - 1);
-    if (u > hi) u = hi;
-    return (int)floorf(u);
+VPT_DEV uint32_t nearest_cell(float s, float fn, float hi) {
+    float u = vmin(vmax(s * fn, 0.0f), hi);
+    return (uint32_t)u;                // u >= 0: truncation == floor
 }
 // texture(uVolume, p).r for an R8 volume (Volume.js:49-60): integer texel values interpolated x, y, z,
-// normalised once by /255.
-VPT_DEV float sample_volume(const DevVolume &v, f3 p) {
-    if (v.filter == 0) {
-        int x = nearest_cell(p.x, v.fnx, v.nx), y = nearest_cell(p.y, v.fny, v.ny), z = nearest_cell(p.z, v.fnz, v.nz);
-        return (float)(*brick_addr(v, x, y, z)) / 255.0f;
+// normalised once by * fl32(1/255)  (255 * VPT_INV255 == 1.0f exactly).
+#define VPT_INV255 0.00392156862745098f
+template <bool WIDE>
+VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_t x, uint32_t y, uint32_t z) {
+    if (WIDE) {
+        const uint64_t *tx = (const uint64_t *)t.tx, *ty = (const uint64_t *)t.ty, *tz = (const uint64_t *)t.tz;
+        return v.bricks + (tx[x] + ty[y] + tz[z]);
     }
-    int x, y, z; float fx, fy, fz;
-    linear_cell(p.x, v.fnx, v.nx, x, fx);
-    linear_cell(p.y, v.fny, v.ny, y, fy);
-    linear_cell(p.z, v.fnz, v.nz, z, fz);
-    const uint8_t *a = brick_addr(v, x, y, z);
-    // taps: +0,+1 (y,z) ; +5,+6 (y+1,z) ; +25,+26 (y,z+1) ; +30,+31 (y+1,z+1): two 8-byte windows
+    return v.bricks + (uint32_t)(t.tx[x] + t.ty[y] + t.tz[z]);
+}
+template <bool WIDE>
+VPT_DEV float sample_volume(const DevVolume &v, const LdsTables &t, f3 p) {
+    if (v.filter == 0) {
+        uint32_t x = nearest_cell(p.x, v.fnx, v.hx), y = nearest_cell(p.y, v.fny, v.hy), z = nearest_cell(p.z, v.fnz, v.hz);
+        return (float)(*cell_addr<WIDE>(v, t, x, y, z)) * VPT_INV255;
+    }
+    uint32_t x, y, z; float fx, fy, fz;
+    linear_cell(p.x, v.fnx, v.hx, x, fx);
+    linear_cell(p.y, v.fny, v.hy, y, fy);
+    linear_cell(p.z, v.fnz, v.hz, z, fz);
+    const uint8_t *a = cell_addr<WIDE>(v, t, x, y, z);
+    // taps: +0,+1 (y,z) ; +5,+6 (y+1,z) ; +25,+26 (y,z+1) ; +30,+31 (y+1,z+1): two 8-byte windows of one line
     uint64_t w0, w1;
     __builtin_memcpy(&w0, a, 8);
     __builtin_memcpy(&w1, a + 25, 8);
@@ -256,21 +336,20 @@ VPT_DEV float sample_volume(const DevVolume &v, f3 p) {
     float c00 = lerpf(c000, c100, fx), c10 = lerpf(c010, c110, fx);
     float c01 = lerpf(c001, c101, fx), c11 = lerpf(c011, c111, fx);
     float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
-    return lerpf(c0, c1, fz) / 255.0f;
+    return lerpf(c0, c1, fz) * VPT_INV255;
 }
 
-// transfer function: row 0 of the decoded SRGB8_ALPHA8 table, LINEAR / CLAMP_TO_EDGE, staged in LDS.
-// (R8 volume => lookup at (r, 0): both bilinear rows clamp to row 0, so row 0 alone is exact.)
-VPT_DEV float4 sample_tf(const float4 *tf, int tf_w, float tf_fw, float r) {
+// transfer function: row 0 of the decoded SRGB8_ALPHA8 table, LINEAR / CLAMP_TO_EDGE, staged in LDS as
+// (value, forward difference) pairs.  R8 volume => lookup at (r, 0): both bilinear rows clamp to row 0, so row 0
+// alone is exact.  Same clamping argument as linear_cell.
+VPT_DEV float4 sample_tf(const float4 *tf_pairs, float tf_fw, float tf_hi, float r) {
     float u = fmaf(r, tf_fw, -0.5f);
-    if (!(u > -1.0f)) u = -1.0f;
-    if (u > tf_fw) u = tf_fw;
+    u = vmin(vmax(u, 0.0f), tf_hi);
     float fl = floorf(u);
     float f = u - fl;
-    int i = (int)fl;
-    int i0 = max(i, 0), i1 = min(i + 1, tf_w - 1);
-    i0 = min(i0, tf_w - 1);
-    return lerp4(tf[i0], tf[i1], f);
+    uint32_t i = (uint32_t)fl;
+    float4 a = tf_pairs[2 * i], d = tf_pairs[2 * i + 1];
+    return make_float4(fmaf(f, d.x, a.x), fmaf(f, d.y, a.y), fmaf(f, d.z, a.z), fmaf(f, d.w, a.w));
 }
 
 // environment map (RGBA8 decoded to float4 in HBM): MCSRenderer.glsl:59-62 / MCMRenderer.glsl:80-83

@@ -46,6 +46,9 @@ struct vpt_volume {
     uint8_t *linear;       // nx*ny*nz, the "texture storage" blocks are uploaded into
     uint8_t *bricks;       // apron bricks, Morton order
     size_t brick_bytes;
+    uint32_t *tab32;       // separable brick-offset tables TX | TY | TZ (vpt_device.h), 32-bit form
+    uint64_t *tab64;       // 64-bit form (always built; used when brick_bytes > 4 GiB)
+    bool wide;
     bool dirty;            // blocks uploaded since the last brickify
     bool any_upload;
     uint8_t *staging; size_t staging_bytes;
@@ -165,6 +168,19 @@ extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format
         return fail(VPT_ERR_HIP, "hipMalloc volume %dx%dx%d: %s", w, h, d, hipGetErrorString(e));
     }
     HIP_TRY(hipMemsetAsync(v->linear, 0, (size_t)w * h * d, c->stream));   // texStorage3D zero-initialises
+    {   // offset tables: off(x,y,z) = TX[x] + TY[y] + TZ[z]
+        std::vector<uint64_t> t64((size_t)w + h + d);
+        std::vector<uint32_t> t32(t64.size());
+        for (int i = 0; i < w; i++) t64[i] = ((uint64_t)host_spread3(i >> 2) << 7) + (uint64_t)(i & 3);
+        for (int i = 0; i < h; i++) t64[(size_t)w + i] = ((uint64_t)host_spread3(i >> 2) << 8) + (uint64_t)(i & 3) * 5;
+        for (int i = 0; i < d; i++) t64[(size_t)w + h + i] = ((uint64_t)host_spread3(i >> 2) << 9) + (uint64_t)(i & 3) * 25;
+        for (size_t i = 0; i < t64.size(); i++) t32[i] = (uint32_t)t64[i];
+        v->wide = v->brick_bytes > 0xffffffffull;
+        HIP_TRY(hipMalloc(&v->tab32, t32.size() * 4));
+        HIP_TRY(hipMalloc(&v->tab64, t64.size() * 8));
+        HIP_TRY(hipMemcpy(v->tab32, t32.data(), t32.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(v->tab64, t64.data(), t64.size() * 8, hipMemcpyHostToDevice));
+    }
     v->dirty = true;
     *out = v;
     return VPT_OK;
@@ -236,6 +252,8 @@ extern "C" int vpt_volume_destroy(vpt_volume *v) {
     if (v->linear) hipFree(v->linear);
     if (v->bricks) hipFree(v->bricks);
     if (v->staging) hipFree(v->staging);
+    if (v->tab32) hipFree(v->tab32);
+    if (v->tab64) hipFree(v->tab64);
     delete v;
     return VPT_OK;
 }
@@ -405,14 +423,17 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         vpt_volume *v = r->vol;
         a->vol.bricks = v->bricks; a->vol.nx = v->nx; a->vol.ny = v->ny; a->vol.nz = v->nz;
         a->vol.fnx = (float)v->nx; a->vol.fny = (float)v->ny; a->vol.fnz = (float)v->nz;
+        a->vol.hx = (float)(v->nx - 1); a->vol.hy = (float)(v->ny - 1); a->vol.hz = (float)(v->nz - 1);
+        a->vol.tab32 = v->tab32; a->vol.tab64 = v->tab64;
         a->vol.filter = v->filter;
     }
     a->env.texels = r->env; a->env.w = r->env_w; a->env.h = r->env_h; a->env.constant = r->env_const;
-    a->tf = r->tf; a->tf_w = r->tf_w; a->tf_fw = (float)r->tf_w;
+    a->tf = r->tf; a->tf_w = r->tf_w; a->tf_fw = (float)r->tf_w; a->tf_hi = (float)(r->tf_w - 1);
     if (u) {
         memcpy(a->mvp_inv.m, u->mvp_inverse, sizeof(float) * 16);
         a->seed = u->rand_seed; a->offset = u->offset; a->step = u->step_size;
         a->extinction = u->extinction; a->anisotropy = u->anisotropy;
+        a->inv_extinction = 1.0f / u->extinction;      // -log(u)/rate is evaluated as -log(u) * (1/rate)
         a->max_bounces = u->max_bounces; a->steps = u->steps;
         a->light = f3{ u->light_direction[0], u->light_direction[1], u->light_direction[2] };
         a->mix = u->mix; a->blur = u->blur;
@@ -425,7 +446,23 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
     a->samples = r->samples;
     return VPT_OK;
 }
-static size_t tf_lds_bytes(const vpt_renderer *r) { return (size_t)r->tf_w * sizeof(float4); }
+// dynamic LDS of the sampling kernels: transfer-function pairs + the three brick-offset tables
+static size_t lds_bytes(const vpt_renderer *r) {
+    const vpt_volume *v = r->vol;
+    return (size_t)r->tf_w * 2 * sizeof(float4) + (size_t)(v->nx + v->ny + v->nz) * (v->wide ? 8 : 4);
+}
+template <typename K>
+static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigned grid) {
+    size_t lds = lds_bytes(r);
+    if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(VPT_BLOCK), lds, r->ctx->stream, a);
+    return VPT_OK;
+}
+// picks the 32-bit or 64-bit offset-table instantiation
+#define LAUNCH_S(kernel_narrow, kernel_wide, r, a) \
+    VPT_TRY((r)->vol->wide ? launch_sampling(kernel_wide, (r), (a), (unsigned)(r)->ntiles) \
+                           : launch_sampling(kernel_narrow, (r), (a), (unsigned)(r)->ntiles))
 
 static int check_step(const vpt_uniforms *u) {
     // step sizes <= 0 or NaN would never advance t: the reference's spinner enforces min 1 (MIPRenderer.js:24, EAMRenderer.js:34)
@@ -476,9 +513,9 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
     {
         Timed t(r, true);
         switch (r->kind) {
-            case VPT_RENDERER_MIP: LAUNCH(k_mip<0>, r, a, tf_lds_bytes(r)); break;
-            case VPT_RENDERER_EAM: LAUNCH(k_eam<0>, r, a, tf_lds_bytes(r)); break;
-            case VPT_RENDERER_MCS: LAUNCH(k_mcs<0>, r, a, tf_lds_bytes(r)); break;
+            case VPT_RENDERER_MIP: LAUNCH_S((k_mip<0, false>), (k_mip<0, true>), r, a); break;
+            case VPT_RENDERER_EAM: LAUNCH_S((k_eam<0, false>), (k_eam<0, true>), r, a); break;
+            case VPT_RENDERER_MCS: LAUNCH_S((k_mcs<0, false>), (k_mcs<0, true>), r, a); break;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -495,7 +532,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_integrate, r, a, 0); break;
         case VPT_RENDERER_MCM: {
             Timed t(r, true);
-            LAUNCH(k_mcm_integrate<false>, r, a, tf_lds_bytes(r));
+            LAUNCH_S((k_mcm_integrate<false, false>), (k_mcm_integrate<false, true>), r, a);
             r->samples_host += r->valid_pixels * (uint64_t)u->steps;   // exactly W*H*steps per pass (MCMRenderer.glsl:129-133)
         } break;
     }
@@ -525,11 +562,11 @@ extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
     {
         Timed t(r, true);
         switch (r->kind) {
-            case VPT_RENDERER_MIP: LAUNCH(k_mip<1>, r, a, tf_lds_bytes(r)); break;
-            case VPT_RENDERER_EAM: LAUNCH(k_eam<1>, r, a, tf_lds_bytes(r)); break;
-            case VPT_RENDERER_MCS: LAUNCH(k_mcs<1>, r, a, tf_lds_bytes(r)); break;
+            case VPT_RENDERER_MIP: LAUNCH_S((k_mip<1, false>), (k_mip<1, true>), r, a); break;
+            case VPT_RENDERER_EAM: LAUNCH_S((k_eam<1, false>), (k_eam<1, true>), r, a); break;
+            case VPT_RENDERER_MCS: LAUNCH_S((k_mcs<1, false>), (k_mcs<1, true>), r, a); break;
             case VPT_RENDERER_MCM:
-                LAUNCH(k_mcm_integrate<true>, r, a, tf_lds_bytes(r));
+                LAUNCH_S((k_mcm_integrate<true, false>), (k_mcm_integrate<true, true>), r, a);
                 r->samples_host += r->valid_pixels * (uint64_t)u->steps;
                 break;
         }
@@ -632,10 +669,10 @@ extern "C" int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t 
 // ---------------------------------------------------------------------------------------------
 extern "C" int vpt_probe_math(vpt_context *c, int which, const float *in, float *out, size_t n) {
     if (!c || !in || !out) return fail(VPT_ERR_INVALID, "null argument");
-    if (which < 0 || which > VPT_PROBE_F16) return fail(VPT_ERR_INVALID, "unknown probe %d", which);
+    if (which < 0 || which > VPT_PROBE_LOG_UNIFORM) return fail(VPT_ERR_INVALID, "unknown probe %d", which);
     if (n == 0) return VPT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    size_t nin = (which == VPT_PROBE_ATAN2) ? 2 * n : n;
+    size_t nin = (which == VPT_PROBE_ATAN2 || which == VPT_PROBE_MIN || which == VPT_PROBE_MAX) ? 2 * n : n;
     float *din = nullptr, *dout = nullptr;
     HIP_TRY(hipMalloc(&din, nin * sizeof(float)));
     hipError_t e = hipMalloc(&dout, n * sizeof(float));
@@ -664,7 +701,10 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
     if (e != hipSuccess) { hipFree(din); return fail(VPT_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpyAsync(din, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_probe_sample, dim3((unsigned)((n + 255) / 256)), dim3(VPT_BLOCK), tf_lds_bytes(r), c->stream, a, din, dout, n);
+        if (r->vol->wide)
+            hipLaunchKernelGGL(k_probe_sample<true>, dim3((unsigned)((n + 255) / 256)), dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n);
+        else
+            hipLaunchKernelGGL(k_probe_sample<false>, dim3((unsigned)((n + 255) / 256)), dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(rgba, dout, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);

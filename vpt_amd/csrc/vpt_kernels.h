@@ -6,6 +6,8 @@
 // therefore a compact sub-volume in that XCD's L2.  Per-pixel buffers (frame, accumulation, MCM photon
 // state) are stored in THREAD order (tile-major), so every wave access is one contiguous 64*size
 // segment; only the RGBA16F render buffer — the product handed to the caller — is row-major.
+// LDS per workgroup: the transfer function as (value, difference) pairs and the three brick-offset
+// tables of the volume (vpt_device.h), staged once at kernel entry.
 #pragma once
 #include "vpt_device.h"
 
@@ -45,9 +47,9 @@ struct PassArgs {
     PixMap pm;
     DevVolume vol;
     DevEnv env;
-    const float4 *tf; int tf_w; float tf_fw;
+    const float4 *tf; int tf_w; float tf_fw, tf_hi;   // decoded row 0 of the transfer function; (float)w, (float)(w-1)
     Mat4 mvp_inv;
-    float seed, offset, step, extinction, anisotropy;
+    float seed, offset, step, extinction, inv_extinction, anisotropy;
     uint32_t max_bounces, steps;
     f3 light;
     float mix, blur, inv_w, inv_h;
@@ -58,14 +60,34 @@ struct PassArgs {
     unsigned long long *samples; // volume-sample counter
 };
 
-VPT_DEV void stage_tf(float4 *lds, const PassArgs &a) {
-    for (int t = (int)threadIdx.x; t < a.tf_w; t += VPT_BLOCK) lds[t] = a.tf[t];
+// dynamic LDS: [tf pairs: tf_w * 2 float4][TX nx][TY ny][TZ nz] (table entries 4 B, or 8 B when WIDE)
+template <bool WIDE>
+VPT_DEV LdsTables stage_lds(float4 *lds, const PassArgs &a) {
+    for (int t = (int)threadIdx.x; t < a.tf_w; t += VPT_BLOCK) {
+        float4 v = a.tf[t], n = a.tf[min(t + 1, a.tf_w - 1)];
+        lds[2 * t] = v;
+        lds[2 * t + 1] = make_float4(n.x - v.x, n.y - v.y, n.z - v.z, n.w - v.w);
+    }
+    int ntab = a.vol.nx + a.vol.ny + a.vol.nz;
+    uint32_t *tab = (uint32_t *)(lds + 2 * a.tf_w);
+    if (WIDE) {
+        uint64_t *t64 = (uint64_t *)tab;
+        for (int t = (int)threadIdx.x; t < ntab; t += VPT_BLOCK) t64[t] = a.vol.tab64[t];
+    } else {
+        for (int t = (int)threadIdx.x; t < ntab; t += VPT_BLOCK) tab[t] = a.vol.tab32[t];
+    }
     __syncthreads();
+    LdsTables r;
+    r.tf = lds;
+    int s = WIDE ? 2 : 1;
+    r.tx = tab; r.ty = tab + s * a.vol.nx; r.tz = tab + s * (a.vol.nx + a.vol.ny);
+    return r;
 }
 // sampleVolumeColor: MIPRenderer.glsl:45-49 (= EAM :46-50, MCS :64-68, MCM :85-89)
-VPT_DEV float4 sample_volume_color(const PassArgs &a, const float4 *tf_lds, f3 p) {
-    float r = sample_volume(a.vol, p);
-    return sample_tf(tf_lds, a.tf_w, a.tf_fw, r);
+template <bool WIDE>
+VPT_DEV float4 sample_volume_color(const PassArgs &a, const LdsTables &t, f3 p) {
+    float r = sample_volume<WIDE>(a.vol, t, p);
+    return sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
 }
 VPT_DEV void count_samples(unsigned long long *ctr, uint32_t n) {
     for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
@@ -82,7 +104,8 @@ VPT_DEV uint2 pack_half4(float x, float y, float z, float w) {
 // MIP — MIPRenderer.glsl
 // =============================================================================================
 // generate/fragment main(): MIPRenderer.glsl:51-72; returns the unorm8 frame value
-VPT_DEV uint32_t mip_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p, uint32_t &ns) {
+template <bool WIDE>
+VPT_DEV uint32_t mip_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
     f3 rf, rt;
     unproject(pixel_ndc(p.i, a.pm.W), pixel_ndc(p.j, a.pm.H), a.mvp_inv, rf, rt);
     f3 dir = sub3(rt, rf);
@@ -94,7 +117,7 @@ VPT_DEV uint32_t mip_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p
         float tt = 0.0f, val = 0.0f, offset = a.offset;
         do {
             f3 pos = mix3(from, to, offset);
-            val = vmax(sample_volume_color(a, tf_lds, pos).w, val);
+            val = vmax(sample_volume_color<WIDE>(a, t, pos).w, val);
             ns++;
             tt += a.step;
             float m = offset + a.step;
@@ -106,14 +129,14 @@ VPT_DEV uint32_t mip_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p
 }
 // MODE 0: _generateFrame only (frame <- value).  MODE 1: whole render(): generate, integrate
 // (MIPRenderer.glsl:105-109, max on unorm8), renderFrame (:141-144) in one pass.
-template <int MODE>
+template <int MODE, bool WIDE>
 __global__ void __launch_bounds__(VPT_BLOCK) k_mip(PassArgs a) {
-    extern __shared__ float4 tf_lds[];
-    stage_tf(tf_lds, a);
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<WIDE>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        uint32_t q = mip_pixel(a, tf_lds, p, ns);
+        uint32_t q = mip_pixel<WIDE>(a, t, p, ns);
         uint8_t *frame = (uint8_t *)a.frame, *acc = (uint8_t *)a.acc;
         if (MODE == 0) {
             frame[p.k] = (uint8_t)q;
@@ -148,7 +171,8 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mip_reset(PassArgs a) {   // MIPR
 // EAM — EAMRenderer.glsl
 // =============================================================================================
 // generate/fragment main(): EAMRenderer.glsl:52-80; returns packed RGBA8
-VPT_DEV uint32_t eam_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p, uint32_t &ns) {
+template <bool WIDE>
+VPT_DEV uint32_t eam_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
     f3 rf, rt;
     unproject(pixel_ndc(p.i, a.pm.W), pixel_ndc(p.j, a.pm.H), a.mvp_inv, rf, rt);
     f3 dir = sub3(rt, rf);
@@ -163,7 +187,7 @@ VPT_DEV uint32_t eam_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p
         float kk = ray_step_length * a.extinction;
         while (tt < 1.0f && aw < 0.99f) {
             f3 pos = mix3(from, to, tt);
-            float4 c = sample_volume_color(a, tf_lds, pos);
+            float4 c = sample_volume_color<WIDE>(a, t, pos);
             ns++;
             c.w *= kk;
             c.x *= c.w; c.y *= c.w; c.z *= c.w;
@@ -171,7 +195,7 @@ VPT_DEV uint32_t eam_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p
             ax = fmaf(w, c.x, ax); ay = fmaf(w, c.y, ay); az = fmaf(w, c.z, az); aw = fmaf(w, c.w, aw);
             tt += a.step;
         }
-        if (aw > 1.0f) { ax /= aw; ay /= aw; az /= aw; }
+        if (aw > 1.0f) { float ia = rcp_nr(aw); ax *= ia; ay *= ia; az *= ia; }
         ox = ax; oy = ay; oz = az;
     }
     return to_unorm8(ox) | (to_unorm8(oy) << 8) | (to_unorm8(oz) << 16) | (255u << 24);
@@ -189,14 +213,14 @@ VPT_DEV uint2 eam_to_half4(uint32_t q) {   // render: EAMRenderer.glsl:151-153
     return pack_half4(from_unorm8(q & 0xffu), from_unorm8((q >> 8) & 0xffu),
                       from_unorm8((q >> 16) & 0xffu), from_unorm8(q >> 24));
 }
-template <int MODE>
+template <int MODE, bool WIDE>
 __global__ void __launch_bounds__(VPT_BLOCK) k_eam(PassArgs a) {
-    extern __shared__ float4 tf_lds[];
-    stage_tf(tf_lds, a);
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<WIDE>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        uint32_t q = eam_pixel(a, tf_lds, p, ns);
+        uint32_t q = eam_pixel<WIDE>(a, t, p, ns);
         uint32_t *frame = (uint32_t *)a.frame, *acc = (uint32_t *)a.acc;
         if (MODE == 0) {
             frame[p.k] = q;
@@ -228,35 +252,40 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_eam_reset(PassArgs a) {   // EAMR
 // MCS — MCSRenderer.glsl
 // =============================================================================================
 // sampleDistance: MCSRenderer.glsl:70-87
-VPT_DEV float mcs_sample_distance(const PassArgs &a, const float4 *tf_lds, uint32_t &state, f3 from, f3 to, uint32_t &ns) {
+template <bool WIDE>
+VPT_DEV float mcs_sample_distance(const PassArgs &a, const LdsTables &t, uint32_t &state, f3 from, f3 to, uint32_t &ns) {
     float max_distance = length3(sub3(from, to));
+    float inv_max = rcp_nr(max_distance);
     float dist = 0.0f;
     for (uint32_t it = 0; it < VPT_MAX_TRACK_ITERS; it++) {
-        dist += random_exponential(state, a.extinction);
+        dist += random_exponential(state, a.inv_extinction);
         if (!(dist <= max_distance)) break;
-        f3 p = mix3(from, to, dist / max_distance);
-        float4 ts = sample_volume_color(a, tf_lds, p);
+        f3 p = mix3(from, to, dist * inv_max);
+        float4 ts = sample_volume_color<WIDE>(a, t, p);
         ns++;
         if (random_uniform(state) < ts.w) break;
     }
     return dist;
 }
 // sampleTransmittance: MCSRenderer.glsl:89-105
-VPT_DEV float mcs_sample_transmittance(const PassArgs &a, const float4 *tf_lds, uint32_t &state, f3 from, f3 to, uint32_t &ns) {
+template <bool WIDE>
+VPT_DEV float mcs_sample_transmittance(const PassArgs &a, const LdsTables &t, uint32_t &state, f3 from, f3 to, uint32_t &ns) {
     float max_distance = length3(sub3(from, to));
+    float inv_max = rcp_nr(max_distance);
     float dist = 0.0f, tr = 1.0f;
     for (uint32_t it = 0; it < VPT_MAX_TRACK_ITERS; it++) {
-        dist += random_exponential(state, a.extinction);
+        dist += random_exponential(state, a.inv_extinction);
         if (!(dist <= max_distance)) break;
-        f3 p = mix3(from, to, dist / max_distance);
-        float4 ts = sample_volume_color(a, tf_lds, p);
+        f3 p = mix3(from, to, dist * inv_max);
+        float4 ts = sample_volume_color<WIDE>(a, t, p);
         ns++;
         tr *= 1.0f - ts.w;
     }
     return tr;
 }
 // generate/fragment main(): MCSRenderer.glsl:107-137
-VPT_DEV float4 mcs_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p, uint32_t &ns) {
+template <bool WIDE>
+VPT_DEV float4 mcs_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
     float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
     f3 rf, rt;
     unproject(px, py, a.mvp_inv, rf, rt);
@@ -268,16 +297,16 @@ VPT_DEV float4 mcs_pixel(const PassArgs &a, const float4 *tf_lds, const Pix &p, 
     f3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
     float max_distance = length3(sub3(from, to));
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
-    float dist = mcs_sample_distance(a, tf_lds, state, from, to, ns);
+    float dist = mcs_sample_distance<WIDE>(a, t, state, from, to, ns);
     if (!(dist <= max_distance)) return sample_environment(a.env, dir_unit);
-    from = mix3(from, to, dist / max_distance);
+    from = mix3(from, to, dist * rcp_nr(max_distance));
     f2 tb2 = intersect_cube(from, a.light);
     tb2.y = vmax(tb2.y, 0.0f);
     to = madd3(from, tb2.y, a.light);
-    float4 diffuse = sample_volume_color(a, tf_lds, from);
+    float4 diffuse = sample_volume_color<WIDE>(a, t, from);
     ns++;
     float4 light = sample_environment(a.env, a.light);
-    float tr = mcs_sample_transmittance(a, tf_lds, state, from, to, ns);
+    float tr = mcs_sample_transmittance<WIDE>(a, t, state, from, to, ns);
     return make_float4((diffuse.x * light.x) * tr, (diffuse.y * light.y) * tr,
                        (diffuse.z * light.z) * tr, (diffuse.w * light.w) * tr);
 }
@@ -285,14 +314,14 @@ VPT_DEV float4 mcs_mix(float4 acc, float4 frame, float inv) {   // MCSRenderer.g
     return make_float4(fmaf(frame.x - acc.x, inv, acc.x), fmaf(frame.y - acc.y, inv, acc.y),
                        fmaf(frame.z - acc.z, inv, acc.z), fmaf(frame.w - acc.w, inv, acc.w));
 }
-template <int MODE>
+template <int MODE, bool WIDE>
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
-    extern __shared__ float4 tf_lds[];
-    stage_tf(tf_lds, a);
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<WIDE>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        float4 c = mcs_pixel(a, tf_lds, p, ns);
+        float4 c = mcs_pixel<WIDE>(a, t, p, ns);
         float4 *frame = (float4 *)a.frame, *acc = (float4 *)a.acc;
         if (MODE == 0) {
             frame[p.k] = c;
@@ -328,34 +357,40 @@ struct Photon {
     f3 position, direction, transmittance, radiance;
     uint32_t bounces, samples;
 };
-// mixins/unprojectRand.glsl:3-24
-VPT_DEV void unproject_rand(uint32_t &state, float px, float py, const PassArgs &a, f3 &from, f3 &to) {
-    f2 d = random_disk(state);
-    float ox = d.x * a.blur, oy = d.y * a.blur;
+// mixins/unprojectRand.glsl:3-24.  The near-plane point depends on the pixel only when blur == 0 (the reference
+// always passes 0: MCMRenderer.js:93,157): the two disk uniforms are still drawn, their product with 0 is an exact
+// zero, so `from` equals the un-jittered unprojection `from0` computed once per pixel.
+VPT_DEV void unproject_rand(uint32_t &state, float px, float py, const PassArgs &a, f3 from0, f3 &from, f3 &to) {
+    if (a.blur == 0.0f) {
+        random_uniform(state); random_uniform(state);
+        from = from0;
+    } else {
+        f2 d = random_disk(state);
+        from = dehomogenize(mat4_mul_point(a.mvp_inv, px + d.x * a.blur, py + d.y * a.blur, -1.0f));
+    }
     float sx = random_uniform(state), sy = random_uniform(state);
     float ax = fmaf(sx, 2.0f, -1.0f) * a.inv_w;
     float ay = fmaf(sy, 2.0f, -1.0f) * a.inv_h;
-    float4 n = mat4_mul_point(a.mvp_inv, px + ox, py + oy, -1.0f);
-    float4 f = mat4_mul_point(a.mvp_inv, px + ax, py + ay, 1.0f);
-    from = f3{ n.x / n.w, n.y / n.w, n.z / n.w };
-    to = f3{ f.x / f.w, f.y / f.w, f.z / f.w };
+    to = dehomogenize(mat4_mul_point(a.mvp_inv, px + ax, py + ay, 1.0f));
+}
+VPT_DEV f3 unproject_near(float px, float py, const PassArgs &a) {
+    return dehomogenize(mat4_mul_point(a.mvp_inv, px + 0.0f, py + 0.0f, -1.0f));
 }
 // resetPhoton: MCMRenderer.glsl:70-78
-VPT_DEV void reset_photon(uint32_t &state, Photon &ph, float px, float py, const PassArgs &a) {
+VPT_DEV void reset_photon(uint32_t &state, Photon &ph, float px, float py, const PassArgs &a, f3 from0) {
     f3 from, to;
-    unproject_rand(state, px, py, a, from, to);
+    unproject_rand(state, px, py, a, from0, from, to);
     ph.direction = normalize3(sub3(to, from));
     ph.bounces = 0u;
-    f2 tb = intersect_cube(from, ph.direction);
-    tb.x = vmax(tb.x, 0.0f);
-    ph.position = madd3(from, tb.x, ph.direction);
+    float tnear = vmax(intersect_cube_near(from, ph.direction), 0.0f);
+    ph.position = madd3(from, tnear, ph.direction);
     ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
 }
 // sampleHenyeyGreensteinAngleCosine: MCMRenderer.glsl:91-95
 VPT_DEV float hg_cos(uint32_t &state, float g) {
     float g2 = g * g;
-    float c = (1.0f - g2) / fmaf(2.0f * g, random_uniform(state), 1.0f - g);
-    return fmaf(-c, c, 1.0f + g2) / (2.0f * g);
+    float c = (1.0f - g2) * rcp_nr(fmaf(2.0f * g, random_uniform(state), 1.0f - g));
+    return fmaf(-c, c, 1.0f + g2) * rcp_nr(2.0f * g);
 }
 // sampleHenyeyGreenstein: MCMRenderer.glsl:97-106
 VPT_DEV f3 sample_hg(uint32_t &state, float g, f3 dir) {
@@ -368,13 +403,13 @@ VPT_DEV f3 sample_hg(uint32_t &state, float g, f3 dir) {
     float s = sqrtf(fmaf(-hgcos, hgcos, 1.0f));
     return f3{ fmaf(s, c.x, hgcos * dir.x), fmaf(s, c.y, hgcos * dir.y), fmaf(s, c.z, hgcos * dir.z) };
 }
-// radiance += (rad - radiance) / float(samples)   (MCMRenderer.glsl:147-150,154-157)
+// radiance += (rad - radiance) / float(samples)   (MCMRenderer.glsl:147-150,154-157), as * (1/n)
 VPT_DEV void photon_deposit(Photon &ph, f3 rad) {
     ph.samples++;
-    float n = (float)ph.samples;
-    ph.radiance.x += (rad.x - ph.radiance.x) / n;
-    ph.radiance.y += (rad.y - ph.radiance.y) / n;
-    ph.radiance.z += (rad.z - ph.radiance.z) / n;
+    float inv_n = rcp_nr((float)ph.samples);
+    ph.radiance.x += (rad.x - ph.radiance.x) * inv_n;
+    ph.radiance.y += (rad.y - ph.radiance.y) * inv_n;
+    ph.radiance.z += (rad.z - ph.radiance.z) * inv_n;
 }
 
 // reset/fragment main(): MCMRenderer.glsl:259-275 (seeded from the NDC position)
@@ -384,12 +419,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
     if (p.valid) {
         float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
         uint32_t state = hash3(__float_as_uint(px), __float_as_uint(py), __float_as_uint(a.seed));
-        f3 from, to;
-        unproject_rand(state, px, py, a, from, to);
-        ph.direction = normalize3(sub3(to, from));
-        f2 tb = intersect_cube(from, ph.direction);
-        tb.x = vmax(tb.x, 0.0f);
-        ph.position = madd3(from, tb.x, ph.direction);
+        reset_photon(state, ph, px, py, a, unproject_near(px, py, a));
     } else {
         ph.position = f3{ 0.0f, 0.0f, 0.0f };
         ph.direction = f3{ 0.0f, 0.0f, 1.0f };
@@ -402,10 +432,10 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
 
 // integrate/fragment main(): MCMRenderer.glsl:116-172.  FUSE_RENDER additionally performs
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
-template <bool FUSE_RENDER>
+template <bool FUSE_RENDER, bool WIDE>
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_integrate(PassArgs a) {
-    extern __shared__ float4 tf_lds[];
-    stage_tf(tf_lds, a);
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<WIDE>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
     float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
@@ -417,24 +447,29 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_integrate(PassArgs a) {
     ph.transmittance = f3{ s2.x, s2.y, s2.z };
     ph.radiance = f3{ s3.x, s3.y, s3.z };
     ph.samples = (uint32_t)(s3.w + 0.5f);
+    const f3 from0 = unproject_near(px, py, a);
 
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
     for (uint32_t s = 0u; s < a.steps; s++) {
-        float dist = random_exponential(state, a.extinction);
+        float dist = random_exponential(state, a.inv_extinction);
         ph.position = madd3(ph.position, dist, ph.direction);
-        float4 vs = sample_volume_color(a, tf_lds, ph.position);
+        float4 vs = sample_volume_color<WIDE>(a, t, ph.position);
         float p_null = 1.0f - vs.w;
         float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
         float p_abs = 1.0f - p_null - p_scat;
         float wheel = random_uniform(state);
         f3 q = ph.position;
-        if (q.x > 1.0f || q.y > 1.0f || q.z > 1.0f || q.x < 0.0f || q.y < 0.0f || q.z < 0.0f) {
-            float4 env = sample_environment(a.env, ph.direction);
-            photon_deposit(ph, f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z });
-            reset_photon(state, ph, px, py, a);
-        } else if (wheel < p_abs) {
-            photon_deposit(ph, f3{ 0.0f, 0.0f, 0.0f });
-            reset_photon(state, ph, px, py, a);
+        // any(greaterThan(pos, 1)) || any(lessThan(pos, 0)), NaN components compare false
+        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+        if (oob || wheel < p_abs) {
+            // out of bounds: radiance = transmittance * env; absorption: radiance = 0 — one shared deposit + resetPhoton
+            f3 rad = { 0.0f, 0.0f, 0.0f };
+            if (oob) {
+                float4 env = sample_environment(a.env, ph.direction);
+                rad = f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z };
+            }
+            photon_deposit(ph, rad);
+            reset_photon(state, ph, px, py, a, from0);
         } else if (wheel < p_abs + p_scat) {
             ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
             ph.direction = sample_hg(state, a.anisotropy, ph.direction);
@@ -503,13 +538,19 @@ __global__ void k_probe_math(int which, const float *in, float *out, size_t n) {
         case 5: r = __uint_as_float(pcg(__float_as_uint(in[t]))); break;
         case 6: { uint32_t st = __float_as_uint(in[t]); r = random_uniform(st); } break;
         case 7: r = __uint_as_float((uint32_t)to_half_bits(in[t])); break;
+        case 8: r = rcp_nr(in[t]); break;
+        case 9: r = rsqrt_nr(in[t]); break;
+        case 10: r = vmin(in[2 * t], in[2 * t + 1]); break;
+        case 11: r = vmax(in[2 * t], in[2 * t + 1]); break;
+        case 12: r = vpt_logf_uniform(in[t]); break;
     }
     out[t] = r;
 }
+template <bool WIDE>
 __global__ void __launch_bounds__(VPT_BLOCK) k_probe_sample(PassArgs a, const float *xyz, float4 *out, size_t n) {
-    extern __shared__ float4 tf_lds[];
-    stage_tf(tf_lds, a);
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    out[t] = sample_volume_color(a, tf_lds, f3{ xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2] });
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<WIDE>(lds_raw, a);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = sample_volume_color<WIDE>(a, t, f3{ xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] });
 }

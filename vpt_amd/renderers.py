@@ -103,6 +103,7 @@ class AbstractRenderer(PropertyBag):
         return u
 
     def _hooks_overridden(self):
+        # a user subclass that overrides a hook of the shipped class must see its hook called
         base = type(self)._BASE
         return any(getattr(type(self), n) is not getattr(base, n)
                    for n in ('_generateFrame', '_integrateFrame', '_renderFrame'))
@@ -416,6 +417,10 @@ class MCMRenderer(AbstractRenderer):
     def _renderFused(self):
         self._bind_volume()
         N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_integrate())))
+
+
+for _cls in (MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer):
+    _cls._BASE = _cls
 
 
 def RendererFactory(which):
