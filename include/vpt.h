@@ -158,6 +158,8 @@ VPT_API int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t *la
 #define VPT_PROBE_MIN     10  /* in = pairs (a, b) ; n outputs */
 #define VPT_PROBE_MAX     11
 #define VPT_PROBE_LOG_UNIFORM 12  /* log on the range of random_uniform */
+#define VPT_PROBE_RCPZ    13  /* rcp_nrz: reciprocal with 1/(+-0) = +-inf */
+#define VPT_PROBE_SQRT    14  /* sqrt_nr = x * rsqrt_nr(x) */
 VPT_API int vpt_probe_math(vpt_context *ctx, int which, const float *in, float *out, size_t n);
 /* samples texture(uVolume, p) -> transfer function at n positions (xyz triples); out = n RGBA float4 */
 VPT_API int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n);

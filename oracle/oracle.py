@@ -56,6 +56,8 @@ def lib():
         L.vpo_asinf.restype = C.c_float; L.vpo_asinf.argtypes = [C.c_float]
         L.vpo_rcp_nr.restype = C.c_float; L.vpo_rcp_nr.argtypes = [C.c_float]
         L.vpo_rsqrt_nr.restype = C.c_float; L.vpo_rsqrt_nr.argtypes = [C.c_float]
+        L.vpo_rcp_nrz.restype = C.c_float; L.vpo_rcp_nrz.argtypes = [C.c_float]
+        L.vpo_sqrt_nr.restype = C.c_float; L.vpo_sqrt_nr.argtypes = [C.c_float]
         L.vpo_min.restype = C.c_float; L.vpo_min.argtypes = [C.c_float, C.c_float]
         L.vpo_max.restype = C.c_float; L.vpo_max.argtypes = [C.c_float, C.c_float]
         L.vpo_pcg.restype = C.c_uint32; L.vpo_pcg.argtypes = [C.c_uint32]

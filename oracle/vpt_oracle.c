@@ -109,6 +109,17 @@ VPO_API float vpo_rcp_nr(float x) {
     r = fmaf(fmaf(-x, r, 1.0f), r, r);
     return r;
 }
+/* the same with the iterate clamped to +-FLT_MAX before the last step: 1/(+-0) = +-inf, as the slab test needs;
+ * identical to vpo_rcp_nr wherever that is finite.  med3(r, -M, M) for NaN r is NaN here (only reachable from NaN x). */
+VPO_API float vpo_rcp_nrz(float x) {
+    float r = u2f(0x7EF311C7u - f2u(x));
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    if (r > 3.402823466e+38f) r = 3.402823466e+38f;
+    if (r < -3.402823466e+38f) r = -3.402823466e+38f;
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
 /* software reciprocal square root: integer seed + 3 Newton-Raphson steps (normal x > 0) */
 VPO_API float vpo_rsqrt_nr(float x) {
     float y = u2f(0x5F375A86u - (f2u(x) >> 1));
@@ -118,6 +129,8 @@ VPO_API float vpo_rsqrt_nr(float x) {
     y = y * fmaf(-h * y, y, 1.5f);
     return y;
 }
+/* sqrt(x) = x * inversesqrt(x) (GLSL ES 3.00 §4.5.1: sqrt inherits the precision of 1/inversesqrt); sqrt(+0) = +0 */
+VPO_API float vpo_sqrt_nr(float x) { return x * vpo_rsqrt_nr(x); }
 /* GLSL normalize(v) = v * inversesqrt(dot(v, v)) */
 static inline v3 normalize3(v3 a) {
     float inv = vpo_rsqrt_nr(dot3(a, a));
@@ -255,7 +268,7 @@ static inline v2 random_square(uint32_t *state) {
 }
 /* distribution/disk.glsl:3-7, constants.glsl:4 (TWOPI 6.28318530718) */
 static inline v2 random_disk(uint32_t *state) {
-    float radius = sqrtf(vpo_random_uniform(state));
+    float radius = vpo_sqrt_nr(vpo_random_uniform(state));
     float angle = 6.28318530718f * vpo_random_uniform(state);
     float s, c; vpo_sincosf(angle, &s, &c);
     v2 r = { radius * c, radius * s };
@@ -265,7 +278,7 @@ static inline v2 random_disk(uint32_t *state) {
 static inline v3 random_sphere(uint32_t *state) {
     v2 d = random_disk(state);
     float norm = fmaf(d.y, d.y, d.x * d.x);
-    float radius = 2.0f * sqrtf(1.0f - norm);
+    float radius = 2.0f * vpo_sqrt_nr(1.0f - norm);
     float z = fmaf(-2.0f, norm, 1.0f);
     v3 r = { radius * d.x, radius * d.y, z };
     return r;
@@ -447,7 +460,7 @@ static inline float ndc_to_uv(float p) { return fmaf(p, 0.5f, 0.5f); }
 
 /* mixins/intersectCube.glsl:3-11 */
 static inline v2 intersect_cube(v3 o, v3 d) {
-    v3 inv = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };     /* (a - o) / d as (a - o) * (1/d) */
+    v3 inv = { vpo_rcp_nrz(d.x), vpo_rcp_nrz(d.y), vpo_rcp_nrz(d.z) };     /* (a - o) / d as (a - o) * rcp(d), rcp(+-0) = +-inf */
     v3 tmin = { (0.0f - o.x) * inv.x, (0.0f - o.y) * inv.y, (0.0f - o.z) * inv.z };
     v3 tmax = { (1.0f - o.x) * inv.x, (1.0f - o.y) * inv.y, (1.0f - o.z) * inv.z };
     v3 t1 = { vmin(tmin.x, tmax.x), vmin(tmin.y, tmax.y), vmin(tmin.z, tmax.z) };
@@ -739,7 +752,7 @@ static v3 sample_hg(uint32_t *state, float g, v3 dir) {
     float ud = dot3(u, dir);
     v3 c = { fmaf(-ud, dir.x, u.x), fmaf(-ud, dir.y, u.y), fmaf(-ud, dir.z, u.z) };
     c = normalize3(c);
-    float s = sqrtf(fmaf(-hgcos, hgcos, 1.0f));
+    float s = vpo_sqrt_nr(fmaf(-hgcos, hgcos, 1.0f));
     v3 r = { fmaf(s, c.x, hgcos * dir.x), fmaf(s, c.y, hgcos * dir.y), fmaf(s, c.z, hgcos * dir.z) };
     return r;
 }

@@ -13,7 +13,7 @@ FORMAT_R8 = 0
 BUFFER_RENDER, BUFFER_FRAME, BUFFER_ACCUM = 0, 1, 2
 BUFFER_MCM_POSITION, BUFFER_MCM_DIRECTION, BUFFER_MCM_TRANSMITTANCE, BUFFER_MCM_RADIANCE = 3, 4, 5, 6
 (PROBE_LOG, PROBE_SIN, PROBE_COS, PROBE_ASIN, PROBE_ATAN2, PROBE_PCG, PROBE_UNIFORM, PROBE_F16,
- PROBE_RCP, PROBE_RSQRT, PROBE_MIN, PROBE_MAX, PROBE_LOG_UNIFORM) = range(13)
+ PROBE_RCP, PROBE_RSQRT, PROBE_MIN, PROBE_MAX, PROBE_LOG_UNIFORM, PROBE_RCPZ, PROBE_SQRT) = range(15)
 
 # every symbol include/vpt.h declares (tests check the library exports all of them)
 SYMBOLS = [

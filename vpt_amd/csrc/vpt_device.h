@@ -50,6 +50,16 @@ VPT_DEV float rcp_nr(float x) {
     r = fmaf(fmaf(-x, r, 1.0f), r, r);
     return r;
 }
+// rcp_nrz: the same with the iterate clamped to +-FLT_MAX before the last step, so that 1/(+-0) = +-inf (and tiny
+// denormals overflow to inf) as the slab test of intersectCube needs; identical to rcp_nr wherever that is finite.
+VPT_DEV float rcp_nrz(float x) {
+    float r = __uint_as_float(0x7EF311C7u - __float_as_uint(x));
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    r = __builtin_amdgcn_fmed3f(r, -3.402823466e+38f, 3.402823466e+38f);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
 // rsqrt_nr(x) ~ 1/sqrt(x) for normal x > 0: integer seed + 3 Newton-Raphson steps; relative error < 3e-7.
 // GLSL normalize(v) = v * inversesqrt(dot(v,v)) (inversesqrt: 2 ULP, ES 3.00 §4.5.1).
 VPT_DEV float rsqrt_nr(float x) {
@@ -61,6 +71,8 @@ VPT_DEV float rsqrt_nr(float x) {
     return y;
 }
 VPT_DEV f3 normalize3(f3 a) { float inv = rsqrt_nr(dot3(a, a)); return f3{ a.x * inv, a.y * inv, a.z * inv }; }
+// sqrt_nr(x) = x * rsqrt_nr(x): sqrt(+0) = +0 (the seed stays finite); GLSL: sqrt inherits 1/inversesqrt precision
+VPT_DEV float sqrt_nr(float x) { return x * rsqrt_nr(x); }
 
 // ---- transcendental routines ---------------------------------------------------------------
 // natural log on {0} U [2^-126, inf]
@@ -189,7 +201,7 @@ VPT_DEV float random_uniform(uint32_t &state) { state = pcg(state); return (floa
 // -log(u)/rate as -log(u) * inv_rate, inv_rate = 1/rate once per pass (contract)
 VPT_DEV float random_exponential(uint32_t &state, float inv_rate) { return -vpt_logf_uniform(random_uniform(state)) * inv_rate; }
 VPT_DEV f2 random_disk(uint32_t &state) {
-    float radius = sqrtf(random_uniform(state));
+    float radius = sqrt_nr(random_uniform(state));
     float angle = 6.28318530718f * random_uniform(state);
     float s, c; vpt_sincosf(angle, s, c);
     return f2{ radius * c, radius * s };
@@ -197,7 +209,7 @@ VPT_DEV f2 random_disk(uint32_t &state) {
 VPT_DEV f3 random_sphere(uint32_t &state) {
     f2 d = random_disk(state);
     float norm = fmaf(d.y, d.y, d.x * d.x);
-    float radius = 2.0f * sqrtf(1.0f - norm);
+    float radius = 2.0f * sqrt_nr(1.0f - norm);
     float z = fmaf(-2.0f, norm, 1.0f);
     return f3{ radius * d.x, radius * d.y, z };
 }
@@ -227,8 +239,8 @@ VPT_DEV void unproject(float px, float py, const Mat4 &M, f3 &from, f3 &to) {
 VPT_DEV float pixel_ndc(int i, int n) { return (float)(2 * i + 1) / (float)n - 1.0f; }
 VPT_DEV float ndc_to_uv(float p) { return fmaf(p, 0.5f, 0.5f); }
 
-// mixins/intersectCube.glsl:3-11; (a - o) / d as (a - o) * (1/d) with an IEEE reciprocal (1/0 = +-inf matters)
-VPT_DEV f3 cube_inv_dir(f3 d) { return f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z }; }
+// mixins/intersectCube.glsl:3-11; (a - o) / d as (a - o) * rcp(d), with the reciprocal form whose 1/0 is +-inf
+VPT_DEV f3 cube_inv_dir(f3 d) { return f3{ rcp_nrz(d.x), rcp_nrz(d.y), rcp_nrz(d.z) }; }
 VPT_DEV f2 intersect_cube(f3 o, f3 d) {
     f3 inv = cube_inv_dir(d);
     f3 tmin = { (0.0f - o.x) * inv.x, (0.0f - o.y) * inv.y, (0.0f - o.z) * inv.z };

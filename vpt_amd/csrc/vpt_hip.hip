@@ -285,6 +285,7 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     if (r->G == 1) r->local_h = r->H;
     r->tiles_x = (r->W + VPT_TILE - 1) / VPT_TILE;
     r->tiles_y = (r->local_h + VPT_TILE - 1) / VPT_TILE;
+    r->tiles_y = (r->tiles_y + 7) / 8 * 8;                 // map_pixel deals tile rows over the 8 XCDs
     r->ntiles = r->tiles_x * r->tiles_y;
     r->npix_padded = (size_t)r->ntiles * VPT_BLOCK;
     uint64_t valid = 0;
@@ -669,7 +670,7 @@ extern "C" int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t 
 // ---------------------------------------------------------------------------------------------
 extern "C" int vpt_probe_math(vpt_context *c, int which, const float *in, float *out, size_t n) {
     if (!c || !in || !out) return fail(VPT_ERR_INVALID, "null argument");
-    if (which < 0 || which > VPT_PROBE_LOG_UNIFORM) return fail(VPT_ERR_INVALID, "unknown probe %d", which);
+    if (which < 0 || which > VPT_PROBE_SQRT) return fail(VPT_ERR_INVALID, "unknown probe %d", which);
     if (n == 0) return VPT_OK;
     HIP_TRY(hipSetDevice(c->device));
     size_t nin = (which == VPT_PROBE_ATAN2 || which == VPT_PROBE_MIN || which == VPT_PROBE_MAX) ? 2 * n : n;

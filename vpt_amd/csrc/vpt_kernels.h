@@ -23,15 +23,17 @@ struct PixMap {
 };
 struct Pix { int i, j, l, k; bool valid; };
 
-VPT_DEV int xcd_swizzle(int b, int n) {
-    int q = n >> 3, r = n & 7;
-    int xcd = b & 7, idx = b >> 3;
-    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
+// Workgroup -> tile.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share an XCD's L2).
+// XCD x owns the tile rows ty with ty % 8 == x and walks each of them left to right: consecutive blocks of one XCD
+// are neighbouring tiles (shared bricks hit in that XCD's L2), while every XCD gets rows from the whole image, so
+// cube-missing and cube-crossing tiles balance (a contiguous band per XCD left the centre XCDs ~1.5x the work).
+// tiles_y is padded to a multiple of 8 by the host, so the map is a bijection on [0, ntiles).
 VPT_DEV Pix map_pixel(const PixMap &m) {
-    int t = xcd_swizzle((int)blockIdx.x, m.ntiles);
-    int tx = t % m.tiles_x, ty = t / m.tiles_x;
+    int b = (int)blockIdx.x;
+    int xcd = b & 7, idx = b >> 3;
+    int rowgroup = idx / m.tiles_x, tx = idx - rowgroup * m.tiles_x;
+    int ty = rowgroup * 8 + xcd;
+    int t = ty * m.tiles_x + tx;
     int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     Pix p;
     p.i = tx * VPT_TILE + (w & 1) * 8 + (lane & 7);
@@ -400,7 +402,7 @@ VPT_DEV f3 sample_hg(uint32_t &state, float g, f3 dir) {
     float ud = dot3(u, dir);
     f3 c = { fmaf(-ud, dir.x, u.x), fmaf(-ud, dir.y, u.y), fmaf(-ud, dir.z, u.z) };
     c = normalize3(c);
-    float s = sqrtf(fmaf(-hgcos, hgcos, 1.0f));
+    float s = sqrt_nr(fmaf(-hgcos, hgcos, 1.0f));
     return f3{ fmaf(s, c.x, hgcos * dir.x), fmaf(s, c.y, hgcos * dir.y), fmaf(s, c.z, hgcos * dir.z) };
 }
 // radiance += (rad - radiance) / float(samples)   (MCMRenderer.glsl:147-150,154-157), as * (1/n)
@@ -433,7 +435,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
 // integrate/fragment main(): MCMRenderer.glsl:116-172.  FUSE_RENDER additionally performs
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
 template <bool FUSE_RENDER, bool WIDE>
-__global__ void __launch_bounds__(VPT_BLOCK) k_mcm_integrate(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_mcm_integrate(PassArgs a) {
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<WIDE>(lds_raw, a);
     Pix p = map_pixel(a.pm);
@@ -543,6 +545,8 @@ __global__ void k_probe_math(int which, const float *in, float *out, size_t n) {
         case 10: r = vmin(in[2 * t], in[2 * t + 1]); break;
         case 11: r = vmax(in[2 * t], in[2 * t + 1]); break;
         case 12: r = vpt_logf_uniform(in[t]); break;
+        case 13: r = rcp_nrz(in[t]); break;
+        case 14: r = sqrt_nr(in[t]); break;
     }
     out[t] = r;
 }
