@@ -64,6 +64,34 @@ def test_math_probes_bit_exact(gpu_ctx, oracle):
     assert_same_bits(gpu_ctx.probe_math(N.PROBE_ATAN2, yx.reshape(-1)), want, "atan2")
 
 
+def test_rcp_rsqrt_minmax_probes_bit_exact(gpu_ctx, oracle):
+    """the contract's software reciprocal / rsqrt / sqrt and the minNum / maxNum semantic of v_min_f32 / v_max_f32"""
+    L = oracle.lib()
+    rng = np.random.default_rng(4)
+    x = (np.exp(rng.uniform(-85, 85, 100000)) * rng.choice([-1.0, 1.0], 100000)).astype(np.float32)
+    x = np.concatenate([x, np.float32([1, -1, 2, 0.5, 3, 1e-38, -1e-38, 3e38, 255, 1920, 1080])])
+    assert_same_bits(gpu_ctx.probe_math(N.PROBE_RCP, x), np.array([L.vpo_rcp_nr(float(v)) for v in x], np.float32), "rcp_nr")
+    xz = np.concatenate([x, np.float32([0.0, -0.0, 1e-40, -1e-40, 1e-45])])
+    assert_same_bits(gpu_ctx.probe_math(N.PROBE_RCPZ, xz), np.array([L.vpo_rcp_nrz(float(v)) for v in xz], np.float32), "rcp_nrz")
+    xp = np.concatenate([np.abs(x), np.float32([0.0, 1.0, 4.0, 1e-30])])
+    assert_same_bits(gpu_ctx.probe_math(N.PROBE_SQRT, xp), np.array([L.vpo_sqrt_nr(float(v)) for v in xp], np.float32), "sqrt_nr")
+    xq = np.abs(x)
+    assert_same_bits(gpu_ctx.probe_math(N.PROBE_RSQRT, xq), np.array([L.vpo_rsqrt_nr(float(v)) for v in xq], np.float32), "rsqrt_nr")
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    pairs = np.float32([[1, 2], [2, 1], [0.0, -0.0], [-0.0, 0.0], [nan, 1], [1, nan], [-inf, inf], [inf, -inf], [nan, -0.0],
+                        [-3, -3], [1e-45, 0], [-1e-45, 0]] + rng.normal(size=(5000, 2)).tolist())
+    for probe, f in ((N.PROBE_MIN, L.vpo_min), (N.PROBE_MAX, L.vpo_max)):
+        got = gpu_ctx.probe_math(probe, pairs.reshape(-1))
+        want = np.array([f(float(a), float(b)) for a, b in pairs], np.float32)
+        both_nan = np.isnan(want)
+        assert (np.isnan(got) == both_nan).all()
+        assert_same_bits(got[~both_nan], want[~both_nan], "min/max probe %d" % probe)
+    k = rng.integers(0, 2 ** 32, size=100000, dtype=np.uint64)
+    u = (k.astype(np.float32) * np.float32(2.0 ** -32)).astype(np.float32)
+    u[:3] = [0.0, 1.0, 2.0 ** -32]
+    assert_same_bits(gpu_ctx.probe_math(N.PROBE_LOG_UNIFORM, u), np.array([L.vpo_logf(float(v)) for v in u], np.float32), "log on uniforms")
+
+
 def test_rng_and_half_probes(gpu_ctx, oracle):
     L = oracle.lib()
     rng = np.random.default_rng(2)

@@ -1,0 +1,316 @@
+"""CPU: pins the oracle (oracle/vpt_oracle.c) before it is trusted as the checker.
+
+The reference ships no tests or fixtures for this path ("parity unpinned" by its own tests).
+Pins used here: (1) the inverse-MVP matrices produced by the reference's vendored gl-matrix 3.4.1
+(tests/golden/mvp_inverse.json), (2) PCG known answers derived independently in big-integer Python
+(tests/golden/pcg_kat.json), (3) accuracy of the contract's math routines against libm / numpy in float64,
+(4) closed-form analytic results of the passes."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import default_matrix, orbit_camera
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def ulp_err(got, ref64):
+    ref32 = ref64.astype(np.float32)
+    return np.abs(got.astype(np.float64) - ref64) / np.spacing(np.abs(ref32)).astype(np.float64)
+
+
+# ---- (1) matrix recipe --------------------------------------------------------------------------------
+def test_mvp_inverse_matches_gl_matrix_fixture():
+    from vpt_amd.scene import Node, Transform, PerspectiveCamera, mvp_inverse_matrix
+    d = json.load(open(os.path.join(GOLD, "mvp_inverse.json")))
+    assert len(d["cases"]) >= 4
+    for c in d["cases"]:
+        cam = Node()
+        cam.transform.localTranslation = c["camera"]["translation"]
+        cam.transform.localRotation = c["camera"]["rotation"]
+        cam.transform.localScale = c["camera"]["scale"]
+        pc = PerspectiveCamera(cam)
+        pc.fovy, pc.aspect, pc.near, pc.far = c["fovy"], c["aspect"], c["near"], c["far"]
+        cam.components.append(pc)
+        t = Transform(Node())
+        t.localRotation = c["model"]["rotation"]
+        t.localTranslation = c["model"]["translation"]
+        t.localScale = c["model"]["scale"]
+        m = mvp_inverse_matrix(cam, t)
+        assert (m.view(np.uint32) == np.array(c["inverse_bits"], dtype=np.uint32)).all(), c["name"]
+
+
+def test_default_scene_unprojects_to_survey_values(oracle):
+    """SURVEY §8c sanity: centre of the image unprojects to near (0.5,0.5,2.4), far (0.5,0.5,-97.4978)"""
+    m = default_matrix(1.0)
+    f, t = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    oracle.lib().vpo_unproject(m.ctypes.data_as(C.c_void_p), 0.0, 0.0, f.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p))
+    assert np.allclose(f, [0.5, 0.5, 2.4], atol=1e-5)
+    assert np.allclose(t, [0.5, 0.5, -97.4978], atol=1e-3)
+
+
+# ---- (2) RNG known answers ---------------------------------------------------------------------------
+def test_pcg_known_answers(oracle):
+    L = oracle.lib()
+    d = json.load(open(os.path.join(GOLD, "pcg_kat.json")))
+    for x, y in d["pcg"]:
+        assert L.vpo_pcg(x) == y
+    for (a, b, c), y in d["hash3"]:
+        assert L.vpo_hash3(a, b, c) == y
+    for chain in d["uniform_chain"]:
+        st = C.c_uint32(L.vpo_hash3(*chain["seed_triple"]))
+        for state, bits in chain["chain"]:
+            u = L.vpo_random_uniform(C.byref(st))
+            assert st.value == state
+            assert np.float32(u).view(np.uint32) == bits
+    for state, bits in d["uniform_edge"]:
+        # vpo_random_uniform hashes first; test the conversion itself through numpy's RNE cast
+        assert (np.float32(np.uint32(state)) * np.float32(2.0 ** -32)).view(np.uint32) == bits
+    # SURVEY §8c values
+    assert [L.vpo_pcg(v) for v in (0, 1, 0xffffffff, 12345)] == [129708002, 2831084092, 3861530882, 4099845390]
+    assert L.vpo_hash3(0x3f000000, 0x3f000000, 0x3f000000) == 2645452624
+
+
+def test_uniform_range_inclusive(oracle):
+    """float(~0u) rounds to 2^32: the uniform reaches exactly 1.0 and exactly 0.0"""
+    assert np.float32(np.uint32(0xffffffff)) * np.float32(2.0 ** -32) == np.float32(1.0)
+    assert np.float32(np.uint32(0)) * np.float32(2.0 ** -32) == np.float32(0.0)
+    L = oracle.lib()
+    assert L.vpo_logf(0.0) == -math.inf and L.vpo_logf(1.0) == 0.0
+
+
+# ---- (3) math routines of the contract ------------------------------------------------------------------
+def test_log_accuracy(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(10)
+    k = rng.integers(1, 2 ** 32, size=50000, dtype=np.uint64)
+    u = (k.astype(np.float32) * np.float32(2.0 ** -32)).astype(np.float32)
+    u = np.concatenate([u, np.float32([2.0 ** -32, 0.5, 0.99999994, 0.7071068, 0.70710677])])
+    got = np.array([L.vpo_logf(float(x)) for x in u], np.float32)
+    ref = np.log(u.astype(np.float64))
+    ok = u < 1.0
+    assert ulp_err(got[ok], ref[ok]).max() <= 2.0
+    assert got[~ok].tolist() == [0.0] * int((~ok).sum())
+
+
+def test_sincos_accuracy(oracle):
+    L = oracle.lib()
+    a = np.linspace(0, 6.28318530718, 40001).astype(np.float32)
+    s, c = C.c_float(), C.c_float()
+    gs, gc = np.empty_like(a), np.empty_like(a)
+    for i, x in enumerate(a):
+        L.vpo_sincosf(float(x), C.byref(s), C.byref(c)); gs[i], gc[i] = s.value, c.value
+    assert np.abs(gs - np.sin(a.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(gc - np.cos(a.astype(np.float64))).max() < 2.5e-7
+
+
+def test_atan2_asin_accuracy(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    yx = rng.normal(size=(20000, 2)).astype(np.float32)
+    got = np.array([L.vpo_atan2f(float(p[0]), float(p[1])) for p in yx], np.float32)
+    assert np.abs(got - np.arctan2(yx[:, 0].astype(np.float64), yx[:, 1].astype(np.float64))).max() < 6e-7
+    x = rng.uniform(-1, 1, 20000).astype(np.float32)
+    got = np.array([L.vpo_asinf(float(v)) for v in x], np.float32)
+    assert np.abs(got - np.arcsin(x.astype(np.float64))).max() < 4e-7
+    assert math.isnan(L.vpo_asinf(1.5)) and L.vpo_atan2f(0.0, -1.0) == pytest.approx(math.pi)
+
+
+def test_rcp_rsqrt_within_glsl_precision(oracle):
+    """GLSL ES 3.00 §4.5.1: a/b 2.5 ULP, inversesqrt 2 ULP; sqrt inherits 1/inversesqrt"""
+    L = oracle.lib()
+    rng = np.random.default_rng(12)
+    x = (np.exp(rng.uniform(-80, 80, 100000)) * rng.choice([-1.0, 1.0], 100000)).astype(np.float32)
+    r = np.array([L.vpo_rcp_nr(float(v)) for v in x], np.float32)
+    rz = np.array([L.vpo_rcp_nrz(float(v)) for v in x], np.float32)
+    assert ulp_err(r, 1.0 / x.astype(np.float64)).max() <= 2.5
+    assert (r.view(np.uint32) == rz.view(np.uint32)).all()
+    assert L.vpo_rcp_nrz(0.0) == math.inf and L.vpo_rcp_nrz(-0.0) == -math.inf and math.isnan(L.vpo_rcp_nr(0.0))
+    xp = np.abs(x)
+    q = np.array([L.vpo_rsqrt_nr(float(v)) for v in xp], np.float32)
+    assert ulp_err(q, 1.0 / np.sqrt(xp.astype(np.float64))).max() <= 2.0
+    s = np.array([L.vpo_sqrt_nr(float(v)) for v in xp], np.float32)
+    assert ulp_err(s, np.sqrt(xp.astype(np.float64))).max() <= 3.0
+    assert L.vpo_sqrt_nr(0.0) == 0.0
+
+
+def test_min_max_are_minnum_maxnum(oracle):
+    L = oracle.lib()
+    nan = float("nan")
+    assert L.vpo_min(nan, 2.0) == 2.0 and L.vpo_min(2.0, nan) == 2.0 and math.isnan(L.vpo_min(nan, nan))
+    assert L.vpo_max(nan, -2.0) == -2.0 and L.vpo_max(-2.0, nan) == -2.0
+    assert math.copysign(1.0, L.vpo_min(0.0, -0.0)) == -1.0 and math.copysign(1.0, L.vpo_min(-0.0, 0.0)) == -1.0
+    assert math.copysign(1.0, L.vpo_max(0.0, -0.0)) == 1.0 and math.copysign(1.0, L.vpo_max(-0.0, 0.0)) == 1.0
+    assert L.vpo_min(1.0, 2.0) == 1.0 and L.vpo_max(1.0, 2.0) == 2.0 and L.vpo_max(-math.inf, 3.0) == 3.0
+
+
+def test_half_conversion_matches_numpy(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(13)
+    f = np.concatenate([rng.normal(size=50000).astype(np.float32) * np.float32(100),
+                        (rng.random(50000, dtype=np.float32) * np.float32(2e-4)).astype(np.float32),
+                        np.float32([0, -0.0, 1, 65504, 65519.99, 65520, 70000, 5.96e-8, 2.98e-8, 2.9802322e-8, 2.9802326e-8, 6.1e-5, np.inf, -np.inf])])
+    with np.errstate(over="ignore"):
+        want = f.astype(np.float16).view(np.uint16)
+    got = np.array([L.vpo_f32_to_f16(float(v)) for v in f], np.uint16)
+    assert (got == want).all()
+
+
+def test_srgb_table_matches_product_lut(oracle):
+    """the product embeds a generated sRGB LUT (vpt_amd/csrc/vpt_srgb_lut.h); the oracle evaluates the formula"""
+    import re
+    txt = open(os.path.join(os.path.dirname(GOLD), "..", "vpt_amd", "csrc", "vpt_srgb_lut.h")).read()
+    vals = [float.fromhex(v) for v in re.findall(r"(0x[0-9a-fA-F.]+p[+-]\d+)f", txt)]
+    assert len(vals) == 256
+    L = oracle.lib()
+    for c in range(256):
+        assert np.float32(vals[c]) == np.float32(L.vpo_srgb_to_linear(c))
+    assert vals[0] == 0.0 and vals[255] == 1.0
+
+
+def test_unorm8_round_trip_is_identity():
+    c = np.arange(256, dtype=np.float32)
+    assert (np.rint((c / np.float32(255.0)) * np.float32(255.0)) == c).all()
+    # texel normalisation constant of the sampler: 255 * fl32(1/255) == 1 exactly
+    assert np.float32(255.0) * np.float32(0.00392156862745098) == np.float32(1.0)
+
+
+# ---- (4) analytic checks of the passes -----------------------------------------------------------------
+def test_mip_nearest_equals_integer_max_along_ray(oracle):
+    """with NEAREST filtering and a monotone alpha ramp, MIP == TF.alpha(max voxel met on the ray):
+    the frame is an integer max-reduce over u8 voxels (checked against an independent numpy march)."""
+    from vpt_amd.synthetic import sphere_volume
+    n, w, h, steps = 32, 48, 48, 32
+    vol = sphere_volume(n)
+    sc = oracle.OracleScene(vol, "nearest")
+    m = default_matrix(1.0)
+    fr = oracle.make_frame(w, h, m, offset=0.25, steps=steps)
+    r = oracle.OracleRenderer("mip", sc, w, h)
+    r.reset(fr); r.render(fr)
+    got = r.acc.reshape(h, w)
+    # independent float64 march of the same sample positions
+    L = oracle.lib()
+    want = np.zeros((h, w), np.uint8)
+    f3, t3 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    tb = np.zeros(2, np.float32)
+    for j in range(h):
+        for i in range(w):
+            px = np.float32(np.float32(2 * i + 1) / np.float32(w) - np.float32(1))
+            py = np.float32(np.float32(2 * j + 1) / np.float32(h) - np.float32(1))
+            L.vpo_unproject(m.ctypes.data_as(C.c_void_p), float(px), float(py), f3.ctypes.data_as(C.c_void_p), t3.ctypes.data_as(C.c_void_p))
+            d = (t3 - f3).astype(np.float32)
+            L.vpo_intersect_cube(f3.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), tb.ctypes.data_as(C.c_void_p))
+            t0, t1 = max(float(tb[0]), 0.0), max(float(tb[1]), 0.0)
+            if t0 >= t1:
+                continue
+            f32 = np.float32
+
+            def mix(a, b, t):          # fmaf(b, t, a * (1 - t)) per component, emulated through float64
+                c = (a * f32(f32(1) - t)).astype(np.float32)
+                return (b.astype(np.float64) * np.float64(t) + c.astype(np.float64)).astype(np.float32)
+            a = mix(f3, t3, f32(t0))
+            b = mix(f3, t3, f32(t1))
+            best = 0
+            off = f32(0.25)
+            for s in range(steps):
+                p = mix(a, b, off)
+                idx = np.clip(np.floor(p * f32(n)), 0, n - 1).astype(int)
+                best = max(best, int(vol[idx[2], idx[1], idx[0]]))
+                mm = f32(off + f32(1.0 / steps))
+                off = f32(mm - np.floor(mm))
+            alpha = min(max(2.0 * best / 255.0 - 0.5, 0.0), 1.0)       # default 2x1 TF: alpha(v) = clamp(2v - 1/2)
+            want[j, i] = int(np.rint(alpha * 255.0))
+    # with the default ramp, alpha * 255 = 2v - 127.5 is a half-integer for every voxel value v, so the unorm8
+    # quantisation is a rounding tie that fp32 (oracle) and float64 (here) may break differently: <= 1 level apart
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and got.max() == 255 and got.min() == 0
+    assert (want > 0).sum() > 100
+
+
+def test_eam_homogeneous_cube_closed_form(oracle):
+    """constant volume, constant TF alpha a: A_k = 1 - (1 - a*dl*ext)^k per ray (front-to-back)"""
+    n, w, h, slices, ext = 8, 24, 24, 20, 3.0
+    vol = np.full((n, n, n), 200, np.uint8)
+    tf = np.zeros((1, 2, 4), np.uint8); tf[0, :, :] = [255, 255, 255, 128]
+    sc = oracle.OracleScene(vol, "linear", tf=tf)
+    m = default_matrix(1.0)
+    fr = oracle.make_frame(w, h, m, offset=0.0, steps=slices, extinction=ext, mix=1.0)
+    r = oracle.OracleRenderer("eam", sc, w, h)
+    r.reset(fr); r.render(fr)
+    img = r.acc.reshape(h, w, 4)
+    a = 128 / 255.0
+    # centre pixel: ray along -z through the cube, chord length 1 -> dl = 1/slices
+    k = slices
+    A = 1 - (1 - a * (1.0 / slices) * ext) ** k
+    centre = img[h // 2, w // 2]
+    assert abs(int(centre[0]) - round(255 * A)) <= 2 and centre[3] == 255
+    assert (img[0, 0] == [0, 0, 0, 255]).all()       # corner ray misses the cube
+
+
+def test_mcs_mcm_homogeneous_transmittance_in_expectation(oracle):
+    """homogeneous medium, alpha a, extinction s: P(no real collision over chord L) = exp(-s*a*L).
+    MCS: the fraction of cube-crossing centre-region pixels that escape (alpha channel of env = 1, scattered pixels
+    carry alpha = diffuse.a * light.a * T < 1) estimates it."""
+    n, w, h = 8, 96, 96
+    vol = np.full((n, n, n), 255, np.uint8)
+    a, s = 0.5, 2.0
+    tf = np.zeros((1, 2, 4), np.uint8); tf[0, :, :] = [255, 255, 255, 128]
+    sc = oracle.OracleScene(vol, "nearest", tf=tf)
+    m = default_matrix(1.0)
+    r = oracle.OracleRenderer("mcs", sc, w, h)
+    esc, tot = 0, 0
+    for k in range(6):
+        fr = oracle.make_frame(w, h, m, seed=0.1 + 0.13 * k, extinction=s, mix=1.0, light_dir=(0.0, 1.0, 0.0))
+        r.generate(fr)
+        fimg = r.frame.reshape(h, w, 4)
+        core = fimg[40:56, 40:56]                      # rays that cross the full depth of the cube (chord ~ 1)
+        esc += int((core[..., 3] == 1.0).sum()); tot += core[..., 3].size
+    p = esc / tot
+    assert abs(p - math.exp(-s * (128 / 255.0) * 1.0)) < 0.04, p
+
+
+def test_mcm_counts_and_state_invariants(oracle):
+    from vpt_amd.synthetic import sphere_volume
+    w, h, n = 40, 24, 16
+    vol = sphere_volume(n, noise=30.0)
+    sc = oracle.OracleScene(vol, "linear")
+    m = default_matrix(w / h)
+    r = oracle.OracleRenderer("mcm", sc, w, h)
+    fr = oracle.make_frame(w, h, m, seed=0.3, extinction=5.0, mcm_steps=7, max_bounces=4)
+    r.reset(fr)
+    rad0 = r.state[3].reshape(h, w, 4)
+    assert (rad0[..., :3] == 1.0).all() and (rad0[..., 3] == 0.0).all()      # MCMRenderer.glsl:268-270
+    d = r.state[1].reshape(h, w, 4)[..., :3]
+    assert np.allclose(np.linalg.norm(d, axis=-1), 1.0, atol=1e-5)
+    total = 0
+    for k in range(4):
+        fr.seed = float(np.float32(0.17 * (k + 1)))
+        total += r.integrate(fr)
+    assert total == w * h * 7 * 4                                            # exactly P*steps samples per pass
+    st = [s.reshape(h, w, 4) for s in r.state]
+    assert (st[1][..., 3] <= 4).all() and (st[1][..., 3] >= 0).all()         # bounces never exceed uMaxBounces
+    assert (st[3][..., 3] >= 0).all() and np.isfinite(st[3]).all()
+    r.render_frame(fr)
+    img = r.image_f16()
+    assert (img[..., 3] == 1.0).all()
+
+
+def test_oracle_openmp_rows_equal_scalar(oracle):
+    from vpt_amd.synthetic import sphere_volume
+    w, h, n = 64, 48, 16
+    vol = sphere_volume(n, noise=20.0)
+    sc = oracle.OracleScene(vol, "linear")
+    m = default_matrix(w / h)
+    outs = []
+    for nt in (1, 4):
+        r = oracle.OracleRenderer("mcm", sc, w, h)
+        fr = oracle.make_frame(w, h, m, seed=0.3, extinction=4.0, nthreads=nt)
+        r.reset(fr)
+        fr.seed = float(np.float32(0.77)); r.render(fr)
+        outs.append([s.copy() for s in r.state])
+    for a, b in zip(*outs):
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()

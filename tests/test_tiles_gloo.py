@@ -1,0 +1,62 @@
+"""CPU, world_size 2 (gloo): the N > 1 path of bench.py — per-rank row shards, one equal-sized all_gather per frame,
+reassembly by index_select — reproduces the full frame on every rank."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from vpt_amd.tiles import FrameGather, row_owner, local_rows
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    W, H = 37, 70
+    for rows in (8, 5):
+        g = FrameGather(dist, torch, W, H, torch.device("cpu"), rows_per_block=rows)
+        assert g.rows == local_rows(H, world, rows) and g.shard() == (rank, world, rows)
+        owner, lrow = row_owner(H, world, rows)
+        # the "render": every pixel holds (global row, column, frame id, 1) — what a bit-exact shard would write
+        for frame in range(3):
+            b = frame & 1
+            g.wait(b)
+            g.send[b].zero_()
+            for j in range(H):
+                if owner[j] == rank:
+                    g.send[b][lrow[j], :, 0] = j
+                    g.send[b][lrow[j], :, 1] = torch.arange(W, dtype=torch.float16)
+                    g.send[b][lrow[j], :, 2] = frame
+                    g.send[b][lrow[j], :, 3] = 1
+            g.gather(b)
+            img = g.frame(b)
+            assert img.shape == (H, W, 4)
+            assert (img[:, :, 0] == torch.arange(H, dtype=torch.float16)[:, None]).all()
+            assert (img[:, :, 1] == torch.arange(W, dtype=torch.float16)[None, :]).all()
+            assert (img[:, :, 2] == frame).all() and (img[:, :, 3] == 1).all()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_frame_gather_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o
