@@ -1,0 +1,94 @@
+'use strict';
+// node js/test/test_gpu.js — GPU: the Node.js host (js/vpt) through the N-API addon and the C-ABI, checked against the
+// scalar JS ray-march (oracle/js/raymarch.js, test infrastructure).  Run by tests/test_js_gpu.py under -m gpu.
+const assert = require('assert');
+const vpt = require('../vpt/index.js');
+const cpu = require('../../oracle/js/raymarch.js');
+const { native } = require('../vpt/native.js');
+
+function sphere(n) {
+    const v = new Uint8Array(n * n * n);
+    for (let z = 0; z < n; z++) { for (let y = 0; y < n; y++) { for (let x = 0; x < n; x++) {
+        const dx = (x + 0.5) / n - 0.5, dy = (y + 0.5) / n - 0.5, dz = (z + 0.5) / n - 0.5;
+        const r = Math.sqrt(dx * dx + dy * dy + dz * dz);
+        const wob = 40 * Math.sin(17 * dx) * Math.cos(13 * dy + 5 * dz);
+        v[(z * n + y) * n + x] = Math.max(0, Math.min(255, Math.round(255 * Math.max(0, 1 - r / 0.45) + (r < 0.45 ? wob : 0))));
+    } } }
+    return v;
+}
+function goldenRng() { let k = 1; return () => { const v = (k * 0.61803398875) % 1; k++; return v; }; }
+
+async function main() {
+    const N = native();
+    const n = 32, W = 80, H = 48;
+    const vol = sphere(n);
+    const ctx = new vpt.Context(0);
+    const volume = new vpt.Volume(ctx, new vpt.RAWReader(vol, { width: n, height: n, depth: n }));
+    let progress = 0;
+    volume.addEventListener('progress', e => { progress = e.detail; });
+    await volume.load();                                           // RenderingContext.js:124-134
+    volume.setFilter('linear');
+    assert.strictEqual(progress, 1);
+    const camera = vpt.defaultCamera(W / H);
+    const transform = new vpt.Transform(new vpt.Node());
+    const scene = new cpu.Scene(vol, n, n, n, 'linear', null, null);
+    const mvpInv = vpt.mvpInverseMatrix(camera, transform);
+
+    // ---- MIP: hooks one by one and fused, 3 frames
+    for (const fused of [false, true]) {
+        const R = vpt.RendererFactory('mip');
+        const r = new R(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng(), fused });
+        r.steps = 40;
+        r.reset();
+        const acc = new Uint8Array(W * H), rng = goldenRng();
+        for (let k = 0; k < 3; k++) {
+            r.render();
+            cpu.mipRender(scene, { width: W, height: H, mvpInv, offset: rng(), steps: 40 }, acc);
+        }
+        const got = r.read(N.VPT_BUFFER_ACCUM, new Uint8Array(W * H));
+        let bad = 0;
+        for (let i = 0; i < W * H; i++) { if (got[i] !== acc[i]) { bad++; } }
+        assert.ok(bad <= 1, 'MIP fused=' + fused + ': ' + bad + ' pixels differ');
+        const tex = r.getTexture();
+        assert.strictEqual(tex.width, W); assert.strictEqual(tex.height, H); assert.strictEqual(tex.data.length, W * H * 4);
+        assert.ok(r.sampleCount() > 0);
+        r.destroy();
+    }
+
+    // ---- MCM: reset + 4 passes, state buffers
+    {
+        const R = vpt.RendererFactory('mcm');
+        const r = new R(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });
+        r.extinction = 6; r.bounces = 3; r.steps = 5; r.anisotropy = 0.3;
+        r.dispatchEvent(new vpt.CustomEvent('change', { detail: { name: 'extinction', value: 6 } }));    // Application.js:130-137 -> reset()
+        const st = [0, 1, 2, 3].map(() => new Float32Array(W * H * 4)), rng = goldenRng();
+        rng();                                                     // the constructor-time state is replaced by the 'change' reset
+        const fr = { width: W, height: H, mvpInv, seed: 0, extinction: 6, anisotropy: 0.3, bounces: 3, steps: 5 };
+        // two resets happened on the GPU side? no: one explicit reset() via the change event only
+        const rng2 = goldenRng();
+        fr.seed = rng2();
+        cpu.mcmReset(fr, st);
+        for (let k = 0; k < 4; k++) { r.render(); fr.seed = rng2(); cpu.mcmIntegrate(scene, fr, st); }
+        const bufs = [N.VPT_BUFFER_MCM_POSITION, N.VPT_BUFFER_MCM_DIRECTION, N.VPT_BUFFER_MCM_TRANSMITTANCE, N.VPT_BUFFER_MCM_RADIANCE];
+        let badPixels = new Set();
+        bufs.forEach((b, bi) => {
+            const got = new Uint32Array(r.read(b, new Float32Array(W * H * 4)).buffer), want = new Uint32Array(st[bi].buffer);
+            for (let i = 0; i < got.length; i++) { if (got[i] !== want[i]) { badPixels.add(i >> 2); } }
+        });
+        assert.ok(badPixels.size <= 4, 'MCM: ' + badPixels.size + ' pixels differ');
+        assert.strictEqual(r.sampleCount(), W * H * 5 * 4);
+        r.destroy();
+    }
+
+    // ---- errors are thrown Errors carrying the native message
+    {
+        const r = new vpt.MIPRenderer(ctx, null, camera, null, { resolution: 32 });
+        r.reset();
+        assert.throws(() => r.render(), /no ready volume/);
+        r.destroy();
+    }
+    volume.destroy();
+    ctx.destroy();
+    console.log('js gpu ok');
+}
+main().catch(e => { console.error(e); process.exit(1); });

@@ -1,0 +1,36 @@
+'use strict';
+// node js/test/test_host.js — host-side checks that need no GPU: the addon loads, the matrix recipe matches the
+// gl-matrix fixture bit for bit, PropertyBag / factory behave like the reference's.
+const assert = require('assert');
+const fs = require('fs');
+const path = require('path');
+const vpt = require('../vpt/index.js');
+
+const fixture = JSON.parse(fs.readFileSync(path.join(__dirname, '..', '..', 'tests', 'golden', 'mvp_inverse.json')));
+for (const c of fixture.cases) {
+    const cam = new vpt.Node();
+    cam.transform.localTranslation = c.camera.translation;
+    cam.transform.localRotation = c.camera.rotation;
+    cam.transform.localScale = c.camera.scale;
+    const pc = new vpt.PerspectiveCamera(cam, { fovy: c.fovy, aspect: c.aspect, near: c.near, far: c.far });
+    cam.components.push(pc);
+    const t = new vpt.Transform(new vpt.Node());
+    t.localRotation = c.model.rotation; t.localTranslation = c.model.translation; t.localScale = c.model.scale;
+    const m = vpt.mvpInverseMatrix(cam, t);
+    const bits = Array.from(new Uint32Array(m.buffer));
+    assert.deepStrictEqual(bits, c.inverse_bits, c.name);
+}
+const bag = new vpt.PropertyBag();
+bag.registerProperties([{ name: 'steps', value: 64 }]);
+assert.strictEqual(bag.steps, 64);
+let seen = null;
+bag.addEventListener('change', e => { seen = e.detail; });
+bag.dispatchEvent(new vpt.CustomEvent('change', { detail: { name: 'steps', value: 8 } }));
+assert.deepStrictEqual(seen, { name: 'steps', value: 8 });
+assert.throws(() => vpt.RendererFactory('iso'), /No suitable class/);
+assert.strictEqual(vpt.RendererFactory('mcm'), vpt.MCMRenderer);
+// the addon loads and reports the struct size the JS side packs
+const { native } = require('../vpt/native.js');
+assert.strictEqual(native().UNIFORMS_BYTES, vpt.U.SIZE);
+assert.ok(/vpt/.test(native().version()));
+console.log('js host ok:', fixture.cases.length, 'matrix cases');

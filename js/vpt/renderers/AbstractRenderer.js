@@ -1,0 +1,124 @@
+'use strict';
+// src/js/renderers/AbstractRenderer.js:15-157, re-hosted: the frame / accumulation / render buffers are HIP device
+// buffers owned by the native renderer; the hooks call the C-ABI through the N-API addon.
+//   new R(gl, volume, camera, environmentTexture, { resolution, transform })
+//   gl = vpt Context; environmentTexture = { data: Uint8Array RGBA8, width, height } or null (1x1 white).
+//   options.resolution: number (square, as in the reference) or { width, height }.
+//   options.rng: replaces Math.random() for the per-frame draws (fixed-seed runs).
+const { PropertyBag } = require('../PropertyBag.js');
+const { Transform, mvpInverseMatrix } = require('../scene.js');
+const { native } = require('../native.js');
+
+// byte layout of struct vpt_uniforms (include/vpt.h)
+const U = { MVP: 0, SEED: 64, OFFSET: 68, STEP: 72, EXTINCTION: 76, ANISOTROPY: 80, BOUNCES: 84, STEPS: 88, LIGHT: 92, MIX: 104, BLUR: 108, SIZE: 112 };
+
+class AbstractRenderer extends PropertyBag {
+
+constructor(gl, volume, camera, environmentTexture, options) {
+    super();
+    options = options || {};
+    this._resolution = options.resolution !== undefined ? options.resolution : 512;       // AbstractRenderer.js:20
+    this._gl = gl;
+    this._volume = volume;
+    this._camera = camera;
+    this._environmentTexture = environmentTexture;
+    this._volumeTransform = options.transform !== undefined ? options.transform : new Transform();   // :27
+    this.rng = options.rng || Math.random;
+    this.fused = options.fused !== undefined ? options.fused : true;
+    this._h = null;
+    this._boundVolume = undefined;
+    this._rebuildBuffers();
+    if (environmentTexture) {
+        native().rendererSetEnvironment(this._h, environmentTexture.data, environmentTexture.width, environmentTexture.height);
+    }
+}
+
+_size() {
+    const r = this._resolution;
+    return typeof r === 'number' ? [r, r] : [r.width, r.height];
+}
+
+_rebuildBuffers() {                                                                          // :78-92
+    const N = native();
+    const size = this._size();
+    if (!this._h) {
+        this._h = N.rendererCreate(this._gl._h, this.constructor.KIND(), size[0], size[1]);
+    } else {
+        N.rendererResize(this._h, size[0], size[1]);
+    }
+}
+
+_bindVolume() {
+    const tex = this._volume ? this._volume.getTexture() : null;
+    if (tex !== this._boundVolume) { native().rendererSetVolume(this._h, tex); this._boundVolume = tex; }
+}
+
+_newUniforms() {
+    const buf = new ArrayBuffer(U.SIZE);
+    new Float32Array(buf, 0, 16).set(mvpInverseMatrix(this._camera, this._volumeTransform));
+    return new DataView(buf);
+}
+
+destroy() { if (this._h) { native().rendererDestroy(this._h); this._h = null; } }           // :51-58
+
+render() {                                                                                   // :60-70
+    if (this.fused && !this._hooksOverridden()) { this._renderFused(); return; }
+    this._generateFrame();
+    this._integrateFrame();
+    this._renderFrame();
+}
+
+reset() { this._resetFrame(); }                                                              // :72-76
+
+setVolume(volume) { this._volume = volume; this.reset(); }                                   // :94-97
+
+// :99-104 — { data: Uint8Array RGBA8, width, height } (the reference passes a TexImageSource)
+setTransferFunction(transferFunction) {
+    native().rendererSetTransferFunction(this._h, transferFunction.data, transferFunction.width, transferFunction.height);
+}
+
+setResolution(resolution) {                                                                  // :106-112
+    if (resolution !== this._resolution) {
+        this._resolution = resolution;
+        this._rebuildBuffers();
+        this.reset();
+    }
+}
+
+// :114-116 — the RGBA16F colour attachment, read back as raw half bits [rows][width][4]
+getTexture() {
+    const size = this._size();
+    const rows = native().rendererLocalRows(this._h);
+    const out = new Uint16Array(rows * size[0] * 4);
+    native().rendererRead(this._h, native().VPT_BUFFER_RENDER, out);
+    return { data: out, width: size[0], height: rows, format: 'RGBA16F' };
+}
+
+read(buffer, out) { native().rendererRead(this._h, buffer, out); return out; }
+sampleCount() { return native().rendererSampleCount(this._h); }
+
+_hooksOverridden() {
+    const base = this.constructor.BASE().prototype, mine = Object.getPrototypeOf(this);
+    return ['_generateFrame', '_integrateFrame', '_renderFrame'].some(n => mine[n] !== base[n]);
+}
+
+_resetFrame() {}
+_generateFrame() {}
+_integrateFrame() {}
+_renderFrame() {}
+_renderFused() {}
+
+}
+
+function installChangeHandler(renderer, resetOn) {
+    renderer.addEventListener('change', e => {
+        const name = e.detail.name;
+        if (name === 'transferFunction') { renderer.setTransferFunction(renderer.transferFunction); }
+        if (resetOn.indexOf(name) >= 0) { renderer.reset(); }
+    });
+}
+const transferFunctionProperty = () => ({
+    name: 'transferFunction', label: 'Transfer function', type: 'transfer-function', value: new Uint8Array(256),
+});
+
+module.exports = { AbstractRenderer, U, installChangeHandler, transferFunctionProperty };
