@@ -46,7 +46,7 @@ function rcpNrz(x) {
     let r = u2f((0x7EF311C7 - f2u(x)) >>> 0);
     r = fma(fma(-x, r, 1), r, r); r = fma(fma(-x, r, 1), r, r);
     const M = 3.4028234663852886e+38;
-    if (r > M) { r = M; } if (r < -M) { r = -M; }
+    if (r !== r) { r = -M; } if (r > M) { r = M; } if (r < -M) { r = -M; }
     r = fma(fma(-x, r, 1), r, r);
     return r;
 }

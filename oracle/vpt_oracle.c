@@ -110,11 +110,13 @@ VPO_API float vpo_rcp_nr(float x) {
     return r;
 }
 /* the same with the iterate clamped to +-FLT_MAX before the last step: 1/(+-0) = +-inf, as the slab test needs;
- * identical to vpo_rcp_nr wherever that is finite.  med3(r, -M, M) for NaN r is NaN here (only reachable from NaN x). */
+ * identical to vpo_rcp_nr wherever that is finite (NaN iterates only arise outside the domain, |x| > 2^125 or NaN x). */
 VPO_API float vpo_rcp_nrz(float x) {
     float r = u2f(0x7EF311C7u - f2u(x));
     r = fmaf(fmaf(-x, r, 1.0f), r, r);
     r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    /* v_med3_f32(r, -FLT_MAX, FLT_MAX): a NaN operand makes the instruction return min3 of the others (= -FLT_MAX) */
+    if (r != r) r = -3.402823466e+38f;
     if (r > 3.402823466e+38f) r = 3.402823466e+38f;
     if (r < -3.402823466e+38f) r = -3.402823466e+38f;
     r = fmaf(fmaf(-x, r, 1.0f), r, r);
