@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--check", type=int, default=1, help="verify the gathered frame against rank-local rows")
+    ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
     return ap.parse_args()
 
 
@@ -83,8 +84,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     W, H = args.width, args.height
@@ -93,7 +97,7 @@ def main():
     with torch.cuda.stream(stream):
         ctx = vpt_amd.Context(local_rank, stream=stream.cuda_stream)
         gvol = vpt_amd.Volume.from_array(ctx, vol, 'linear')
-        gather = FrameGather(dist, torch, W, H, device)
+        gather = FrameGather(dist, torch, W, H, device, always_collective=bool(args.force_dist))
         camera = default_camera(W / H)
         transform = Transform(Node())
         opts = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng()}
@@ -119,7 +123,7 @@ def main():
         torch.cuda.synchronize()
         r.clear_sample_count()
         r.set_profiling(True)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -127,7 +131,7 @@ def main():
             step(k)
         gather.wait(0); gather.wait(1)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -136,7 +140,7 @@ def main():
         samples_local = r.sample_count()
 
         tt = torch.tensor([dt, float(samples_local)], dtype=torch.float64, device=device)
-        if world > 1:
+        if use_dist:
             tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
             dt_max, samples = float(tmax[0]), float(tsum[1])
@@ -144,7 +148,7 @@ def main():
             dt_max, samples = dt, float(samples_local)
 
         ok = True
-        if args.check and world > 1:
+        if args.check and use_dist:
             # the gathered frame must hold this rank's own rows unchanged
             b = (args.steps - 1) & 1
             frame = gather.frame(b)
@@ -192,7 +196,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     r.destroy(); gvol.destroy(); ctx.destroy()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("gathered frame does not match the rank-local rows")

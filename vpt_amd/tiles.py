@@ -39,8 +39,9 @@ class FrameGather:
 
     ``dist`` is torch.distributed (backend nccl == RCCL on GPUs, gloo in the CPU tests)."""
 
-    def __init__(self, dist, torch, width, height, device, rows_per_block=ROWS_PER_BLOCK, nbuf=2):
+    def __init__(self, dist, torch, width, height, device, rows_per_block=ROWS_PER_BLOCK, nbuf=2, always_collective=False):
         self.dist, self.torch = dist, torch
+        self.always_collective = always_collective and dist.is_initialized()   # exercise RCCL even with one rank
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.W, self.H = width, height
@@ -62,7 +63,7 @@ class FrameGather:
 
     def gather(self, k):
         """enqueue the all_gather of send[k] into recv[k]; overlaps with whatever is launched next"""
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             self.recv[k] = self.send[k]
             return
         self.work[k] = self.dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), async_op=True)
