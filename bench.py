@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--check", type=int, default=1, help="verify the gathered frame against rank-local rows")
+    ap.add_argument("--fused", type=int, default=1, help="0: run the three hooks as separate launches (profiling aid)")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
     return ap.parse_args()
 
@@ -100,7 +101,7 @@ def main():
         gather = FrameGather(dist, torch, W, H, device, always_collective=bool(args.force_dist))
         camera = default_camera(W / H)
         transform = Transform(Node())
-        opts = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng()}
+        opts = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng(), 'fused': bool(args.fused)}
         if world > 1:
             opts['shard'] = gather.shard()
         r = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, opts)
