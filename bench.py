@@ -66,6 +66,34 @@ def cpu_baseline(vol, args, matrix, tf):
                       "oracle/vpt_oracle.c with OpenMP over rows, %.2f s wall" % (passes, w, h, args.volume, dt)}
 
 
+def cpu_baseline_js(vol, args, matrix):
+    """The scalar JavaScript ray-march BASELINE.json asks for (oracle/js/raymarch.js, single thread, node): MCM reset +
+    2 integrate passes over a centred band of rows of the same 1920x1080 frame / volume; samples/s of the band."""
+    import shutil, subprocess, tempfile
+    import numpy as np
+    node = shutil.which("node")
+    if node is None:
+        return {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "node not installed"}
+    w, h = args.width, args.height
+    band = 96
+    y0 = max(0, h // 2 - band // 2); y1 = min(h, y0 + band)
+    with tempfile.TemporaryDirectory() as tmp:
+        vol.tofile(os.path.join(tmp, "vol.raw"))
+        job = {"kind": "mcm", "nx": args.volume, "ny": args.volume, "nz": args.volume, "width": w, "height": h,
+               "steps": 8, "bounces": 8, "extinction": 1.0, "anisotropy": 0.0, "reset_seed": 0.5,
+               "seeds": [float(np.float32((k + 1) * 0.61803398875 % 1.0)) for k in range(2)], "y0": y0, "y1": y1,
+               "mvp_inverse_bits": np.asarray(matrix, np.float32).view(np.uint32).tolist(), "volume": os.path.join(tmp, "vol.raw")}
+        json.dump(job, open(os.path.join(tmp, "job.json"), "w"))
+        res = subprocess.run([node, os.path.join(ROOT, "oracle", "js", "raymarch.js"), os.path.join(tmp, "job.json")],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        if res.returncode != 0:
+            return {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "node failed: " + res.stderr.decode()[-200:]}
+        info = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    return {"value": info["samples"] / info["seconds"], "unit": "volume samples/s", "cores": 1, "kind": "port",
+            "sample": "scalar JS (node %s) MCM, 2 integrate passes (steps=8) over rows %d..%d of the %dx%d frame, same %d^3 volume, %.2f s"
+                      % (subprocess.check_output([node, "--version"]).decode().strip(), y0, y1, w, h, args.volume, info["seconds"])}
+
+
 def main():
     args = parse()
     import numpy as np
@@ -195,6 +223,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(vol, args, r._matrix(), None)
             except Exception as e:                                      # the baseline is reporting only
                 out["cpu_baseline"] = {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+            try:
+                out["cpu_baseline_js"] = cpu_baseline_js(vol, args, r._matrix())
+            except Exception as e:
+                out["cpu_baseline_js"] = {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+            out["host_cores"] = len(os.sched_getaffinity(0))
         print(json.dumps(out), flush=True)
     r.destroy(); gvol.destroy(); ctx.destroy()
     if use_dist:
