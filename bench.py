@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--check", type=int, default=1, help="verify the gathered frame against rank-local rows")
     ap.add_argument("--fused", type=int, default=1, help="0: run the three hooks as separate launches (profiling aid)")
+    ap.add_argument("--gather", default="native", choices=["native", "torch"],
+                    help="frame gather for N > 1: 'native' = RCCL pipeline below the C ABI (vpt_gather_*), 'torch' = torch.distributed all_gather")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
     return ap.parse_args()
 
@@ -103,7 +105,7 @@ def main():
     from vpt_amd import _native as N
     from vpt_amd.scene import default_camera, Transform, Node
     from vpt_amd.synthetic import sphere_volume, GoldenRatioRng
-    from vpt_amd.tiles import FrameGather
+    from vpt_amd.tiles import FrameGather, RcclFrameGather
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,17 +140,46 @@ def main():
         assert r.local_rows() == gather.rows
         nbytes = gather.send[0].numel() * 2
         r.reset()
+        native = None
+        if use_dist and args.gather == "native":
+            # bootstrap the library's own RCCL communicator through torch.distributed; every rank must agree that it
+            # came up, otherwise all of them fall back to the torch.distributed gather
+            err = ""
+            try:
+                ids = [RcclFrameGather.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                native = RcclFrameGather(r, ids[0], rank, world)
+            except Exception as e:                       # noqa: BLE001 - reported below
+                err = repr(e)
+            flag = torch.tensor([0 if native is not None else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(flag)
+            if int(flag[0]) != 0:
+                if native is not None:
+                    native.destroy()
+                native = None
+                args.gather = "torch"
+                if rank == 0:
+                    print("native RCCL gather unavailable (%s); using torch.distributed all_gather" % err, file=sys.stderr)
 
         def step(k):
+            if native is not None:
+                native.render()                      # kernel + async RCCL all_gather, one enqueue each, below the C ABI
+                return
             b = k & 1
             gather.wait(b)
             r.set_render_target(gather.send[b].data_ptr(), nbytes)
             r.render()
             gather.gather(b)
 
+        def drain():
+            if native is not None:
+                native.synchronize()
+            else:
+                gather.wait(0); gather.wait(1)
+
         for k in range(args.warmup):
             step(k)
-        gather.wait(0); gather.wait(1)
+        drain()
         torch.cuda.synchronize()
         r.clear_sample_count()
         r.set_profiling(True)
@@ -158,7 +189,7 @@ def main():
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(k)
-        gather.wait(0); gather.wait(1)
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -179,11 +210,18 @@ def main():
         ok = True
         if args.check and use_dist:
             # the gathered frame must hold this rank's own rows unchanged
-            b = (args.steps - 1) & 1
-            frame = gather.frame(b)
-            rows = torch.as_tensor(r.global_rows(), device=device)
-            valid = rows >= 0
-            ok = bool(torch.equal(frame.index_select(0, rows[valid]), gather.send[b][valid]))
+            rows_np = r.global_rows()
+            valid_np = rows_np >= 0
+            if native is not None:
+                frame = native.frame()                              # [H][W][4] float16 on the host
+                own = r.read(N.BUFFER_RENDER)                       # the send buffer the last frame was rendered into
+                ok = bool((frame[rows_np[valid_np]].view(np.uint16) == own[valid_np].view(np.uint16)).all())
+            else:
+                b = (args.steps - 1) & 1
+                frame = gather.frame(b)
+                rows = torch.as_tensor(rows_np, device=device)
+                valid = rows >= 0
+                ok = bool(torch.equal(frame.index_select(0, rows[valid]), gather.send[b][valid]))
         torch.cuda.synchronize()
 
     if rank == 0:
@@ -209,7 +247,7 @@ def main():
             "config": {"workload": "%s renderer, synthetic %d^3 u8 volume (radial sphere + lattice noise), %dx%d, "
                                    "default camera, default 2x1 transfer function, extinction %g, anisotropy 0, bounces 8, "
                                    "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
-                       "parallelism": "image rows sharded over %d GPU(s), per-frame RCCL all_gather" % world if world > 1 else "single GPU",
+                       "parallelism": ("image rows sharded over %d GPU(s), per-frame RCCL all_gather (%s pipeline)" % (world, args.gather)) if use_dist else "single GPU",
                        "samples_per_step": samples / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -229,6 +267,8 @@ def main():
                 out["cpu_baseline_js"] = {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
             out["host_cores"] = len(os.sched_getaffinity(0))
         print(json.dumps(out), flush=True)
+    if native is not None:
+        native.destroy()
     r.destroy(); gvol.destroy(); ctx.destroy()
     if use_dist:
         dist.destroy_process_group()

@@ -144,6 +144,23 @@ VPT_API int vpt_renderer_clear_sample_count(vpt_renderer *r);
 VPT_API int vpt_renderer_set_profiling(vpt_renderer *r, int enabled);
 VPT_API int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t *launches);
 
+/* ---- multi-GPU frame gather (no reference counterpart).  One process per GPU; the image plane is sharded
+ * with vpt_renderer_set_shard and every frame is all-gathered over RCCL/xGMI.  The pipeline lives below the C ABI so
+ * that a frame costs the host two enqueues: kernel k+1 (context stream) overlaps the all_gather of frame k (own
+ * communication stream), ordered by HIP events; send/receive buffers are double-buffered. */
+typedef struct vpt_gather vpt_gather;
+/* RCCL bootstrap: ONE rank obtains the 128-byte id and shares it with the others out of band (e.g. torch.distributed) */
+VPT_API int vpt_gather_unique_id(void *id128);
+/* collective: every rank of `world` calls it with the same id; the renderer must already be sharded (rank, world) */
+VPT_API int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, int world, vpt_gather **out);
+VPT_API int vpt_gather_destroy(vpt_gather *g);
+/* render() of the renderer into the next send buffer + asynchronous all_gather of it */
+VPT_API int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u);
+/* blocks until every enqueued frame has been rendered and gathered */
+VPT_API int vpt_gather_synchronize(vpt_gather *g);
+/* the most recently gathered frame, rows put back in order: [height][width] RGBA16F -> host (blocks) */
+VPT_API int vpt_gather_read_frame(vpt_gather *g, void *host_dst, size_t nbytes);
+
 /* ---- test probes: evaluate device-side building blocks on the GPU (tests/ compares with the oracle) */
 #define VPT_PROBE_LOG     0   /* out[i] = log(in[i]) */
 #define VPT_PROBE_SIN     1

@@ -305,6 +305,23 @@ def test_sharded_equals_unsharded(gpu_ctx, oracle, kind, world, rows):
     full.destroy(); sc.gvol.destroy()
 
 
+def test_native_rccl_gather_single_rank(gpu_ctx, oracle):
+    """vpt_gather_*: the RCCL pipeline below the C ABI with a one-rank communicator — frames equal the plain render()"""
+    from vpt_amd.tiles import RcclFrameGather
+    sc = Scene(gpu_ctx, oracle, 32, 100, 70, tf=colour_tf(64, 1), camera=orbit_camera(100 / 70))
+    plain = sc.renderer('mcm'); plain.extinction = 9; plain.reset()
+    shard = sc.renderer('mcm', shard=(0, 1, 8)); shard.extinction = 9; shard.reset()
+    g = RcclFrameGather(shard, RcclFrameGather.unique_id(), 0, 1)
+    for k in range(5):
+        plain.render()
+        g.render()
+        if k in (0, 3, 4):
+            assert_same_bits(g.frame(), plain.getTexture(), "gathered frame %d" % k)
+    g.synchronize()
+    assert_same_bits(shard.read(N.BUFFER_MCM_RADIANCE), plain.read(N.BUFFER_MCM_RADIANCE), "state after gather pipeline")
+    g.destroy(); plain.destroy(); shard.destroy(); sc.gvol.destroy()
+
+
 def test_errors_are_loud(gpu_ctx):
     with pytest.raises(RuntimeError, match="No suitable class"):
         vpt_amd.RendererFactory('iso')

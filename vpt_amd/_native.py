@@ -29,6 +29,8 @@ SYMBOLS = [
     "vpt_renderer_set_render_target",
     "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile",
+    "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_synchronize",
+    "vpt_gather_read_frame",
     "vpt_probe_math", "vpt_probe_sample",
 ]
 
@@ -91,6 +93,8 @@ def lib():
         "vpt_renderer_set_profiling": [P, I],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],
         "vpt_probe_math": [P, I, P, P, SZ], "vpt_probe_sample": [P, P, P, SZ],
+        "vpt_gather_unique_id": [P], "vpt_gather_create": [P, P, I, I, PP], "vpt_gather_destroy": [P],
+        "vpt_gather_render": [P, UP], "vpt_gather_synchronize": [P], "vpt_gather_read_frame": [P, P, SZ],
     }
     for name, argtypes in sig.items():
         f = getattr(L, name)

@@ -3,6 +3,7 @@
 //        -fno-gpu-flush-denormals-to-zero -shared -fPIC (see vpt_amd/csrc/Makefile)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -712,5 +713,159 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(din); hipFree(dout);
     if (e != hipSuccess) return fail(VPT_ERR_HIP, "probe: %s", hipGetErrorString(e));
+    return VPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU frame gather over RCCL (dlopen'ed: the library stays loadable where RCCL is absent)
+// ---------------------------------------------------------------------------------------------
+typedef struct ncclComm *ncclComm_t_;
+typedef struct { char internal[128]; } ncclUniqueId_;
+struct Rccl {
+    void *handle;
+    int (*GetUniqueId)(ncclUniqueId_ *);
+    int (*CommInitRank)(ncclComm_t_ *, int, ncclUniqueId_, int);
+    int (*CommDestroy)(ncclComm_t_);
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t_, hipStream_t);
+    const char *(*GetErrorString)(int);
+};
+static Rccl g_rccl = {};
+static int rccl_load() {
+    if (g_rccl.handle) return VPT_OK;
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(VPT_ERR_UNSUPPORTED, "RCCL not loadable: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(ncclUniqueId_ *))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(ncclComm_t_ *, int, ncclUniqueId_, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(ncclComm_t_))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, ncclComm_t_, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
+        return fail(VPT_ERR_UNSUPPORTED, "RCCL library lacks an expected symbol");
+    g_rccl.handle = h;
+    return VPT_OK;
+}
+#define RCCL_TRY(expr) do { int e_ = (expr); if (e_ != 0) \
+    return fail(VPT_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(e_)); } while (0)
+
+struct vpt_gather {
+    vpt_renderer *r;
+    int rank, world;
+    ncclComm_t_ comm;
+    hipStream_t comm_stream;
+    size_t send_bytes;                 // W * local_h * 8
+    void *send[2], *recv[2];
+    hipEvent_t rendered[2], gathered[2];
+    bool used[2];
+    uint64_t frames;
+    void *assembled;                   // [H][W] RGBA16F scratch for read_frame
+};
+
+// gathered [world][local_h][W] -> [H][W]: global row j lives on rank (j / R) % G at local row ((j / R) / G) * R + j % R
+__global__ void k_assemble_rows(const uint2 *gathered, uint2 *out, int W, int H, int local_h, int G, int R) {
+    int j = (int)blockIdx.y;
+    int b = j / R;
+    int rank = (G == 1) ? 0 : b % G;
+    int lrow = (G == 1) ? j : (b / G) * R + (j - b * R);
+    const uint2 *src = gathered + ((size_t)rank * local_h + lrow) * W;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < W; i += (int)(gridDim.x * blockDim.x)) out[(size_t)j * W + i] = src[i];
+}
+
+extern "C" int vpt_gather_unique_id(void *id128) {
+    if (!id128) return fail(VPT_ERR_INVALID, "id is null");
+    VPT_TRY(rccl_load());
+    ncclUniqueId_ id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return VPT_OK;
+}
+extern "C" int vpt_gather_destroy(vpt_gather *g) {
+    if (!g) return VPT_OK;
+    hipSetDevice(g->r->ctx->device);
+    hipStreamSynchronize(g->r->ctx->stream);
+    if (g->comm_stream) hipStreamSynchronize(g->comm_stream);
+    vpt_renderer_set_render_target(g->r, nullptr, 0);
+    if (g->comm) g_rccl.CommDestroy(g->comm);
+    for (int b = 0; b < 2; b++) {
+        if (g->send[b]) hipFree(g->send[b]);
+        if (g->recv[b]) hipFree(g->recv[b]);
+        if (g->rendered[b]) hipEventDestroy(g->rendered[b]);
+        if (g->gathered[b]) hipEventDestroy(g->gathered[b]);
+    }
+    if (g->assembled) hipFree(g->assembled);
+    if (g->comm_stream) hipStreamDestroy(g->comm_stream);
+    delete g;
+    return VPT_OK;
+}
+extern "C" int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, int world, vpt_gather **out) {
+    if (!r || !id128 || !out) return fail(VPT_ERR_INVALID, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(VPT_ERR_INVALID, "bad rank %d / world %d", rank, world);
+    if (r->G != world || r->g != rank) return fail(VPT_ERR_INVALID, "renderer is sharded %d/%d, gather asked for %d/%d", r->g, r->G, rank, world);
+    VPT_TRY(rccl_load());
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    vpt_gather *g = new vpt_gather();
+    memset(g, 0, sizeof(*g));
+    g->r = r; g->rank = rank; g->world = world;
+    g->send_bytes = (size_t)r->W * r->local_h * 8;
+    int rc = VPT_OK;
+    hipError_t e = hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipMalloc(&g->send[b], g->send_bytes);
+        if (e == hipSuccess) e = hipMalloc(&g->recv[b], g->send_bytes * world);
+        if (e == hipSuccess) e = hipMemset(g->send[b], 0, g->send_bytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->rendered[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->gathered[b], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipMalloc(&g->assembled, (size_t)r->W * r->H * 8);
+    if (e != hipSuccess) rc = fail(VPT_ERR_HIP, "gather buffers: %s", hipGetErrorString(e));
+    if (rc == VPT_OK) {
+        ncclUniqueId_ id;
+        memcpy(&id, id128, sizeof(id));
+        int ne = g_rccl.CommInitRank(&g->comm, world, id, rank);
+        if (ne != 0) { g->comm = nullptr; rc = fail(VPT_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(ne)); }
+    }
+    if (rc != VPT_OK) { char keep[512]; strncpy(keep, g_err, sizeof(keep)); keep[511] = 0; vpt_gather_destroy(g); strncpy(g_err, keep, sizeof(g_err)); return rc; }
+    *out = g;
+    return VPT_OK;
+}
+extern "C" int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u) {
+    if (!g || !u) return fail(VPT_ERR_INVALID, "null argument");
+    vpt_renderer *r = g->r;
+    hipStream_t cs = r->ctx->stream;
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    int b = (int)(g->frames & 1);
+    if (g->used[b]) HIP_TRY(hipStreamWaitEvent(cs, g->gathered[b], 0));     // the gather that last read send[b] is done
+    VPT_TRY(vpt_renderer_set_render_target(r, g->send[b], g->send_bytes));
+    VPT_TRY(vpt_renderer_render(r, u));
+    HIP_TRY(hipEventRecord(g->rendered[b], cs));
+    HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[b], 0));
+    RCCL_TRY(g_rccl.AllGather(g->send[b], g->recv[b], g->send_bytes, /*ncclUint8*/ 1, g->comm, g->comm_stream));
+    HIP_TRY(hipEventRecord(g->gathered[b], g->comm_stream));
+    g->used[b] = true;
+    g->frames++;
+    return VPT_OK;
+}
+extern "C" int vpt_gather_synchronize(vpt_gather *g) {
+    if (!g) return fail(VPT_ERR_INVALID, "gather is null");
+    HIP_TRY(hipSetDevice(g->r->ctx->device));
+    HIP_TRY(hipStreamSynchronize(g->r->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(g->comm_stream));
+    return VPT_OK;
+}
+extern "C" int vpt_gather_read_frame(vpt_gather *g, void *dst, size_t nbytes) {
+    if (!g || !dst) return fail(VPT_ERR_INVALID, "null argument");
+    if (g->frames == 0) return fail(VPT_ERR_INVALID, "no frame has been gathered yet");
+    vpt_renderer *r = g->r;
+    size_t need = (size_t)r->W * r->H * 8;
+    if (nbytes < need) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, need);
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    int b = (int)((g->frames - 1) & 1);
+    HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->gathered[b], 0));
+    hipLaunchKernelGGL(k_assemble_rows, dim3((unsigned)((r->W + 255) / 256), (unsigned)r->H), dim3(256), 0, g->comm_stream,
+                       (const uint2 *)g->recv[b], (uint2 *)g->assembled, r->W, r->H, r->local_h, r->G, r->R);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dst, g->assembled, need, hipMemcpyDeviceToHost, g->comm_stream));
+    HIP_TRY(hipStreamSynchronize(g->comm_stream));
     return VPT_OK;
 }

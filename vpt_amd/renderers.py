@@ -264,9 +264,12 @@ class MIPRenderer(AbstractRenderer):
     def _renderFrame(self):                                        # :119-131
         N.check(N.lib().vpt_renderer_render_frame(self._h, None))
 
+    def _prepare_frame_uniforms(self):
+        return self._prepare_generate()
+
     def _renderFused(self):
         self._bind_volume()
-        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_generate())))
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
 
 
 class EAMRenderer(AbstractRenderer):
@@ -311,10 +314,13 @@ class EAMRenderer(AbstractRenderer):
     def _renderFrame(self):
         N.check(N.lib().vpt_renderer_render_frame(self._h, None))
 
+    def _prepare_frame_uniforms(self):
+        self._prepare_generate()
+        return self._prepare_integrate()
+
     def _renderFused(self):
         self._bind_volume()
-        self._prepare_generate()
-        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_integrate())))
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
 
 
 class MCSRenderer(AbstractRenderer):
@@ -366,10 +372,13 @@ class MCSRenderer(AbstractRenderer):
     def _renderFrame(self):
         N.check(N.lib().vpt_renderer_render_frame(self._h, None))
 
+    def _prepare_frame_uniforms(self):
+        self._prepare_generate()
+        return self._prepare_integrate()
+
     def _renderFused(self):
         self._bind_volume()
-        self._prepare_generate()
-        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_integrate())))
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
 
 
 class MCMRenderer(AbstractRenderer):
@@ -414,9 +423,12 @@ class MCMRenderer(AbstractRenderer):
     def _renderFrame(self):                                        # :187-199
         N.check(N.lib().vpt_renderer_render_frame(self._h, None))
 
+    def _prepare_frame_uniforms(self):
+        return self._prepare_integrate()
+
     def _renderFused(self):
         self._bind_volume()
-        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_integrate())))
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
 
 
 for _cls in (MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer):

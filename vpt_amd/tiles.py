@@ -74,3 +74,50 @@ class FrameGather:
         if self.world == 1:
             return self.recv[k][:self.H]
         return self.recv[k].index_select(0, self.index)
+
+
+class RcclFrameGather:
+    """The same pipeline below the C ABI (vpt_gather_*): the library owns the send / receive buffers, an RCCL
+    communicator and a communication stream; one call per frame enqueues kernel + all_gather.  ``id_bytes`` is the
+    128-byte RCCL id obtained by ONE rank (``RcclFrameGather.unique_id()``) and shared with the others, e.g. through
+    ``torch.distributed.broadcast_object_list``."""
+
+    def __init__(self, renderer, id_bytes, rank, world):
+        import ctypes as C
+        from . import _native as N
+        self._N, self._C = N, C
+        self.renderer = renderer
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        N.check(N.lib().vpt_gather_create(renderer._h, buf, rank, world, C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _native as N
+        buf = C.create_string_buffer(128)
+        N.check(N.lib().vpt_gather_unique_id(buf))
+        return bytes(buf.raw)
+
+    def render(self):
+        """one AbstractRenderer.render() (fused pass) into the send buffer + asynchronous all_gather"""
+        r = self.renderer
+        r._bind_volume()
+        u = r._prepare_frame_uniforms()
+        self._N.check(self._N.lib().vpt_gather_render(self._h, self._C.byref(u)))
+
+    def synchronize(self):
+        self._N.check(self._N.lib().vpt_gather_synchronize(self._h))
+
+    def frame(self):
+        w, h = self.renderer._size()
+        out = np.empty((h, w, 4), dtype=np.float16)
+        self._N.check(self._N.lib().vpt_gather_read_frame(self._h, out.ctypes.data_as(self._C.c_void_p), out.nbytes))
+        return out
+
+    def destroy(self):
+        if self._h:
+            self._N.lib().vpt_gather_destroy(self._h)
+            self._h = None
