@@ -54,3 +54,9 @@ if __name__ == "__main__":
     if "h" in which: run('mcm', 512, 1920, 1080, 100, 10)
     if "c4" in which: run('mcm', 1024, 1920, 1080, 100, 10)
     if "c5" in which: run('mcm', 2048, 3840, 2160, 20, 3)
+    if "mcs_ext" in which:
+        for ext in (1, 10, 50, 200):
+            run('mcs', 512, 1920, 1080, 60, 6, extinction=ext)
+    if "mcm_ext" in which:
+        for ext in (1, 10, 50, 200):
+            run('mcm', 512, 1920, 1080, 60, 6, extinction=ext)

@@ -79,6 +79,8 @@ struct vpt_renderer {
     size_t events_used;
 };
 
+static const size_t COUNTER_BYTES = (size_t)VPT_COUNTER_SLOTS * VPT_COUNTER_STRIDE * sizeof(unsigned long long);
+
 static size_t frame_elem(int kind) {
     switch (kind) {
         case VPT_RENDERER_MIP: return 1;
@@ -358,8 +360,8 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->render_target = nullptr;
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
-        hipError_t e = hipMalloc(&r->samples, sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemsetAsync(r->samples, 0, sizeof(unsigned long long), c->stream);
+        hipError_t e = hipMalloc(&r->samples, COUNTER_BYTES);
+        if (e == hipSuccess) e = hipMemsetAsync(r->samples, 0, COUNTER_BYTES, c->stream);
         if (e != hipSuccess) rc = fail(VPT_ERR_HIP, "hipMalloc counter: %s", hipGetErrorString(e));
     }
     static const uint8_t default_tf[8] = { 255, 0, 0, 0, 255, 0, 0, 255 };   // AbstractRenderer.js:31-44
@@ -631,16 +633,18 @@ extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t
 extern "C" int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count) {
     if (!r || !count) return fail(VPT_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(r->ctx->device));
-    unsigned long long dev = 0;
-    HIP_TRY(hipMemcpyAsync(&dev, r->samples, sizeof(dev), hipMemcpyDeviceToHost, r->ctx->stream));
+    unsigned long long slots[VPT_COUNTER_SLOTS * VPT_COUNTER_STRIDE];
+    HIP_TRY(hipMemcpyAsync(slots, r->samples, COUNTER_BYTES, hipMemcpyDeviceToHost, r->ctx->stream));
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
-    *count = (uint64_t)dev + r->samples_host;
+    uint64_t dev = 0;
+    for (int i = 0; i < VPT_COUNTER_SLOTS; i++) dev += slots[i * VPT_COUNTER_STRIDE];
+    *count = dev + r->samples_host;
     return VPT_OK;
 }
 extern "C" int vpt_renderer_clear_sample_count(vpt_renderer *r) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
     HIP_TRY(hipSetDevice(r->ctx->device));
-    HIP_TRY(hipMemsetAsync(r->samples, 0, sizeof(unsigned long long), r->ctx->stream));
+    HIP_TRY(hipMemsetAsync(r->samples, 0, COUNTER_BYTES, r->ctx->stream));
     r->samples_host = 0;
     return VPT_OK;
 }

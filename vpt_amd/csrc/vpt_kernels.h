@@ -91,9 +91,20 @@ VPT_DEV float4 sample_volume_color(const PassArgs &a, const LdsTables &t, f3 p) 
     float r = sample_volume<WIDE>(a.vol, t, p);
     return sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
 }
+// volume-sample counter: wave reduction (shuffles) -> workgroup reduction (one LDS word) -> ONE global atomic per
+// workgroup, spread over VPT_COUNTER_SLOTS addresses on separate 128-B lines (32 k same-address atomics per frame
+// serialised at ~12 ns each and dominated the cheap passes); the host sums the slots.
+#define VPT_COUNTER_SLOTS 64
+#define VPT_COUNTER_STRIDE 16      // unsigned long long words per slot = 128 B
 VPT_DEV void count_samples(unsigned long long *ctr, uint32_t n) {
+    __shared__ uint32_t block_sum;
+    if (threadIdx.x == 0) block_sum = 0;
+    __syncthreads();
     for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
-    if (((int)threadIdx.x & 63) == 0 && n) atomicAdd(ctr, (unsigned long long)n);
+    if (((int)threadIdx.x & 63) == 0 && n) atomicAdd(&block_sum, n);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_sum)
+        atomicAdd(ctr + (size_t)(blockIdx.x % VPT_COUNTER_SLOTS) * VPT_COUNTER_STRIDE, (unsigned long long)block_sum);
 }
 VPT_DEV uint2 pack_half4(float x, float y, float z, float w) {
     uint2 r;
