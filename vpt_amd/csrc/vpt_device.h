@@ -303,16 +303,15 @@ struct LdsTables {
 // LINEAR filter cell: u = s*N - 0.5 clamped to [0, N-1]; i = trunc(u); f = u - i.
 // Equal to the GL definition (taps clamp(i0), clamp(i0+1) of the unclamped u; oracle linear_coord) because every
 // clamped case degenerates to an exact edge value: u < 0 -> (t[0], f = 0); u >= N-1 -> (t[N-1], apron = t[N-1]).
+// 4 instructions: v_fma, v_med3 (clamp; a NaN operand makes it return min3 of the others = 0), v_fract (= u - floor(u),
+// exact for u >= 0), v_cvt_u32 (truncation == floor for u >= 0).
 VPT_DEV void linear_cell(float s, float fn, float hi, uint32_t &i, float &f) {
-    float u = fmaf(s, fn, -0.5f);
-    u = vmin(vmax(u, 0.0f), hi);       // NaN -> 0 (maxNum)
-    float fl = floorf(u);
-    f = u - fl;
-    i = (uint32_t)fl;
+    float u = __builtin_amdgcn_fmed3f(fmaf(s, fn, -0.5f), 0.0f, hi);
+    f = __builtin_amdgcn_fractf(u);
+    i = (uint32_t)u;
 }
 VPT_DEV uint32_t nearest_cell(float s, float fn, float hi) {
-    float u = vmin(vmax(s * fn, 0.0f), hi);
-    return (uint32_t)u;                // u >= 0: truncation == floor
+    return (uint32_t)__builtin_amdgcn_fmed3f(s * fn, 0.0f, hi);   // u >= 0: truncation == floor
 }
 // texture(uVolume, p).r for an R8 volume (Volume.js:49-60): integer texel values interpolated x, y, z,
 // normalised once by * fl32(1/255)  (255 * VPT_INV255 == 1.0f exactly).
@@ -325,9 +324,15 @@ VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_
     }
     return v.bricks + (uint32_t)(t.tx[x] + t.ty[y] + t.tz[z]);
 }
-template <bool WIDE>
+// V: variant bits fixed at launch — bit 0 = 64-bit offset tables (WIDE), bit 1 = NEAREST filter.  No run-time branch
+// inside the sampler: consecutive samples of a ray stay straight-line code, so their loads are issued together.
+#define VPT_V_WIDE    1
+#define VPT_V_NEAREST 2
+#define VPT_V_ALIGNED 4   // fetch the two tap windows as dword-aligned 12-byte loads + v_alignbyte (texture-path bound kernels)
+template <int V>
 VPT_DEV float sample_volume(const DevVolume &v, const LdsTables &t, f3 p) {
-    if (v.filter == 0) {
+    constexpr bool WIDE = (V & VPT_V_WIDE) != 0;
+    if (V & VPT_V_NEAREST) {
         uint32_t x = nearest_cell(p.x, v.fnx, v.hx), y = nearest_cell(p.y, v.fny, v.hy), z = nearest_cell(p.z, v.fnz, v.hz);
         return (float)(*cell_addr<WIDE>(v, t, x, y, z)) * VPT_INV255;
     }
@@ -336,11 +341,25 @@ VPT_DEV float sample_volume(const DevVolume &v, const LdsTables &t, f3 p) {
     linear_cell(p.y, v.fny, v.hy, y, fy);
     linear_cell(p.z, v.fnz, v.hz, z, fz);
     const uint8_t *a = cell_addr<WIDE>(v, t, x, y, z);
-    // taps: +0,+1 (y,z) ; +5,+6 (y+1,z) ; +25,+26 (y,z+1) ; +30,+31 (y+1,z+1): two 8-byte windows of one line
-    uint64_t w0, w1;
-    __builtin_memcpy(&w0, a, 8);
-    __builtin_memcpy(&w1, a + 25, 8);
-    uint32_t l0 = (uint32_t)w0, h0 = (uint32_t)(w0 >> 32), l1 = (uint32_t)w1, h1 = (uint32_t)(w1 >> 32);
+    // taps: +0,+1 (y,z) ; +5,+6 (y+1,z) ; +25,+26 (y,z+1) ; +30,+31 (y+1,z+1): two 8-byte windows of one line.
+    // tools/gather_rates.hip (MI355X, L1-resident gathers): a dword-aligned 8/12/16-byte wave load costs ~27-33 cycles
+    // of the CU's texture path, a byte-aligned 8-byte one 2x that.  Kernels bound by that path (MIP, EAM: ~60 VALU
+    // instructions per sample) fetch 12 aligned bytes per window and realign in registers (v_alignbyte_b32); the
+    // VALU-bound MCM / MCS keep the two unaligned 8-byte loads (fewer instructions).
+    uint32_t l0, h0, l1, h1;
+    if (V & VPT_V_ALIGNED) {
+        struct W3 { uint32_t a, b, c; };
+        uintptr_t p0 = (uintptr_t)a, p1 = p0 + 25;
+        W3 q0 = *(const W3 *)(p0 & ~(uintptr_t)3), q1 = *(const W3 *)(p1 & ~(uintptr_t)3);
+        uint32_t s0 = (uint32_t)p0 & 3u, s1 = (uint32_t)p1 & 3u;
+        l0 = __builtin_amdgcn_alignbyte(q0.b, q0.a, s0); h0 = __builtin_amdgcn_alignbyte(q0.c, q0.b, s0);
+        l1 = __builtin_amdgcn_alignbyte(q1.b, q1.a, s1); h1 = __builtin_amdgcn_alignbyte(q1.c, q1.b, s1);
+    } else {
+        uint64_t w0, w1;
+        __builtin_memcpy(&w0, a, 8);
+        __builtin_memcpy(&w1, a + 25, 8);
+        l0 = (uint32_t)w0; h0 = (uint32_t)(w0 >> 32); l1 = (uint32_t)w1; h1 = (uint32_t)(w1 >> 32);
+    }
     float c000 = (float)(l0 & 0xffu), c100 = (float)((l0 >> 8) & 0xffu);
     float c010 = (float)((h0 >> 8) & 0xffu), c110 = (float)((h0 >> 16) & 0xffu);
     float c001 = (float)(l1 & 0xffu), c101 = (float)((l1 >> 8) & 0xffu);
@@ -355,11 +374,9 @@ VPT_DEV float sample_volume(const DevVolume &v, const LdsTables &t, f3 p) {
 // (value, forward difference) pairs.  R8 volume => lookup at (r, 0): both bilinear rows clamp to row 0, so row 0
 // alone is exact.  Same clamping argument as linear_cell.
 VPT_DEV float4 sample_tf(const float4 *tf_pairs, float tf_fw, float tf_hi, float r) {
-    float u = fmaf(r, tf_fw, -0.5f);
-    u = vmin(vmax(u, 0.0f), tf_hi);
-    float fl = floorf(u);
-    float f = u - fl;
-    uint32_t i = (uint32_t)fl;
+    float u = __builtin_amdgcn_fmed3f(fmaf(r, tf_fw, -0.5f), 0.0f, tf_hi);
+    float f = __builtin_amdgcn_fractf(u);
+    uint32_t i = (uint32_t)u;
     float4 a = tf_pairs[2 * i], d = tf_pairs[2 * i + 1];
     return make_float4(fmaf(f, d.x, a.x), fmaf(f, d.y, a.y), fmaf(f, d.z, a.z), fmaf(f, d.w, a.w));
 }

@@ -463,10 +463,24 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(VPT_BLOCK), lds, r->ctx->stream, a);
     return VPT_OK;
 }
-// picks the 32-bit or 64-bit offset-table instantiation
-#define LAUNCH_S(kernel_narrow, kernel_wide, r, a) \
-    VPT_TRY((r)->vol->wide ? launch_sampling(kernel_wide, (r), (a), (unsigned)(r)->ntiles) \
-                           : launch_sampling(kernel_narrow, (r), (a), (unsigned)(r)->ntiles))
+// picks the instantiation for (offset-table width, filter): V = VPT_V_WIDE | VPT_V_NEAREST bits
+#define LAUNCH_S(KT, r, a) do { \
+    int v_ = ((r)->vol->wide ? VPT_V_WIDE : 0) | ((r)->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0); \
+    unsigned g_ = (unsigned)(r)->ntiles; \
+    switch (v_) { \
+        case 0: VPT_TRY(launch_sampling(KT(0), (r), (a), g_)); break; \
+        case 1: VPT_TRY(launch_sampling(KT(1), (r), (a), g_)); break; \
+        case 2: VPT_TRY(launch_sampling(KT(2), (r), (a), g_)); break; \
+        default: VPT_TRY(launch_sampling(KT(3), (r), (a), g_)); break; \
+    } } while (0)
+#define K_MIP0(V) (k_mip<0, V | VPT_V_ALIGNED>)
+#define K_MIP1(V) (k_mip<1, V | VPT_V_ALIGNED>)
+#define K_EAM0(V) (k_eam<0, V | VPT_V_ALIGNED>)
+#define K_EAM1(V) (k_eam<1, V | VPT_V_ALIGNED>)
+#define K_MCS0(V) (k_mcs<0, V>)
+#define K_MCS1(V) (k_mcs<1, V>)
+#define K_MCM0(V) (k_mcm_integrate<false, V>)
+#define K_MCM1(V) (k_mcm_integrate<true, V>)
 
 static int check_step(const vpt_uniforms *u) {
     // step sizes <= 0 or NaN would never advance t: the reference's spinner enforces min 1 (MIPRenderer.js:24, EAMRenderer.js:34)
@@ -517,9 +531,9 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
     {
         Timed t(r, true);
         switch (r->kind) {
-            case VPT_RENDERER_MIP: LAUNCH_S((k_mip<0, false>), (k_mip<0, true>), r, a); break;
-            case VPT_RENDERER_EAM: LAUNCH_S((k_eam<0, false>), (k_eam<0, true>), r, a); break;
-            case VPT_RENDERER_MCS: LAUNCH_S((k_mcs<0, false>), (k_mcs<0, true>), r, a); break;
+            case VPT_RENDERER_MIP: LAUNCH_S(K_MIP0, r, a); break;
+            case VPT_RENDERER_EAM: LAUNCH_S(K_EAM0, r, a); break;
+            case VPT_RENDERER_MCS: LAUNCH_S(K_MCS0, r, a); break;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -536,7 +550,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_integrate, r, a, 0); break;
         case VPT_RENDERER_MCM: {
             Timed t(r, true);
-            LAUNCH_S((k_mcm_integrate<false, false>), (k_mcm_integrate<false, true>), r, a);
+            LAUNCH_S(K_MCM0, r, a);
             r->samples_host += r->valid_pixels * (uint64_t)u->steps;   // exactly W*H*steps per pass (MCMRenderer.glsl:129-133)
         } break;
     }
@@ -566,11 +580,11 @@ extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
     {
         Timed t(r, true);
         switch (r->kind) {
-            case VPT_RENDERER_MIP: LAUNCH_S((k_mip<1, false>), (k_mip<1, true>), r, a); break;
-            case VPT_RENDERER_EAM: LAUNCH_S((k_eam<1, false>), (k_eam<1, true>), r, a); break;
-            case VPT_RENDERER_MCS: LAUNCH_S((k_mcs<1, false>), (k_mcs<1, true>), r, a); break;
+            case VPT_RENDERER_MIP: LAUNCH_S(K_MIP1, r, a); break;
+            case VPT_RENDERER_EAM: LAUNCH_S(K_EAM1, r, a); break;
+            case VPT_RENDERER_MCS: LAUNCH_S(K_MCS1, r, a); break;
             case VPT_RENDERER_MCM:
-                LAUNCH_S((k_mcm_integrate<true, false>), (k_mcm_integrate<true, true>), r, a);
+                LAUNCH_S(K_MCM1, r, a);
                 r->samples_host += r->valid_pixels * (uint64_t)u->steps;
                 break;
         }
@@ -707,10 +721,14 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
     if (e != hipSuccess) { hipFree(din); return fail(VPT_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpyAsync(din, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        if (r->vol->wide)
-            hipLaunchKernelGGL(k_probe_sample<true>, dim3((unsigned)((n + 255) / 256)), dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n);
-        else
-            hipLaunchKernelGGL(k_probe_sample<false>, dim3((unsigned)((n + 255) / 256)), dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n);
+        int v = (r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0);
+        dim3 grid((unsigned)((n + 255) / 256));
+        switch (v) {
+            case 0: hipLaunchKernelGGL(k_probe_sample<0>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 1: hipLaunchKernelGGL(k_probe_sample<1>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 2: hipLaunchKernelGGL(k_probe_sample<2>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            default: hipLaunchKernelGGL(k_probe_sample<3>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(rgba, dout, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);

@@ -14,6 +14,7 @@
 #define VPT_TILE        16
 #define VPT_BLOCK       256
 #define VPT_MAX_TRACK_ITERS 65536u
+#define VPT_UNROLL      4          // samples in flight per ray in the MIP / EAM marches
 
 struct PixMap {
     int W, H;          // full image plane
@@ -86,9 +87,9 @@ VPT_DEV LdsTables stage_lds(float4 *lds, const PassArgs &a) {
     return r;
 }
 // sampleVolumeColor: MIPRenderer.glsl:45-49 (= EAM :46-50, MCS :64-68, MCM :85-89)
-template <bool WIDE>
+template <int V>
 VPT_DEV float4 sample_volume_color(const PassArgs &a, const LdsTables &t, f3 p) {
-    float r = sample_volume<WIDE>(a.vol, t, p);
+    float r = sample_volume<V>(a.vol, t, p);
     return sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
 }
 // volume-sample counter: wave reduction (shuffles) -> workgroup reduction (one LDS word) -> ONE global atomic per
@@ -117,7 +118,7 @@ VPT_DEV uint2 pack_half4(float x, float y, float z, float w) {
 // MIP — MIPRenderer.glsl
 // =============================================================================================
 // generate/fragment main(): MIPRenderer.glsl:51-72; returns the unorm8 frame value
-template <bool WIDE>
+template <int V>
 VPT_DEV uint32_t mip_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
     f3 rf, rt;
     unproject(pixel_ndc(p.i, a.pm.W), pixel_ndc(p.j, a.pm.H), a.mvp_inv, rf, rt);
@@ -128,28 +129,44 @@ VPT_DEV uint32_t mip_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, 
     if (!(tb.x >= tb.y)) {
         f3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
         float tt = 0.0f, val = 0.0f, offset = a.offset;
+        // The march is latency bound (LDS table -> brick line -> LDS transfer function per sample, ~1.5 us): the sample
+        // positions do not depend on sampled values, so VPT_UNROLL samples are put in flight together.  The trip count
+        // is still decided by the fp32 accumulation of t (do { ... } while (t < 1)); samples past the exit are fetched
+        // speculatively at a valid position and discarded; max() is exact, so the grouping does not change the result.
+        bool more = true;
         do {
-            f3 pos = mix3(from, to, offset);
-            val = vmax(sample_volume_color<WIDE>(a, t, pos).w, val);
-            ns++;
-            tt += a.step;
-            float m = offset + a.step;
-            offset = m - floorf(m);
-        } while (tt < 1.0f);
+            f3 pos[VPT_UNROLL]; bool act[VPT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < VPT_UNROLL; u++) {
+                act[u] = more;
+                pos[u] = mix3(from, to, offset);
+                if (more) {
+                    tt += a.step;
+                    float m = offset + a.step;
+                    offset = m - floorf(m);
+                    more = tt < 1.0f;
+                }
+            }
+            float al[VPT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < VPT_UNROLL; u++) al[u] = sample_volume_color<V>(a, t, pos[u]).w;
+#pragma unroll
+            for (int u = 0; u < VPT_UNROLL; u++) if (act[u]) { val = vmax(al[u], val); ns++; }
+        } while (more);
         out = val;
     }
     return to_unorm8(out);
 }
 // MODE 0: _generateFrame only (frame <- value).  MODE 1: whole render(): generate, integrate
 // (MIPRenderer.glsl:105-109, max on unorm8), renderFrame (:141-144) in one pass.
-template <int MODE, bool WIDE>
+template <int MODE, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_mip(PassArgs a) {
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<WIDE>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        uint32_t q = mip_pixel<WIDE>(a, t, p, ns);
+        uint32_t q = mip_pixel<V>(a, t, p, ns);
         uint8_t *frame = (uint8_t *)a.frame, *acc = (uint8_t *)a.acc;
         if (MODE == 0) {
             frame[p.k] = (uint8_t)q;
@@ -184,7 +201,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mip_reset(PassArgs a) {   // MIPR
 // EAM — EAMRenderer.glsl
 // =============================================================================================
 // generate/fragment main(): EAMRenderer.glsl:52-80; returns packed RGBA8
-template <bool WIDE>
+template <int V>
 VPT_DEV uint32_t eam_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
     f3 rf, rt;
     unproject(pixel_ndc(p.i, a.pm.W), pixel_ndc(p.j, a.pm.H), a.mvp_inv, rf, rt);
@@ -198,15 +215,30 @@ VPT_DEV uint32_t eam_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, 
         float tt = a.step * a.offset;
         float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;
         float kk = ray_step_length * a.extinction;
-        while (tt < 1.0f && aw < 0.99f) {
-            f3 pos = mix3(from, to, tt);
-            float4 c = sample_volume_color<WIDE>(a, t, pos);
-            ns++;
-            c.w *= kk;
-            c.x *= c.w; c.y *= c.w; c.z *= c.w;
-            float w = 1.0f - aw;
-            ax = fmaf(w, c.x, ax); ay = fmaf(w, c.y, ay); az = fmaf(w, c.z, az); aw = fmaf(w, c.w, aw);
-            tt += a.step;
+        // while (t < 1 && A.a < 0.99): the fetch positions depend only on t, so VPT_UNROLL samples are fetched together
+        // (speculatively past early termination) and composited in order under the reference's per-sample condition.
+        bool alive = true;
+        while (alive) {
+            float tq[VPT_UNROLL];
+            tq[0] = tt;
+#pragma unroll
+            for (int u = 1; u < VPT_UNROLL; u++) tq[u] = tq[u - 1] + a.step;
+            float4 c[VPT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < VPT_UNROLL; u++) c[u] = sample_volume_color<V>(a, t, mix3(from, to, tq[u]));
+#pragma unroll
+            for (int u = 0; u < VPT_UNROLL; u++) {
+                if (alive && tq[u] < 1.0f && aw < 0.99f) {
+                    ns++;
+                    float cw = c[u].w * kk;
+                    float cx = c[u].x * cw, cy = c[u].y * cw, cz = c[u].z * cw;
+                    float w = 1.0f - aw;
+                    ax = fmaf(w, cx, ax); ay = fmaf(w, cy, ay); az = fmaf(w, cz, az); aw = fmaf(w, cw, aw);
+                    tt = tq[u] + a.step;
+                } else {
+                    alive = false;
+                }
+            }
         }
         if (aw > 1.0f) { float ia = rcp_nr(aw); ax *= ia; ay *= ia; az *= ia; }
         ox = ax; oy = ay; oz = az;
@@ -226,14 +258,14 @@ VPT_DEV uint2 eam_to_half4(uint32_t q) {   // render: EAMRenderer.glsl:151-153
     return pack_half4(from_unorm8(q & 0xffu), from_unorm8((q >> 8) & 0xffu),
                       from_unorm8((q >> 16) & 0xffu), from_unorm8(q >> 24));
 }
-template <int MODE, bool WIDE>
+template <int MODE, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_eam(PassArgs a) {
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<WIDE>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        uint32_t q = eam_pixel<WIDE>(a, t, p, ns);
+        uint32_t q = eam_pixel<V>(a, t, p, ns);
         uint32_t *frame = (uint32_t *)a.frame, *acc = (uint32_t *)a.acc;
         if (MODE == 0) {
             frame[p.k] = q;
@@ -265,7 +297,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_eam_reset(PassArgs a) {   // EAMR
 // MCS — MCSRenderer.glsl
 // =============================================================================================
 // sampleDistance: MCSRenderer.glsl:70-87
-template <bool WIDE>
+template <int V>
 VPT_DEV float mcs_sample_distance(const PassArgs &a, const LdsTables &t, uint32_t &state, f3 from, f3 to, uint32_t &ns) {
     float max_distance = length3(sub3(from, to));
     float inv_max = rcp_nr(max_distance);
@@ -274,14 +306,14 @@ VPT_DEV float mcs_sample_distance(const PassArgs &a, const LdsTables &t, uint32_
         dist += random_exponential(state, a.inv_extinction);
         if (!(dist <= max_distance)) break;
         f3 p = mix3(from, to, dist * inv_max);
-        float4 ts = sample_volume_color<WIDE>(a, t, p);
+        float4 ts = sample_volume_color<V>(a, t, p);
         ns++;
         if (random_uniform(state) < ts.w) break;
     }
     return dist;
 }
 // sampleTransmittance: MCSRenderer.glsl:89-105
-template <bool WIDE>
+template <int V>
 VPT_DEV float mcs_sample_transmittance(const PassArgs &a, const LdsTables &t, uint32_t &state, f3 from, f3 to, uint32_t &ns) {
     float max_distance = length3(sub3(from, to));
     float inv_max = rcp_nr(max_distance);
@@ -290,14 +322,14 @@ VPT_DEV float mcs_sample_transmittance(const PassArgs &a, const LdsTables &t, ui
         dist += random_exponential(state, a.inv_extinction);
         if (!(dist <= max_distance)) break;
         f3 p = mix3(from, to, dist * inv_max);
-        float4 ts = sample_volume_color<WIDE>(a, t, p);
+        float4 ts = sample_volume_color<V>(a, t, p);
         ns++;
         tr *= 1.0f - ts.w;
     }
     return tr;
 }
 // generate/fragment main(): MCSRenderer.glsl:107-137
-template <bool WIDE>
+template <int V>
 VPT_DEV float4 mcs_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
     float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
     f3 rf, rt;
@@ -310,16 +342,16 @@ VPT_DEV float4 mcs_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, ui
     f3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
     float max_distance = length3(sub3(from, to));
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
-    float dist = mcs_sample_distance<WIDE>(a, t, state, from, to, ns);
+    float dist = mcs_sample_distance<V>(a, t, state, from, to, ns);
     if (!(dist <= max_distance)) return sample_environment(a.env, dir_unit);
     from = mix3(from, to, dist * rcp_nr(max_distance));
     f2 tb2 = intersect_cube(from, a.light);
     tb2.y = vmax(tb2.y, 0.0f);
     to = madd3(from, tb2.y, a.light);
-    float4 diffuse = sample_volume_color<WIDE>(a, t, from);
+    float4 diffuse = sample_volume_color<V>(a, t, from);
     ns++;
     float4 light = sample_environment(a.env, a.light);
-    float tr = mcs_sample_transmittance<WIDE>(a, t, state, from, to, ns);
+    float tr = mcs_sample_transmittance<V>(a, t, state, from, to, ns);
     return make_float4((diffuse.x * light.x) * tr, (diffuse.y * light.y) * tr,
                        (diffuse.z * light.z) * tr, (diffuse.w * light.w) * tr);
 }
@@ -327,14 +359,14 @@ VPT_DEV float4 mcs_mix(float4 acc, float4 frame, float inv) {   // MCSRenderer.g
     return make_float4(fmaf(frame.x - acc.x, inv, acc.x), fmaf(frame.y - acc.y, inv, acc.y),
                        fmaf(frame.z - acc.z, inv, acc.z), fmaf(frame.w - acc.w, inv, acc.w));
 }
-template <int MODE, bool WIDE>
+template <int MODE, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<WIDE>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        float4 c = mcs_pixel<WIDE>(a, t, p, ns);
+        float4 c = mcs_pixel<V>(a, t, p, ns);
         float4 *frame = (float4 *)a.frame, *acc = (float4 *)a.acc;
         if (MODE == 0) {
             frame[p.k] = c;
@@ -445,10 +477,10 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
 
 // integrate/fragment main(): MCMRenderer.glsl:116-172.  FUSE_RENDER additionally performs
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
-template <bool FUSE_RENDER, bool WIDE>
-__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_mcm_integrate(PassArgs a) {
+template <bool FUSE_RENDER, int V>
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_integrate(PassArgs a) {
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<WIDE>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
     float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
@@ -466,7 +498,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     for (uint32_t s = 0u; s < a.steps; s++) {
         float dist = random_exponential(state, a.inv_extinction);
         ph.position = madd3(ph.position, dist, ph.direction);
-        float4 vs = sample_volume_color<WIDE>(a, t, ph.position);
+        float4 vs = sample_volume_color<V>(a, t, ph.position);
         float p_null = 1.0f - vs.w;
         float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
         float p_abs = 1.0f - p_null - p_scat;
@@ -561,11 +593,11 @@ __global__ void k_probe_math(int which, const float *in, float *out, size_t n) {
     }
     out[t] = r;
 }
-template <bool WIDE>
+template <int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_probe_sample(PassArgs a, const float *xyz, float4 *out, size_t n) {
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<WIDE>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = sample_volume_color<WIDE>(a, t, f3{ xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] });
+    out[i] = sample_volume_color<V>(a, t, f3{ xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] });
 }
