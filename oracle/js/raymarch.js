@@ -163,8 +163,8 @@ const pixelNdc = (i, n) => f(f((2 * i + 1) / n) - 1);
 const ndcToUv = p => fma(p, 0.5, 0.5);
 const P = new Float32Array(3), Q = new Float32Array(3);
 function unprojectPoint(m, x, y, z, out) {
-    const rx = fma(m[12], 1, fma(m[8], z, fma(m[4], y, f(m[0] * x)))), ry = fma(m[13], 1, fma(m[9], z, fma(m[5], y, f(m[1] * x))));
-    const rz = fma(m[14], 1, fma(m[10], z, fma(m[6], y, f(m[2] * x)))), rw = fma(m[15], 1, fma(m[11], z, fma(m[7], y, f(m[3] * x))));
+    const rx = fma(m[4], y, fma(m[0], x, fma(m[8], z, m[12]))), ry = fma(m[5], y, fma(m[1], x, fma(m[9], z, m[13])));
+    const rz = fma(m[6], y, fma(m[2], x, fma(m[10], z, m[14]))), rw = fma(m[7], y, fma(m[3], x, fma(m[11], z, m[15])));
     const i = rcpNr(rw);
     out[0] = f(rx * i); out[1] = f(ry * i); out[2] = f(rz * i);
 }

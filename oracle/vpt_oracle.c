@@ -440,10 +440,11 @@ static v4 sample_environment(const scene_tables *t, v3 d) {
 /* inverseMvp * (x, y, z, 1), column-major, fma chain */
 static inline v4 mat4_mul_point(const float *m, float x, float y, float z) {
     v4 r;
-    r.x = fmaf(m[12], 1.0f, fmaf(m[8],  z, fmaf(m[4], y, m[0] * x)));
-    r.y = fmaf(m[13], 1.0f, fmaf(m[9],  z, fmaf(m[5], y, m[1] * x)));
-    r.z = fmaf(m[14], 1.0f, fmaf(m[10], z, fmaf(m[6], y, m[2] * x)));
-    r.w = fmaf(m[15], 1.0f, fmaf(m[11], z, fmaf(m[7], y, m[3] * x)));
+    /* constant part first (m[8..11]*z + m[12..15], z = +-1), then the x and y terms; GLSL leaves the order open */
+    r.x = fmaf(m[4], y, fmaf(m[0], x, fmaf(m[8],  z, m[12])));
+    r.y = fmaf(m[5], y, fmaf(m[1], x, fmaf(m[9],  z, m[13])));
+    r.z = fmaf(m[6], y, fmaf(m[2], x, fmaf(m[10], z, m[14])));
+    r.w = fmaf(m[7], y, fmaf(m[3], x, fmaf(m[11], z, m[15])));
     return r;
 }
 /* mixins/unproject.glsl:3-10, evaluated at the pixel's own NDC (the reference interpolates the

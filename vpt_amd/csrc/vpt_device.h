@@ -221,13 +221,16 @@ VPT_DEV uint16_t to_half_bits(float f) { return __half_as_ushort(__float2half_rn
 
 // ---- ray set-up -----------------------------------------------------------------------------
 struct Mat4 { float m[16]; };
+// inverseMvp * (x, y, z, 1): the constant part is summed first (c = m[8..11]*z + m[12..15], a pass constant for z = -1
+// and z = +1), then the x and y terms are accumulated — 2 fma per row in the per-event code.  GLSL does not fix the
+// summation order of a matrix-vector product.
 VPT_DEV float4 mat4_mul_point(const Mat4 &M, float x, float y, float z) {
     const float *m = M.m;
     float4 r;
-    r.x = fmaf(m[12], 1.0f, fmaf(m[8],  z, fmaf(m[4], y, m[0] * x)));
-    r.y = fmaf(m[13], 1.0f, fmaf(m[9],  z, fmaf(m[5], y, m[1] * x)));
-    r.z = fmaf(m[14], 1.0f, fmaf(m[10], z, fmaf(m[6], y, m[2] * x)));
-    r.w = fmaf(m[15], 1.0f, fmaf(m[11], z, fmaf(m[7], y, m[3] * x)));
+    r.x = fmaf(m[4], y, fmaf(m[0], x, fmaf(m[8],  z, m[12])));
+    r.y = fmaf(m[5], y, fmaf(m[1], x, fmaf(m[9],  z, m[13])));
+    r.z = fmaf(m[6], y, fmaf(m[2], x, fmaf(m[10], z, m[14])));
+    r.w = fmaf(m[7], y, fmaf(m[3], x, fmaf(m[11], z, m[15])));
     return r;
 }
 VPT_DEV f3 dehomogenize(float4 v) { float i = rcp_nr(v.w); return f3{ v.x * i, v.y * i, v.z * i }; }   // xyz / w
