@@ -135,6 +135,11 @@ VPT_API int vpt_renderer_render_buffer_device(vpt_renderer *r, void **device_ptr
 /* redirect _renderFrame output into caller-owned device memory (>= width*local_rows*8 bytes), e.g. the send buffer of
  * the frame gather; NULL restores the renderer's own render buffer (gl.bindFramebuffer analogue, SingleBuffer.js:28-32) */
 VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, size_t nbytes);
+/* implementation switches (results are identical either way).  VPT_OPTION_MCS_PERSISTENT (default 0): run the MCS
+ * generate pass as persistent waves with __ballot/__popcll active-ray compaction instead of one thread per pixel
+ * (measured slower on MI355X at extinction 1..200 for 512^3 @ 1080p; kept as an option). */
+#define VPT_OPTION_MCS_PERSISTENT 0
+VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
 /* volume samples executed since creation / last clear (SURVEY §8d metric) */
 VPT_API int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count);
 VPT_API int vpt_renderer_clear_sample_count(vpt_renderer *r);

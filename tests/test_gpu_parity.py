@@ -224,11 +224,14 @@ def env_map(w, h, seed=5):
     return rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
 
 
+@pytest.mark.parametrize("persistent", [1, 0])
 @pytest.mark.parametrize("fused,env", [(False, None), (True, None), (True, (16, 8))])
-def test_mcs_parity(gpu_ctx, oracle, fused, env):
+def test_mcs_parity(gpu_ctx, oracle, fused, env, persistent):
+    """persistent = 1: persistent waves with __ballot/__popcll active-ray compaction; 0: one thread per pixel"""
     e = env_map(*env) if env else None
     sc = Scene(gpu_ctx, oracle, 40, 160, 96, tf=colour_tf(256, 1), env=e, camera=orbit_camera(160 / 96))
     r = sc.renderer('mcs', fused=fused)
+    r.set_option(N.OPTION_MCS_PERSISTENT, persistent)
     r.extinction = 12
     o = oracle.OracleRenderer('mcs', sc.osc, sc.w, sc.h)
     r.reset(); o.reset(oracle.make_frame(sc.w, sc.h, sc.m))

@@ -24,8 +24,13 @@ def run(kind, n, w, h, frames, warmup, **props):
     t_up = time.time() - t0
     r = vpt_amd.RendererFactory(kind)(ctx, gvol, default_camera(w / h), None,
                                       {'resolution': (w, h), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+    opt = props.pop('_mcs_persistent', None)
+    if opt is not None:
+        r.set_option(0, opt)
+        props = dict(props, mcs_persistent=opt)
     for k, v in props.items():
-        setattr(r, k, v)
+        if k != 'mcs_persistent':
+            setattr(r, k, v)
     r.reset()
     for _ in range(warmup):
         r.render()
@@ -56,7 +61,8 @@ if __name__ == "__main__":
     if "c5" in which: run('mcm', 2048, 3840, 2160, 20, 3)
     if "mcs_ext" in which:
         for ext in (1, 10, 50, 200):
-            run('mcs', 512, 1920, 1080, 60, 6, extinction=ext)
+            for pers in (0, 1):
+                run('mcs', 512, 1920, 1080, 60, 6, extinction=ext, _mcs_persistent=pers)
     if "mcm_ext" in which:
         for ext in (1, 10, 50, 200):
             run('mcm', 512, 1920, 1080, 60, 6, extinction=ext)

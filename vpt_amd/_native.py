@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvpt_hip.so")
 
 OK = 0
+OPTION_MCS_PERSISTENT = 0
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM = 0, 1, 2, 3
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 FORMAT_R8 = 0
@@ -27,7 +28,7 @@ SYMBOLS = [
     "vpt_renderer_reset", "vpt_renderer_generate", "vpt_renderer_integrate", "vpt_renderer_render_frame",
     "vpt_renderer_render", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
     "vpt_renderer_set_render_target",
-    "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
+    "vpt_renderer_set_option", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile",
     "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_synchronize",
     "vpt_gather_read_frame",
@@ -89,6 +90,7 @@ def lib():
         "vpt_renderer_read": [P, I, P, SZ],
         "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
         "vpt_renderer_set_render_target": [P, P, SZ],
+        "vpt_renderer_set_option": [P, I, I],
         "vpt_renderer_sample_count": [P, C.POINTER(C.c_uint64)], "vpt_renderer_clear_sample_count": [P],
         "vpt_renderer_set_profiling": [P, I],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],

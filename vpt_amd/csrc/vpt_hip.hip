@@ -71,6 +71,8 @@ struct vpt_renderer {
     float4 *st[4];
     uint2 *render;
     uint2 *render_target;          // caller-owned redirect of the render buffer (or null)
+    uint32_t *work_counter;        // tile counter of the persistent MCS kernel
+    bool mcs_persistent;           // use k_mcs_persist (active-ray compaction) for the MCS generate pass
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
     void *scratch; size_t scratch_bytes;
@@ -357,6 +359,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
     for (int i = 0; i < 4; i++) r->st[i] = nullptr;
     r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0;
+    r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
@@ -380,6 +383,7 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (r->tf) hipFree(r->tf);
     if (r->env) hipFree(r->env);
     if (r->samples) hipFree(r->samples);
+    if (r->work_counter) hipFree(r->work_counter);
     for (auto &ev : r->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete r;
     return VPT_OK;
@@ -482,6 +486,29 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
 #define K_MCM0(V) (k_mcm_integrate<false, V>)
 #define K_MCM1(V) (k_mcm_integrate<true, V>)
 
+template <typename K>
+static int launch_mcs_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
+    size_t lds = lds_bytes(r);
+    if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t counter_bytes = (size_t)VPT_WORK_SHARDS * VPT_WORK_STRIDE * sizeof(uint32_t);
+    if (!r->work_counter) HIP_TRY(hipMalloc(&r->work_counter, counter_bytes));
+    HIP_TRY(hipMemsetAsync(r->work_counter, 0, counter_bytes, r->ctx->stream));
+    int ntx8 = (r->W + 7) / 8, nty8 = (r->local_h + 7) / 8, ntiles8 = ntx8 * nty8;
+    int blocks = (ntiles8 + 3) / 4;
+    if (blocks > 256 * 6) blocks = 256 * 6;           // persistent: every wave resident, tiles drawn from the counter
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(VPT_BLOCK), lds, r->ctx->stream, a, r->work_counter, ntx8, ntiles8);
+    return VPT_OK;
+}
+#define LAUNCH_MCS_PERSIST(MODE, r, a) do { \
+    int v_ = ((r)->vol->wide ? VPT_V_WIDE : 0) | ((r)->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0); \
+    switch (v_) { \
+        case 0: VPT_TRY(launch_mcs_persist((k_mcs_persist<MODE, 0>), (r), (a))); break; \
+        case 1: VPT_TRY(launch_mcs_persist((k_mcs_persist<MODE, 1>), (r), (a))); break; \
+        case 2: VPT_TRY(launch_mcs_persist((k_mcs_persist<MODE, 2>), (r), (a))); break; \
+        default: VPT_TRY(launch_mcs_persist((k_mcs_persist<MODE, 3>), (r), (a))); break; \
+    } } while (0)
+
 static int check_step(const vpt_uniforms *u) {
     // step sizes <= 0 or NaN would never advance t: the reference's spinner enforces min 1 (MIPRenderer.js:24, EAMRenderer.js:34)
     if (!(u->step_size > 0.0f)) return fail(VPT_ERR_INVALID, "step_size must be > 0");
@@ -533,7 +560,7 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
         switch (r->kind) {
             case VPT_RENDERER_MIP: LAUNCH_S(K_MIP0, r, a); break;
             case VPT_RENDERER_EAM: LAUNCH_S(K_EAM0, r, a); break;
-            case VPT_RENDERER_MCS: LAUNCH_S(K_MCS0, r, a); break;
+            case VPT_RENDERER_MCS: if (r->mcs_persistent) LAUNCH_MCS_PERSIST(0, r, a); else LAUNCH_S(K_MCS0, r, a); break;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -582,7 +609,7 @@ extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
         switch (r->kind) {
             case VPT_RENDERER_MIP: LAUNCH_S(K_MIP1, r, a); break;
             case VPT_RENDERER_EAM: LAUNCH_S(K_EAM1, r, a); break;
-            case VPT_RENDERER_MCS: LAUNCH_S(K_MCS1, r, a); break;
+            case VPT_RENDERER_MCS: if (r->mcs_persistent) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
             case VPT_RENDERER_MCM:
                 LAUNCH_S(K_MCM1, r, a);
                 r->samples_host += r->valid_pixels * (uint64_t)u->steps;
@@ -643,6 +670,13 @@ extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t
     if (ptr && nbytes < need) return fail(VPT_ERR_INVALID, "render target too small: %zu < %zu", nbytes, need);
     r->render_target = (uint2 *)ptr;
     return VPT_OK;
+}
+extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    switch (option) {
+        case VPT_OPTION_MCS_PERSISTENT: r->mcs_persistent = value != 0; return VPT_OK;
+        default: return fail(VPT_ERR_INVALID, "unknown option %d", option);
+    }
 }
 extern "C" int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count) {
     if (!r || !count) return fail(VPT_ERR_INVALID, "null argument");

@@ -204,6 +204,9 @@ class AbstractRenderer(PropertyBag):
         N.check(N.lib().vpt_renderer_render_buffer_device(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def set_option(self, option, value):
+        N.check(N.lib().vpt_renderer_set_option(self._h, int(option), int(value)))
+
     def set_render_target(self, device_ptr, nbytes):
         """redirect _renderFrame output into caller-owned device memory (None restores the own buffer)"""
         N.check(N.lib().vpt_renderer_set_render_target(self._h, C.c_void_p(device_ptr) if device_ptr else None, nbytes))
