@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--check", type=int, default=1, help="verify the gathered frame against rank-local rows")
+    ap.add_argument("--mcm-persistent", type=int, default=-1, help="MCM only: 1/0 force the persistent-wave kernel on/off")
     ap.add_argument("--mcs-persistent", type=int, default=-1, help="MCS only: 1/0 force the persistent-wave kernel on/off")
     ap.add_argument("--fused", type=int, default=1, help="0: run the three hooks as separate launches (profiling aid)")
     ap.add_argument("--gather", default="native", choices=["native", "torch"],
@@ -138,6 +139,8 @@ def main():
         r = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, opts)
         if args.extinction is not None:
             r.extinction = args.extinction
+        if args.mcm_persistent >= 0:
+            r.set_option(N.OPTION_MCM_PERSISTENT, args.mcm_persistent)
         if args.mcs_persistent >= 0:
             r.set_option(N.OPTION_MCS_PERSISTENT, args.mcs_persistent)
         assert r.local_rows() == gather.rows

@@ -24,12 +24,16 @@ def run(kind, n, w, h, frames, warmup, **props):
     t_up = time.time() - t0
     r = vpt_amd.RendererFactory(kind)(ctx, gvol, default_camera(w / h), None,
                                       {'resolution': (w, h), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+    optm = props.pop('_mcm_persistent', None)
+    if optm is not None:
+        r.set_option(1, optm)
+        props = dict(props, mcm_persistent=optm)
     opt = props.pop('_mcs_persistent', None)
     if opt is not None:
         r.set_option(0, opt)
         props = dict(props, mcs_persistent=opt)
     for k, v in props.items():
-        if k != 'mcs_persistent':
+        if k not in ('mcs_persistent', 'mcm_persistent'):
             setattr(r, k, v)
     r.reset()
     for _ in range(warmup):
@@ -66,3 +70,10 @@ if __name__ == "__main__":
     if "mcm_ext" in which:
         for ext in (1, 10, 50, 200):
             run('mcm', 512, 1920, 1080, 60, 6, extinction=ext)
+    if "mcm_steps" in which:
+        for pers in (0, 1):
+            for st in (1, 2, 4, 8, 16, 32):
+                run('mcm', 512, 1920, 1080, 60, 6, steps=st, _mcm_persistent=pers)
+    for w in which:
+        if w.startswith("mcm_one_"):
+            run('mcm', 512, 1920, 1080, 60, 6, steps=int(w.split("_")[-1]), _mcm_persistent=0)

@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libvpt_hip.so")
 
 OK = 0
 OPTION_MCS_PERSISTENT = 0
+OPTION_MCM_PERSISTENT = 1
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM = 0, 1, 2, 3
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 FORMAT_R8 = 0

@@ -73,6 +73,7 @@ struct vpt_renderer {
     uint2 *render_target;          // caller-owned redirect of the render buffer (or null)
     uint32_t *work_counter;        // tile counter of the persistent MCS kernel
     bool mcs_persistent;           // use k_mcs_persist (active-ray compaction) for the MCS generate pass
+    bool mcm_persistent;           // use k_mcm_persist (persistent waves, state prefetch) for the MCM integrate pass
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
     void *scratch; size_t scratch_bytes;
@@ -359,7 +360,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
     for (int i = 0; i < 4; i++) r->st[i] = nullptr;
     r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0;
-    r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->mcm_persistent = false; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
@@ -500,6 +501,31 @@ static int launch_mcs_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(VPT_BLOCK), lds, r->ctx->stream, a, r->work_counter, ntx8, ntiles8);
     return VPT_OK;
 }
+// persistent MCM: as many workgroups as are resident at once (occupancy query x CUs), never more than there are segments
+template <typename K>
+static int launch_mcm_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
+    size_t lds = lds_bytes(r);
+    if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, VPT_BLOCK, lds));
+    if (per_cu < 1) per_cu = 1;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, r->ctx->device));
+    int nseg = r->tiles_x * ((r->local_h + VPT_TILE - 1) / VPT_TILE) * 4;
+    int blocks = per_cu * prop.multiProcessorCount;
+    if (blocks > (nseg + 3) / 4) blocks = (nseg + 3) / 4;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(VPT_BLOCK), lds, r->ctx->stream, a, nseg);
+    return VPT_OK;
+}
+#define LAUNCH_MCM_PERSIST(FUSE, r, a) do { \
+    int v_ = ((r)->vol->wide ? VPT_V_WIDE : 0) | ((r)->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0); \
+    switch (v_) { \
+        case 0: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 0>), (r), (a))); break; \
+        case 1: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 1>), (r), (a))); break; \
+        case 2: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 2>), (r), (a))); break; \
+        default: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 3>), (r), (a))); break; \
+    } } while (0)
 #define LAUNCH_MCS_PERSIST(MODE, r, a) do { \
     int v_ = ((r)->vol->wide ? VPT_V_WIDE : 0) | ((r)->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0); \
     switch (v_) { \
@@ -577,7 +603,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_integrate, r, a, 0); break;
         case VPT_RENDERER_MCM: {
             Timed t(r, true);
-            LAUNCH_S(K_MCM0, r, a);
+            if (r->mcm_persistent) LAUNCH_MCM_PERSIST(false, r, a); else LAUNCH_S(K_MCM0, r, a);
             r->samples_host += r->valid_pixels * (uint64_t)u->steps;   // exactly W*H*steps per pass (MCMRenderer.glsl:129-133)
         } break;
     }
@@ -611,7 +637,7 @@ extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
             case VPT_RENDERER_EAM: LAUNCH_S(K_EAM1, r, a); break;
             case VPT_RENDERER_MCS: if (r->mcs_persistent) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
             case VPT_RENDERER_MCM:
-                LAUNCH_S(K_MCM1, r, a);
+                if (r->mcm_persistent) LAUNCH_MCM_PERSIST(true, r, a); else LAUNCH_S(K_MCM1, r, a);
                 r->samples_host += r->valid_pixels * (uint64_t)u->steps;
                 break;
         }
@@ -675,6 +701,7 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
     switch (option) {
         case VPT_OPTION_MCS_PERSISTENT: r->mcs_persistent = value != 0; return VPT_OK;
+        case VPT_OPTION_MCM_PERSISTENT: r->mcm_persistent = value != 0; return VPT_OK;
         default: return fail(VPT_ERR_INVALID, "unknown option %d", option);
     }
 }
