@@ -71,6 +71,7 @@ struct vpt_renderer {
     float4 *st[4];
     uint2 *render;
     uint2 *render_target;          // caller-owned redirect of the render buffer (or null)
+    float *ndc_x, *ndc_y;          // pixel-centre NDC tables (W and H entries)
     uint32_t *work_counter;        // tile counter of the persistent MCS kernel
     bool mcs_persistent;           // use k_mcs_persist (active-ray compaction) for the MCS generate pass
     bool mcm_persistent;           // use k_mcm_persist (persistent waves, state prefetch) for the MCM integrate pass
@@ -273,6 +274,9 @@ static void renderer_free_buffers(vpt_renderer *r) {
     for (int i = 0; i < 4; i++) if (r->st[i]) hipFree(r->st[i]);
     if (r->render) hipFree(r->render);
     if (r->scratch) hipFree(r->scratch);
+    if (r->ndc_x) hipFree(r->ndc_x);
+    if (r->ndc_y) hipFree(r->ndc_y);
+    r->ndc_x = r->ndc_y = nullptr;
     r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
     for (int i = 0; i < 4; i++) r->st[i] = nullptr;
 }
@@ -311,6 +315,15 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
             HIP_TRY(hipMalloc(&r->st[i], r->npix_padded * sizeof(float4)));
             HIP_TRY(hipMemsetAsync(r->st[i], 0, r->npix_padded * sizeof(float4), c->stream));
         }
+    }
+    {   // pixel-centre NDC: fl(fl((2i+1)/W) - 1), the exact per-pixel expression of the contract
+        std::vector<float> nx((size_t)r->W), ny((size_t)r->H);
+        for (int i = 0; i < r->W; i++) nx[i] = (float)(2 * i + 1) / (float)r->W - 1.0f;
+        for (int j = 0; j < r->H; j++) ny[j] = (float)(2 * j + 1) / (float)r->H - 1.0f;
+        HIP_TRY(hipMalloc(&r->ndc_x, nx.size() * sizeof(float)));
+        HIP_TRY(hipMalloc(&r->ndc_y, ny.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(r->ndc_x, nx.data(), nx.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(r->ndc_y, ny.data(), ny.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     size_t rb = (size_t)r->W * r->local_h * sizeof(uint2);
     HIP_TRY(hipMalloc(&r->render, rb));
@@ -360,6 +373,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
     for (int i = 0; i < 4; i++) r->st[i] = nullptr;
     r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0;
+    r->ndc_x = r->ndc_y = nullptr;
     r->mcm_persistent = false; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     int rc = renderer_alloc_buffers(r);
@@ -426,6 +440,9 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
     a->pm.W = r->W; a->pm.H = r->H; a->pm.local_h = r->local_h;
     a->pm.tiles_x = r->tiles_x; a->pm.ntiles = r->ntiles;
     a->pm.G = r->G; a->pm.g = r->g; a->pm.R = r->R;
+    a->pm.rshift = -1;
+    for (int sft = 0; sft < 16; sft++) if ((1 << sft) == r->R) a->pm.rshift = sft;
+    a->pm.ndc_x = r->ndc_x; a->pm.ndc_y = r->ndc_y;
     if (need_volume) {
         if (!r->vol || !r->vol->any_upload) return fail(VPT_ERR_NO_VOLUME, "renderer has no ready volume");
         VPT_TRY(vpt_volume_finalize(r->vol));
@@ -460,12 +477,13 @@ static size_t lds_bytes(const vpt_renderer *r) {
     const vpt_volume *v = r->vol;
     return (size_t)r->tf_w * 2 * sizeof(float4) + (size_t)(v->nx + v->ny + v->nz) * (v->wide ? 8 : 4);
 }
+static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)r->tiles_x * 8u, (unsigned)r->tiles_y / 8u); }
 template <typename K>
-static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigned grid) {
+static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigned) {
     size_t lds = lds_bytes(r);
     if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(VPT_BLOCK), lds, r->ctx->stream, a);
+    hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a);
     return VPT_OK;
 }
 // picks the instantiation for (offset-table width, filter): V = VPT_V_WIDE | VPT_V_NEAREST bits
@@ -557,7 +575,7 @@ struct Timed {   // per-launch HIP events around the dominant kernel
     ~Timed() { if (on) hipEventRecord(r->events[idx].second, r->ctx->stream); }
 };
 
-#define LAUNCH(kernel, r, a, lds) hipLaunchKernelGGL(kernel, dim3((unsigned)(r)->ntiles), dim3(VPT_BLOCK), (lds), (r)->ctx->stream, (a))
+#define LAUNCH(kernel, r, a, lds) hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), (lds), (r)->ctx->stream, (a))
 
 extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
@@ -679,7 +697,7 @@ extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t 
     }
     PassArgs a;
     VPT_TRY(make_args(r, nullptr, false, &a));
-    hipLaunchKernelGGL(k_detile, dim3((unsigned)r->ntiles), dim3(VPT_BLOCK), 0, c->stream, a.pm, (const uint8_t *)src, (uint8_t *)r->scratch, (int)elem);
+    hipLaunchKernelGGL(k_detile, tile_grid(r), dim3(VPT_BLOCK), 0, c->stream, a.pm, (const uint8_t *)src, (uint8_t *)r->scratch, (int)elem);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(dst, r->scratch, npix * elem, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -21,6 +21,8 @@ struct PixMap {
     int local_h;       // rows held by this renderer (== H when unsharded)
     int tiles_x, ntiles;
     int G, g, R;       // shard: world, rank, rows per block
+    int rshift;        // log2(R) when R is a power of two, else -1
+    const float *ndc_x, *ndc_y;   // pixel-centre NDC per column / global row: fl(fl((2i+1)/W) - 1), W resp. H entries
 };
 struct Pix { int i, j, l, k; bool valid; };
 
@@ -29,22 +31,31 @@ struct Pix { int i, j, l, k; bool valid; };
 // are neighbouring tiles (shared bricks hit in that XCD's L2), while every XCD gets rows from the whole image, so
 // cube-missing and cube-crossing tiles balance (a contiguous band per XCD left the centre XCDs ~1.5x the work).
 // tiles_y is padded to a multiple of 8 by the host, so the map is a bijection on [0, ntiles).
+// global row of local row l of this shard
+VPT_DEV int global_row(const PixMap &m, int l) {
+    if (m.G == 1) return l;
+    int lb = (m.rshift >= 0) ? (l >> m.rshift) : (l / m.R);
+    return (lb * m.G + m.g) * m.R + (l - lb * m.R);
+}
+// The grid is 2-D so that no integer division is needed: gridDim.x = 8 * tiles_x, blockIdx.x = tx * 8 + xcd,
+// blockIdx.y = row group; the linear workgroup id (y * gridDim.x + x) is what the dispatcher deals over the XCDs and
+// gridDim.x is a multiple of 8, so blockIdx.x & 7 labels the XCD group.
 VPT_DEV Pix map_pixel(const PixMap &m) {
-    int b = (int)blockIdx.x;
-    int xcd = b & 7, idx = b >> 3;
-    int rowgroup = idx / m.tiles_x, tx = idx - rowgroup * m.tiles_x;
-    int ty = rowgroup * 8 + xcd;
+    int xcd = (int)blockIdx.x & 7, tx = (int)blockIdx.x >> 3;
+    int ty = (int)blockIdx.y * 8 + xcd;
     int t = ty * m.tiles_x + tx;
     int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     Pix p;
     p.i = tx * VPT_TILE + (w & 1) * 8 + (lane & 7);
     p.l = ty * VPT_TILE + (w >> 1) * 8 + (lane >> 3);
     p.k = t * VPT_BLOCK + (int)threadIdx.x;
-    int lb = p.l / m.R;
-    p.j = (lb * m.G + m.g) * m.R + (p.l - lb * m.R);
+    p.j = global_row(m, p.l);
     p.valid = (p.i < m.W) && (p.l < m.local_h) && (p.j < m.H);
     return p;
 }
+// pixel-centre NDC from the host-built tables (the IEEE divisions (2i+1)/W are done once per image size, not per pixel)
+VPT_DEV float ndc_col(const PixMap &m, int i) { return m.ndc_x[i]; }
+VPT_DEV float ndc_row(const PixMap &m, int j) { return m.ndc_y[j]; }
 
 struct PassArgs {
     PixMap pm;
@@ -105,7 +116,7 @@ VPT_DEV void count_samples(unsigned long long *ctr, uint32_t n) {
     if (((int)threadIdx.x & 63) == 0 && n) atomicAdd(&block_sum, n);
     __syncthreads();
     if (threadIdx.x == 0 && block_sum)
-        atomicAdd(ctr + (size_t)(blockIdx.x % VPT_COUNTER_SLOTS) * VPT_COUNTER_STRIDE, (unsigned long long)block_sum);
+        atomicAdd(ctr + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % VPT_COUNTER_SLOTS) * VPT_COUNTER_STRIDE, (unsigned long long)block_sum);
 }
 VPT_DEV uint2 pack_half4(float x, float y, float z, float w) {
     uint2 r;
@@ -121,7 +132,7 @@ VPT_DEV uint2 pack_half4(float x, float y, float z, float w) {
 template <int V>
 VPT_DEV uint32_t mip_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
     f3 rf, rt;
-    unproject(pixel_ndc(p.i, a.pm.W), pixel_ndc(p.j, a.pm.H), a.mvp_inv, rf, rt);
+    unproject(ndc_col(a.pm, p.i), ndc_row(a.pm, p.j), a.mvp_inv, rf, rt);
     f3 dir = sub3(rt, rf);
     f2 tb = intersect_cube(rf, dir);
     tb.x = vmax(tb.x, 0.0f); tb.y = vmax(tb.y, 0.0f);
@@ -204,7 +215,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mip_reset(PassArgs a) {   // MIPR
 template <int V>
 VPT_DEV uint32_t eam_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
     f3 rf, rt;
-    unproject(pixel_ndc(p.i, a.pm.W), pixel_ndc(p.j, a.pm.H), a.mvp_inv, rf, rt);
+    unproject(ndc_col(a.pm, p.i), ndc_row(a.pm, p.j), a.mvp_inv, rf, rt);
     f3 dir = sub3(rt, rf);
     f2 tb = intersect_cube(rf, dir);
     tb.x = vmax(tb.x, 0.0f); tb.y = vmax(tb.y, 0.0f);
@@ -331,7 +342,7 @@ VPT_DEV float mcs_sample_transmittance(const PassArgs &a, const LdsTables &t, ui
 // generate/fragment main(): MCSRenderer.glsl:107-137
 template <int V>
 VPT_DEV float4 mcs_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
-    float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
+    float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     f3 rf, rt;
     unproject(px, py, a.mvp_inv, rf, rt);
     f3 dir = sub3(rt, rf);
@@ -456,12 +467,11 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs_persist(PassArgs a, uint32_t 
                 if (tile >= 0) {
                     int ty = tile / ntx8, tx = tile - ty * ntx8;
                     int i = tx * 8 + (idx & 7), l = ty * 8 + (idx >> 3);
-                    int lb = l / a.pm.R;
-                    int j = (lb * a.pm.G + a.pm.g) * a.pm.R + (l - lb * a.pm.R);
+                    int j = global_row(a.pm, l);
                     if (i < a.pm.W && l < a.pm.local_h && j < a.pm.H) {
                         // generate/fragment main() up to the first tracking loop: MCSRenderer.glsl:107-122
                         s.i = i; s.l = l; s.k = pixel_buffer_index(a.pm, i, l);
-                        float px = pixel_ndc(i, a.pm.W), py = pixel_ndc(j, a.pm.H);
+                        float px = ndc_col(a.pm, i), py = ndc_row(a.pm, j);
                         f3 rf, rt;
                         unproject(px, py, a.mvp_inv, rf, rt);
                         f3 dir = sub3(rt, rf);
@@ -614,7 +624,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
     Pix p = map_pixel(a.pm);
     Photon ph;
     if (p.valid) {
-        float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
+        float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
         uint32_t state = hash3(__float_as_uint(px), __float_as_uint(py), __float_as_uint(a.seed));
         reset_photon(state, ph, px, py, a, unproject_near(px, py, a));
     } else {
@@ -700,10 +710,9 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_persist(PassArgs a, int nseg)
         int ty = t16 / a.pm.tiles_x, tx = t16 - ty * a.pm.tiles_x;
         int i = tx * VPT_TILE + (w & 1) * 8 + (lane & 7);
         int l = ty * VPT_TILE + (w >> 1) * 8 + (lane >> 3);
-        int lb = l / a.pm.R;
-        int j = (lb * a.pm.G + a.pm.g) * a.pm.R + (l - lb * a.pm.R);
+        int j = global_row(a.pm, l);
         if (i < a.pm.W && l < a.pm.local_h && j < a.pm.H) {
-            mcm_events<V>(a, t, ph, pixel_ndc(i, a.pm.W), pixel_ndc(j, a.pm.H));
+            mcm_events<V>(a, t, ph, ndc_col(a.pm, i), ndc_row(a.pm, j));
             a.st0[kc] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
             a.st1[kc] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
             a.st2[kc] = make_float4(ph.transmittance.x, ph.transmittance.y, ph.transmittance.z, 0.0f);
@@ -722,7 +731,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
-    float px = pixel_ndc(p.i, a.pm.W), py = pixel_ndc(p.j, a.pm.H);
+    float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     float4 s0 = a.st0[p.k], s1 = a.st1[p.k], s2 = a.st2[p.k], s3 = a.st3[p.k];
     Photon ph;
     ph.position = f3{ s0.x, s0.y, s0.z };
