@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--check", type=int, default=1, help="verify the gathered frame against rank-local rows")
     ap.add_argument("--mcm-persistent", type=int, default=-1, help="MCM only: 1/0 force the persistent-wave kernel on/off")
     ap.add_argument("--mcs-persistent", type=int, default=-1, help="MCS only: 1/0 force the persistent-wave kernel on/off")
+    ap.add_argument("--profile-kernel", type=int, default=8,
+                    help="HIP events around every n-th launch of the dominant kernel in the timed region (1 = every launch, 0 = none)")
     ap.add_argument("--fused", type=int, default=1, help="0: run the three hooks as separate launches (profiling aid)")
     ap.add_argument("--gather", default="native", choices=["native", "torch"],
                     help="frame gather for N > 1: 'native' = RCCL pipeline below the C ABI (vpt_gather_*), 'torch' = torch.distributed all_gather")
@@ -188,7 +190,7 @@ def main():
         drain()
         torch.cuda.synchronize()
         r.clear_sample_count()
-        r.set_profiling(True)
+        r.set_profiling(args.profile_kernel)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -231,8 +233,8 @@ def main():
         torch.cuda.synchronize()
 
     if rank == 0:
-        per_launch_samples = samples_local / max(launches, 1)
-        avg_ms = kernel_ms / max(launches, 1)
+        per_launch_samples = samples_local / max(args.steps, 1)
+        avg_ms = kernel_ms / launches if launches else dt / args.steps * 1e3
         achieved = (B_ALG_MCM if args.renderer == "mcm" else 8.0) * per_launch_samples / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -149,7 +149,8 @@ VPT_API int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count);
 VPT_API int vpt_renderer_clear_sample_count(vpt_renderer *r);
 
 /* per-launch HIP-event timing of the dominant kernel (generate for MIP/EAM/MCS, integrate for MCM) on the
- * context's stream; enable, run, then query: sum of durations in ms and number of timed launches. */
+ * context's stream; enable, run, then query: sum of durations in ms and number of timed launches.
+ * enabled = 1 times every launch, enabled = n > 1 every n-th launch (the two event packets cost ~7 us per launch). */
 VPT_API int vpt_renderer_set_profiling(vpt_renderer *r, int enabled);
 VPT_API int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t *launches);
 

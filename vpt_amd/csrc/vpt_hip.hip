@@ -79,6 +79,7 @@ struct vpt_renderer {
     uint64_t samples_host;         // analytic part (MCM)
     void *scratch; size_t scratch_bytes;
     bool profiling;
+    int profile_every; uint64_t profile_seq;   // time every n-th launch of the dominant kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used;
 };
@@ -372,7 +373,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->vol = nullptr; r->tf = nullptr; r->env = nullptr;
     r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
     for (int i = 0; i < 4; i++) r->st[i] = nullptr;
-    r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0;
+    r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0; r->profile_every = 1; r->profile_seq = 0;
     r->ndc_x = r->ndc_y = nullptr;
     r->mcm_persistent = false; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
@@ -563,6 +564,7 @@ static int check_step(const vpt_uniforms *u) {
 struct Timed {   // per-launch HIP events around the dominant kernel
     vpt_renderer *r; bool on; size_t idx;
     Timed(vpt_renderer *r_, bool dominant) : r(r_), on(r_->profiling && dominant), idx(0) {
+        if (on) on = (r->profile_seq++ % (uint64_t)r->profile_every) == 0;
         if (!on) return;
         if (r->events_used == r->events.size()) {
             hipEvent_t a, b;
@@ -746,6 +748,8 @@ extern "C" int vpt_renderer_set_profiling(vpt_renderer *r, int enabled) {
     HIP_TRY(hipSetDevice(r->ctx->device));
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
     r->profiling = enabled != 0;
+    r->profile_every = enabled > 1 ? enabled : 1;   // enabled = n > 1: every n-th launch only (events cost ~7 us per launch)
+    r->profile_seq = 0;
     r->events_used = 0;
     return VPT_OK;
 }

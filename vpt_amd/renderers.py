@@ -192,7 +192,8 @@ class AbstractRenderer(PropertyBag):
         N.check(N.lib().vpt_renderer_clear_sample_count(self._h))
 
     def set_profiling(self, enabled):
-        N.check(N.lib().vpt_renderer_set_profiling(self._h, 1 if enabled else 0))
+        """False/0: off; True/1: time every launch; n > 1: every n-th launch"""
+        N.check(N.lib().vpt_renderer_set_profiling(self._h, int(enabled)))
 
     def profile(self):
         ms, n = C.c_double(0), C.c_uint32(0)
