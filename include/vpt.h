@@ -139,9 +139,9 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * generate pass as persistent waves with __ballot/__popcll active-ray compaction instead of one thread per pixel
  * (measured slower on MI355X at extinction 1..200 for 512^3 @ 1080p; kept as an option). */
 #define VPT_OPTION_MCS_PERSISTENT 0
-/* VPT_OPTION_MCM_PERSISTENT (default 0): run the MCM integrate pass as persistent waves that prefetch the next pixel
- * segment's photon state under the current segment's events, instead of one workgroup per 16x16 tile (measured 5 %
- * slower: the prefetch registers cost occupancy). */
+/* VPT_OPTION_MCM_PERSISTENT (default 0): 1 = run the MCM integrate pass as persistent waves walking several 8x8-pixel
+ * segments (LDS tables staged once per workgroup), 2 = the same with the next segment's photon state prefetched under
+ * the current segment's events.  Measured 4-8 % slower than one workgroup per tile (register pressure), kept as options. */
 #define VPT_OPTION_MCM_PERSISTENT 1
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
 /* volume samples executed since creation / last clear (SURVEY §8d metric) */

@@ -250,11 +250,11 @@ def test_mcs_parity(gpu_ctx, oracle, fused, env, persistent):
 MCM_BUFFERS = [N.BUFFER_MCM_POSITION, N.BUFFER_MCM_DIRECTION, N.BUFFER_MCM_TRANSMITTANCE, N.BUFFER_MCM_RADIANCE]
 
 
-@pytest.mark.parametrize("persistent", [1, 0])
+@pytest.mark.parametrize("persistent", [0, 1, 2])
 @pytest.mark.parametrize("fused,g,env,ext", [(False, 0.0, None, 1.0), (True, 0.0, None, 8.0), (True, 0.6, None, 8.0),
                                              (True, -0.4, (16, 8), 20.0)])
 def test_mcm_parity(gpu_ctx, oracle, fused, g, env, ext, persistent):
-    """persistent = 1: persistent waves + photon-state prefetch (default); 0: one workgroup per 16x16 tile"""
+    """persistent = 0: one workgroup per 16x16 tile (default); 1: persistent waves; 2: + next-segment state prefetch"""
     e = env_map(*env) if env else None
     sc = Scene(gpu_ctx, oracle, 40, 144, 80, tf=colour_tf(256, 1), env=e, camera=orbit_camera(144 / 80))
     r = sc.renderer('mcm', fused=fused)

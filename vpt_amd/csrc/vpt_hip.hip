@@ -74,7 +74,7 @@ struct vpt_renderer {
     float *ndc_x, *ndc_y;          // pixel-centre NDC tables (W and H entries)
     uint32_t *work_counter;        // tile counter of the persistent MCS kernel
     bool mcs_persistent;           // use k_mcs_persist (active-ray compaction) for the MCS generate pass
-    bool mcm_persistent;           // use k_mcm_persist (persistent waves, state prefetch) for the MCM integrate pass
+    int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
     void *scratch; size_t scratch_bytes;
@@ -375,7 +375,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     for (int i = 0; i < 4; i++) r->st[i] = nullptr;
     r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0; r->profile_every = 1; r->profile_seq = 0;
     r->ndc_x = r->ndc_y = nullptr;
-    r->mcm_persistent = false; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
@@ -540,10 +540,10 @@ static int launch_mcm_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
 #define LAUNCH_MCM_PERSIST(FUSE, r, a) do { \
     int v_ = ((r)->vol->wide ? VPT_V_WIDE : 0) | ((r)->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0); \
     switch (v_) { \
-        case 0: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 0>), (r), (a))); break; \
-        case 1: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 1>), (r), (a))); break; \
-        case 2: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 2>), (r), (a))); break; \
-        default: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 3>), (r), (a))); break; \
+        case 0: VPT_TRY((r)->mcm_persistent == 2 ? launch_mcm_persist((k_mcm_persist<FUSE, 0, true>), (r), (a)) : launch_mcm_persist((k_mcm_persist<FUSE, 0, false>), (r), (a))); break; \
+        case 1: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 1, false>), (r), (a))); break; \
+        case 2: VPT_TRY((r)->mcm_persistent == 2 ? launch_mcm_persist((k_mcm_persist<FUSE, 2, true>), (r), (a)) : launch_mcm_persist((k_mcm_persist<FUSE, 2, false>), (r), (a))); break; \
+        default: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 3, false>), (r), (a))); break; \
     } } while (0)
 #define LAUNCH_MCS_PERSIST(MODE, r, a) do { \
     int v_ = ((r)->vol->wide ? VPT_V_WIDE : 0) | ((r)->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0); \
@@ -721,7 +721,7 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
     switch (option) {
         case VPT_OPTION_MCS_PERSISTENT: r->mcs_persistent = value != 0; return VPT_OK;
-        case VPT_OPTION_MCM_PERSISTENT: r->mcm_persistent = value != 0; return VPT_OK;
+        case VPT_OPTION_MCM_PERSISTENT: r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
         default: return fail(VPT_ERR_INVALID, "unknown option %d", option);
     }
 }

@@ -687,8 +687,8 @@ VPT_DEV Photon photon_unpack(float4 s0, float4 s1, float4 s2, float4 s3) {   // 
 // steps 8): 0.156 ms vs 0.148 ms for the one-workgroup-per-tile kernel — the prefetch registers cost two waves per SIMD
 // (96 vs 72 VGPRs) and the state stream is only ~20 us of the frame (timing builds without state loads / stores:
 // -4 us / -13 us), so this form is kept as an option (VPT_OPTION_MCM_PERSISTENT), not the default.
-template <bool FUSE_RENDER, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) k_mcm_persist(PassArgs a, int nseg) {
+template <bool FUSE_RENDER, int V, bool PREFETCH>
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 5 : 7, 8))) k_mcm_persist(PassArgs a, int nseg) {
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     const int lane = (int)threadIdx.x & 63;
@@ -696,14 +696,16 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_persist(PassArgs a, int nseg)
     int g = (int)blockIdx.x * (VPT_BLOCK / 64) + ((int)threadIdx.x >> 6);
     if (g >= nseg) return;
     size_t k = (size_t)g * 64 + lane;
-    float4 n0 = a.st0[k], n1 = a.st1[k], n2 = a.st2[k], n3 = a.st3[k];
+    float4 n0, n1, n2, n3;
+    if (PREFETCH) { n0 = a.st0[k]; n1 = a.st1[k]; n2 = a.st2[k]; n3 = a.st3[k]; }
     while (g < nseg) {
         const int gc = g;
         const size_t kc = k;
+        if (!PREFETCH) { n0 = a.st0[k]; n1 = a.st1[k]; n2 = a.st2[k]; n3 = a.st3[k]; }
         Photon ph = photon_unpack(n0, n1, n2, n3);
         g += nwaves;
-        if (g < nseg) {                          // wave-uniform: prefetch the next segment's photon state
-            k = (size_t)g * 64 + lane;
+        k = (size_t)g * 64 + lane;
+        if (PREFETCH && g < nseg) {              // wave-uniform: prefetch the next segment's photon state
             n0 = a.st0[k]; n1 = a.st1[k]; n2 = a.st2[k]; n3 = a.st3[k];
         }
         int t16 = gc >> 2, w = gc & 3;
