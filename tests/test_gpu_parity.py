@@ -336,3 +336,109 @@ def test_errors_are_loud(gpu_ctx):
     with pytest.raises(vpt_amd.VptError, match="no ready volume"):
         r.render()
     r.destroy()
+
+
+@pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "mcm"])
+def test_wide_offset_tables_variant(gpu_ctx, oracle, kind):
+    """the 64-bit brick-offset-table kernels (used above 4 GiB of bricked data, e.g. 2048^3) forced on a small volume"""
+    sc = Scene(gpu_ctx, oracle, 24, 72, 40, tf=colour_tf(32, 1), camera=orbit_camera(72 / 40), dims=(20, 24, 17))
+    outs = []
+    for wide in (0, 1):
+        sc.gvol.set_wide_tables(wide)
+        r = sc.renderer(kind)
+        if kind in ('mcs', 'mcm'):
+            r.extinction = 7
+        r.reset()
+        for _ in range(3):
+            r.render()
+        outs.append((r.getTexture(), r.sample_count()))
+        r.destroy()
+    assert_same_bits(outs[0][0], outs[1][0], "%s wide vs narrow tables" % kind)
+    assert outs[0][1] == outs[1][1]
+    sc.gvol.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: size-independent properties + an oracle band
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_scene(gpu_ctx, oracle):
+    sc = Scene(gpu_ctx, oracle, 512, 1920, 1080, noise=48.0)       # the headline workload's volume and image plane
+    yield sc
+    sc.gvol.destroy()
+
+
+def test_full_size_mcm_properties_and_oracle_band(gpu_ctx, oracle, full_scene):
+    """MCM 512^3 @ 1920x1080 (headline config): fused == hook-by-hook, run-to-run determinism, 3-way row sharding ==
+    unsharded, sample count == P*steps, and a 24-row band of the frame bit-identical to the CPU oracle."""
+    sc = full_scene
+    passes = 3
+
+    def run(**opts):
+        r = sc.renderer('mcm', **opts)
+        r.reset()
+        for _ in range(passes):
+            r.render()
+        out = (r.getTexture(), r.read(N.BUFFER_MCM_RADIANCE), r.sample_count(), r.global_rows())
+        r.destroy()
+        return out
+
+    img, rad, ns, _ = run()
+    assert ns == sc.w * sc.h * 8 * passes
+    img2, rad2, _, _ = run()
+    assert_same_bits(img2, img, "determinism"); assert_same_bits(rad2, rad, "determinism (radiance)")
+    img3, rad3, _, _ = run(fused=False)
+    assert_same_bits(img3, img, "fused vs hooks"); assert_same_bits(rad3, rad, "fused vs hooks (radiance)")
+    got = np.zeros_like(img)
+    for rank in range(3):
+        simg, _, _, rows = run(shard=(rank, 3, 8))
+        got[rows[rows >= 0]] = simg[rows >= 0]
+    assert_same_bits(got, img, "3-way sharded vs unsharded")
+    assert np.isfinite(img.astype(np.float32)).all() and (img[..., 3] == 1).all()
+    # oracle on a band of rows through the middle of the cube (same seeds as the mirror drew)
+    y0, y1 = 528, 552
+    o = oracle.OracleRenderer('mcm', sc.osc, sc.w, sc.h)
+    rng = GoldenRatioRng()
+    fr = oracle.make_frame(sc.w, sc.h, sc.m, seed=np.float32(rng()), y0=y0, y1=y1, nthreads=8)
+    o.reset(fr)
+    for _ in range(passes):
+        fr.seed = float(np.float32(rng()))
+        o.integrate(fr)
+    want = o.state[3].reshape(sc.h, sc.w, 4)[y0:y1]
+    assert_same_bits(rad[y0:y1], want, "oracle band rows %d..%d" % (y0, y1))
+
+
+@pytest.mark.parametrize("kind,n,props", [("eam", 256, {}), ("mcs", 512, {"extinction": 20}), ("mip", 256, {})])
+def test_full_size_other_renderers_oracle_band(gpu_ctx, oracle, full_scene, kind, n, props):
+    """C2 / C3-sized passes: fused == hooks and a 16-row oracle band at 1920x1080"""
+    sc = full_scene if n == 512 else Scene(gpu_ctx, oracle, n, 1920, 1080, noise=0.0)
+    frames = 2
+
+    def run(fused):
+        r = sc.renderer(kind, fused=fused)
+        for k, v in props.items():
+            setattr(r, k, v)
+        r.reset()
+        us = []
+        for _ in range(frames):
+            r.render()
+            us.append(r._u)
+        out = (r.getTexture(), r.read(N.BUFFER_ACCUM), r.sample_count(), us)
+        r.destroy()
+        return out
+
+    img, acc, ns, us = run(True)
+    img_h, acc_h, ns_h, _ = run(False)
+    assert_same_bits(img_h, img, "%s fused vs hooks" % kind); assert_same_bits(acc_h, acc, "%s fused vs hooks (acc)" % kind)
+    assert ns == ns_h and ns > 0
+    y0, y1 = 532, 548
+    o = oracle.OracleRenderer(kind, sc.osc, sc.w, sc.h)
+    fr0 = oracle.make_frame(sc.w, sc.h, sc.m, y0=y0, y1=y1, nthreads=8)
+    o.reset(fr0)
+    for u in us:
+        fr = to_frame(oracle, sc, u, y0=y0, y1=y1, nthreads=8)
+        o.render(fr)
+    shape = (sc.h, sc.w) if kind == "mip" else (sc.h, sc.w, 4)
+    assert_same_bits(acc[y0:y1], o.acc.reshape(shape)[y0:y1], "%s oracle band" % kind)
+    if sc is not full_scene:
+        sc.gvol.destroy()

@@ -22,7 +22,7 @@ SYMBOLS = [
     "vpt_device_count", "vpt_context_create", "vpt_context_create_on_stream", "vpt_context_destroy", "vpt_context_synchronize",
     "vpt_last_error", "vpt_version",
     "vpt_volume_create", "vpt_volume_upload_block", "vpt_volume_upload_block_device", "vpt_volume_finalize",
-    "vpt_volume_set_filter", "vpt_volume_destroy", "vpt_volume_bricked_bytes",
+    "vpt_volume_set_filter", "vpt_volume_destroy", "vpt_volume_bricked_bytes", "vpt_volume_set_wide_tables",
     "vpt_renderer_create", "vpt_renderer_set_shard", "vpt_renderer_local_rows", "vpt_renderer_global_row",
     "vpt_renderer_destroy", "vpt_renderer_set_volume", "vpt_renderer_set_transfer_function",
     "vpt_renderer_set_environment", "vpt_renderer_resize",
@@ -79,7 +79,7 @@ def lib():
         "vpt_volume_upload_block": [P, I, I, I, I, I, I, P, SZ],
         "vpt_volume_upload_block_device": [P, I, I, I, I, I, I, P, SZ],
         "vpt_volume_finalize": [P], "vpt_volume_set_filter": [P, I], "vpt_volume_destroy": [P],
-        "vpt_volume_bricked_bytes": [P, C.POINTER(C.c_uint64)],
+        "vpt_volume_bricked_bytes": [P, C.POINTER(C.c_uint64)], "vpt_volume_set_wide_tables": [P, I],
         "vpt_renderer_create": [P, I, I, I, PP],
         "vpt_renderer_set_shard": [P, I, I, I], "vpt_renderer_local_rows": [P, C.POINTER(I)],
         "vpt_renderer_global_row": [P, I, C.POINTER(I)],

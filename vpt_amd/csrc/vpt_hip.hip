@@ -248,6 +248,12 @@ extern "C" int vpt_volume_set_filter(vpt_volume *v, int filter) {
     v->filter = (filter == VPT_FILTER_LINEAR) ? VPT_FILTER_LINEAR : VPT_FILTER_NEAREST;   // Volume.js:121
     return VPT_OK;
 }
+extern "C" int vpt_volume_set_wide_tables(vpt_volume *v, int wide) {
+    if (!v) return fail(VPT_ERR_INVALID, "volume is null");
+    if (!wide && v->brick_bytes > 0xffffffffull) return fail(VPT_ERR_INVALID, "bricked layout exceeds 4 GiB: 64-bit offset tables are required");
+    v->wide = wide != 0;
+    return VPT_OK;
+}
 extern "C" int vpt_volume_bricked_bytes(vpt_volume *v, uint64_t *n) {
     if (!v || !n) return fail(VPT_ERR_INVALID, "null argument");
     *n = v->brick_bytes;

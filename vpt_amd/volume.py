@@ -135,6 +135,10 @@ class Volume(EventTarget):
         vol.setFilter(filter)
         return vol
 
+    def set_wide_tables(self, wide):
+        """force the 64-bit brick-offset tables (automatic above 4 GiB of bricked data)"""
+        N.check(N.lib().vpt_volume_set_wide_tables(self.texture, 1 if wide else 0))
+
     def bricked_bytes(self):
         n = C.c_uint64(0)
         N.check(N.lib().vpt_volume_bricked_bytes(self.texture, C.byref(n)))
