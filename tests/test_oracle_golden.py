@@ -314,3 +314,15 @@ def test_oracle_openmp_rows_equal_scalar(oracle):
         outs.append([s.copy() for s in r.state])
     for a, b in zip(*outs):
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_contract_digests_are_frozen(oracle):
+    """tests/golden/contract_r01.json freezes the oracle's output bits for small seeded scenes of all four renderers"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_contract_fixture", os.path.join(GOLD, "make_contract_fixture.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(GOLD, "contract_r01.json")))["scenes"]
+    sc_list, dm = mod.scenes()
+    assert {s["name"] for s in sc_list} == set(want)
+    for sc in sc_list:
+        assert mod.run(oracle, sc, dm) == want[sc["name"]], sc["name"]
