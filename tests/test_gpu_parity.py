@@ -442,3 +442,39 @@ def test_full_size_other_renderers_oracle_band(gpu_ctx, oracle, full_scene, kind
     assert_same_bits(acc[y0:y1], o.acc.reshape(shape)[y0:y1], "%s oracle band" % kind)
     if sc is not full_scene:
         sc.gvol.destroy()
+
+
+def test_gpu_matches_committed_contract_digests(gpu_ctx):
+    """the HIP path against tests/golden/contract_r01.json alone (no oracle library involved): explicit uniforms through
+    the C-ABI, SHA-256 of the buffers"""
+    import importlib.util, json, os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_contract_fixture", os.path.join(gold, "make_contract_fixture.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(gold, "contract_r01.json")))["scenes"]
+    sc_list, dm = mod.scenes()
+    L = N.lib()
+    seq = lambda k: float(np.float32((k * 0.61803398875) % 1.0))
+    for sc in sc_list:
+        vol = vpt_amd.Volume.from_array(gpu_ctx, sc["vol"], sc["filter"])
+        cam = default_camera(sc["w"] / sc["h"])
+        r = vpt_amd.RendererFactory(sc["kind"])(gpu_ctx, vol, cam, None, {'resolution': (sc["w"], sc["h"]), 'transform': Transform(Node())})
+        if sc["tf"] is not None:
+            r.setTransferFunction(sc["tf"])
+        r._bind_volume()
+        kw = sc["kw"]
+        u = r._new_uniforms()
+        u.rand_seed = seq(1); u.blur = 0.0
+        u.step_size = float(np.float32(1.0 / kw.get("steps", 64)))
+        u.extinction = float(np.float32(kw.get("extinction", 1.0))); u.anisotropy = float(np.float32(kw.get("anisotropy", 0.0)))
+        u.max_bounces = kw.get("max_bounces", 8); u.steps = kw.get("mcm_steps", 8)
+        for i, v in enumerate(kw.get("light_dir", (0.0, 0.0, 1.0))):
+            u.light_direction[i] = float(np.float32(v))
+        N.check(L.vpt_renderer_reset(r._h, C.byref(u)))
+        for k in range(sc["frames"]):
+            u.rand_seed = seq(k + 2); u.offset = seq(k + 2); u.mix = float(np.float32(1.0 / (k + 1)))
+            N.check(L.vpt_renderer_render(r._h, C.byref(u)))
+        bufs = [r.read(b) for b in MCM_BUFFERS] if sc["kind"] == "mcm" else [r.read(N.BUFFER_ACCUM)]
+        got = {"buffers": mod.digest(*bufs), "render_f16": mod.digest(r.getTexture().view(np.uint16)), "samples": r.sample_count()}
+        assert got == want[sc["name"]], sc["name"]
+        r.destroy(); vol.destroy()
