@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--profile-kernel", type=int, default=8,
                     help="HIP events around every n-th launch of the dominant kernel in the timed region (1 = every launch, 0 = none)")
     ap.add_argument("--fused", type=int, default=1, help="0: run the three hooks as separate launches (profiling aid)")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="frames enqueued per host call (vpt_*_play); 0 = 1 (frame by frame)")
+    ap.add_argument("--graph", type=int, default=1, help="replay frame sequences as a captured hipGraph (with --frames-per-launch > 1)")
     ap.add_argument("--gather", default="native", choices=["native", "torch"],
                     help="frame gather for N > 1: 'native' = RCCL pipeline below the C ABI (vpt_gather_*), 'torch' = torch.distributed all_gather")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
@@ -169,6 +172,17 @@ def main():
                 if rank == 0:
                     print("native RCCL gather unavailable (%s); using torch.distributed all_gather" % err, file=sys.stderr)
 
+        fpl = args.frames_per_launch or 1             # measured: sequences do not beat frame-by-frame enqueue
+        if fpl > 1 and native is None and use_dist:
+            fpl = 1                                   # the torch.distributed gather is driven frame by frame
+
+        def step_many(n):
+            """n frames by one native call: per-frame uniforms in a device table, optionally one hipGraph replay"""
+            if native is not None:
+                native.play(n)                       # eager: graphs holding RCCL collectives are slower here (DESIGN.md section 7)
+            else:
+                r.play(n, use_graph=bool(args.graph) and n == fpl)   # one cached graph: only full-size chunks replay it
+
         def step(k):
             if native is not None:
                 native.render()                      # kernel + async RCCL all_gather, one enqueue each, below the C ABI
@@ -185,8 +199,25 @@ def main():
             else:
                 gather.wait(0); gather.wait(1)
 
-        for k in range(args.warmup):
-            step(k)
+        def run_steps(nsteps):
+            if fpl <= 1:
+                for k in range(nsteps):
+                    step(k)
+                return
+            done = 0
+            while done < nsteps:
+                n = min(fpl, nsteps - done)
+                if n == 1:
+                    step(done)
+                else:
+                    step_many(n)
+                done += n
+
+        r.set_profiling(args.profile_kernel)          # before the warm-up so that a captured graph carries its timing events
+        warm = args.warmup
+        run_steps(warm)                               # the first frame sequence runs eagerly (lazy allocations) ...
+        if fpl > 1:
+            run_steps(2 * fpl)                        # ... the next ones capture and replay the graph, outside the timed region
         drain()
         torch.cuda.synchronize()
         r.clear_sample_count()
@@ -195,8 +226,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(k)
+        run_steps(args.steps)
         drain()
         torch.cuda.synchronize()
         if use_dist:
@@ -256,6 +286,7 @@ def main():
                                    "default camera, default 2x1 transfer function, extinction %g, anisotropy 0, bounces 8, "
                                    "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
                        "parallelism": ("image rows sharded over %d GPU(s), per-frame RCCL all_gather (%s pipeline)" % (world, args.gather)) if use_dist else "single GPU",
+                       "frames_per_launch": fpl, "hipgraph": bool(args.graph) and fpl > 1 and native is None,
                        "samples_per_step": samples / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

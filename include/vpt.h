@@ -131,6 +131,13 @@ VPT_API int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u);  
 /* render(): generate -> integrate -> swap -> renderFrame in ONE launch (same results as the three hooks) */
 VPT_API int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u);
 
+/* Frame sequences: `count` consecutive render() passes enqueued by ONE call.  `base` holds the uniforms the frames
+ * share; frame_vars holds count x 8 floats {rand_seed, offset, mix, 0, light.x, light.y, light.z, 0} — the uniforms
+ * that change per frame — which are uploaded to a device table read by the kernels through a device-side frame
+ * counter.  With use_graph != 0 the launch sequence is captured once into a hipGraph and replayed (launch-bound
+ * regimes: small per-GPU shards).  Results are identical to `count` calls of vpt_renderer_render. */
+VPT_API int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int use_graph);
+
 /* read-back (the reference never reads back; it hands getTexture() to the tone mapper). Row-major, local rows. */
 VPT_API int vpt_renderer_read(vpt_renderer *r, int buffer, void *host_dst, size_t nbytes);
 /* device pointer of the row-major RGBA16F render buffer (for the RCCL frame gather) */
@@ -169,6 +176,9 @@ VPT_API int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, int 
 VPT_API int vpt_gather_destroy(vpt_gather *g);
 /* render() of the renderer into the next send buffer + asynchronous all_gather of it */
 VPT_API int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u);
+/* `count` frames of the pipeline by one call (frame_vars as for vpt_renderer_play); always enqueued eagerly — a
+ * captured graph holding RCCL collectives measured slower and unstable on this stack */
+VPT_API int vpt_gather_play(vpt_gather *g, const vpt_uniforms *base, const float *frame_vars, int count);
 /* blocks until every enqueued frame has been rendered and gathered */
 VPT_API int vpt_gather_synchronize(vpt_gather *g);
 /* the most recently gathered frame, rows put back in order: [height][width] RGBA16F -> host (blocks) */

@@ -478,3 +478,58 @@ def test_gpu_matches_committed_contract_digests(gpu_ctx):
         got = {"buffers": mod.digest(*bufs), "render_f16": mod.digest(r.getTexture().view(np.uint16)), "samples": r.sample_count()}
         assert got == want[sc["name"]], sc["name"]
         r.destroy(); vol.destroy()
+
+
+@pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "mcm"])
+def test_play_frame_sequences_equal_render_calls(gpu_ctx, oracle, kind):
+    """vpt_renderer_play: per-frame uniforms from a device table, eager and as a replayed hipGraph == N x render()"""
+    sc = Scene(gpu_ctx, oracle, 32, 100, 70, tf=colour_tf(64, 1), camera=orbit_camera(100 / 70))
+
+    def make():
+        r = sc.renderer(kind)
+        if kind in ('mcs', 'mcm'):
+            r.extinction = 9
+        r.reset()
+        return r
+
+    buf = MCM_BUFFERS[3] if kind == "mcm" else N.BUFFER_ACCUM
+    ref = make()
+    for _ in range(10):
+        ref.render()
+    want_img, want_buf, want_ns = ref.getTexture(), ref.read(buf), ref.sample_count()
+    eager = make()
+    eager.play(3, use_graph=False); eager.play(7, use_graph=False)
+    assert_same_bits(eager.getTexture(), want_img, "%s eager play" % kind); assert_same_bits(eager.read(buf), want_buf, "%s eager play buffer" % kind)
+    assert eager.sample_count() == want_ns
+    graph = make()
+    graph.render(); graph.render()                      # warm: lazy allocations happen outside the capture
+    graph.play(4, use_graph=True); graph.play(4, use_graph=True)     # second call replays the cached graph
+    assert_same_bits(graph.getTexture(), want_img, "%s graph play" % kind); assert_same_bits(graph.read(buf), want_buf, "%s graph play buffer" % kind)
+    assert graph.sample_count() == want_ns
+    for r in (ref, eager, graph):
+        r.destroy()
+    sc.gvol.destroy()
+
+
+def test_native_rccl_gather_play(gpu_ctx, oracle):
+    """vpt_gather_play: frame sequences (kernel + cross-stream event edges + RCCL all_gather per frame) by one call (one-rank comm)"""
+    from vpt_amd.tiles import RcclFrameGather
+    sc = Scene(gpu_ctx, oracle, 32, 100, 70, tf=colour_tf(64, 1), camera=orbit_camera(100 / 70))
+    plain = sc.renderer('mcm'); plain.extinction = 9; plain.reset()
+    shard = sc.renderer('mcm', shard=(0, 1, 8)); shard.extinction = 9; shard.reset()
+    g = RcclFrameGather(shard, RcclFrameGather.unique_id(), 0, 1)
+    g.render(); g.render()
+    for _ in range(2):
+        plain.render()
+    for rep in range(3):
+        g.play(6)
+        for _ in range(6):
+            plain.render()
+        assert_same_bits(g.frame(), plain.getTexture(), "gathered frame after sequence %d" % rep)
+    g.play(3); g.render()
+    for _ in range(4):
+        plain.render()
+    assert_same_bits(g.frame(), plain.getTexture(), "odd-length sequence then single frame")
+    assert_same_bits(shard.read(N.BUFFER_MCM_RADIANCE), plain.read(N.BUFFER_MCM_RADIANCE), "state")
+    assert shard.sample_count() == plain.sample_count()
+    g.destroy(); plain.destroy(); shard.destroy(); sc.gvol.destroy()

@@ -27,11 +27,12 @@ SYMBOLS = [
     "vpt_renderer_destroy", "vpt_renderer_set_volume", "vpt_renderer_set_transfer_function",
     "vpt_renderer_set_environment", "vpt_renderer_resize",
     "vpt_renderer_reset", "vpt_renderer_generate", "vpt_renderer_integrate", "vpt_renderer_render_frame",
-    "vpt_renderer_render", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
+    "vpt_renderer_render", "vpt_renderer_play", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
     "vpt_renderer_set_render_target",
     "vpt_renderer_set_option", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile",
-    "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_synchronize",
+    "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play",
+    "vpt_gather_synchronize",
     "vpt_gather_read_frame",
     "vpt_probe_math", "vpt_probe_sample",
 ]
@@ -88,7 +89,8 @@ def lib():
         "vpt_renderer_resize": [P, I, I],
         "vpt_renderer_reset": [P, UP], "vpt_renderer_generate": [P, UP], "vpt_renderer_integrate": [P, UP],
         "vpt_renderer_render_frame": [P, UP], "vpt_renderer_render": [P, UP],
-        "vpt_renderer_read": [P, I, P, SZ],
+        "vpt_renderer_read": [P, I, P, SZ], "vpt_renderer_play": [P, UP, P, I, I],
+        "vpt_gather_play": [P, UP, P, I],
         "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
         "vpt_renderer_set_render_target": [P, P, SZ],
         "vpt_renderer_set_option": [P, I, I],

@@ -72,6 +72,10 @@ struct vpt_renderer {
     uint2 *render;
     uint2 *render_target;          // caller-owned redirect of the render buffer (or null)
     float *ndc_x, *ndc_y;          // pixel-centre NDC tables (W and H entries)
+    FrameVar *frame_table; FrameVar *frame_staging; uint32_t *frame_counter;   // device ring of per-frame uniforms + pinned staging
+    uint64_t frames_played;        // host copy of the monotonic device frame counter
+    bool warmed;                   // at least one eager fused render() has run (lazy allocations done)
+    struct PlayGraph *play_graph;  // cached hipGraph of a frame sequence
     uint32_t *work_counter;        // tile counter of the persistent MCS kernel
     bool mcs_persistent;           // use k_mcs_persist (active-ray compaction) for the MCS generate pass
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
@@ -81,10 +85,14 @@ struct vpt_renderer {
     bool profiling;
     int profile_every; uint64_t profile_seq;   // time every n-th launch of the dominant kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<uint32_t> event_launches;   // kernel launches covered by each event pair (1, or the frames of a graph replay)
     size_t events_used;
 };
 
 static const size_t COUNTER_BYTES = (size_t)VPT_COUNTER_SLOTS * VPT_COUNTER_STRIDE * sizeof(unsigned long long);
+
+struct PlayGraph;
+static void play_graph_free(PlayGraph *g);
 
 static size_t frame_elem(int kind) {
     switch (kind) {
@@ -290,6 +298,7 @@ static void renderer_free_buffers(vpt_renderer *r) {
 // _rebuildBuffers: AbstractRenderer.js:78-92 (+ the per-renderer buffer specs)
 static int renderer_alloc_buffers(vpt_renderer *r) {
     vpt_context *c = r->ctx;
+    if (r->play_graph) { hipStreamSynchronize(c->stream); play_graph_free(r->play_graph); r->play_graph = nullptr; }
     r->render_target = nullptr;   // an external target was sized for the old geometry
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -381,6 +390,8 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     for (int i = 0; i < 4; i++) r->st[i] = nullptr;
     r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0; r->profile_every = 1; r->profile_seq = 0;
     r->ndc_x = r->ndc_y = nullptr;
+    r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
+    r->warmed = false; r->play_graph = nullptr;
     r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     int rc = renderer_alloc_buffers(r);
@@ -406,6 +417,10 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (r->env) hipFree(r->env);
     if (r->samples) hipFree(r->samples);
     if (r->work_counter) hipFree(r->work_counter);
+    if (r->frame_table) hipFree(r->frame_table);
+    if (r->frame_staging) hipHostFree(r->frame_staging);
+    if (r->frame_counter) hipFree(r->frame_counter);
+    if (r->play_graph) play_graph_free(r->play_graph);
     for (auto &ev : r->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete r;
     return VPT_OK;
@@ -567,17 +582,19 @@ static int check_step(const vpt_uniforms *u) {
     return VPT_OK;
 }
 
-struct Timed {   // per-launch HIP events around the dominant kernel
+struct Timed {   // HIP events around the dominant kernel (or around one graph replay of `launches` of them)
     vpt_renderer *r; bool on; size_t idx;
-    Timed(vpt_renderer *r_, bool dominant) : r(r_), on(r_->profiling && dominant), idx(0) {
+    Timed(vpt_renderer *r_, bool dominant, uint32_t launches = 1) : r(r_), on(r_->profiling && dominant), idx(0) {
         if (on) on = (r->profile_seq++ % (uint64_t)r->profile_every) == 0;
         if (!on) return;
         if (r->events_used == r->events.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
             r->events.push_back({ a, b });
+            r->event_launches.push_back(1);
         }
         idx = r->events_used++;
+        r->event_launches[idx] = launches;
         hipEventRecord(r->events[idx].first, r->ctx->stream);
     }
     ~Timed() { if (on) hipEventRecord(r->events[idx].second, r->ctx->stream); }
@@ -650,6 +667,18 @@ extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u)
     HIP_TRY(hipGetLastError());
     return VPT_OK;
 }
+// the fused render() launch of the renderer's kind (generate -> integrate -> renderFrame in one kernel)
+static int launch_fused(vpt_renderer *r, const PassArgs &a) {
+    switch (r->kind) {
+        case VPT_RENDERER_MIP: LAUNCH_S(K_MIP1, r, a); break;
+        case VPT_RENDERER_EAM: LAUNCH_S(K_EAM1, r, a); break;
+        case VPT_RENDERER_MCS: if (r->mcs_persistent) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
+        case VPT_RENDERER_MCM:
+            if (r->mcm_persistent) LAUNCH_MCM_PERSIST(true, r, a); else LAUNCH_S(K_MCM1, r, a);
+            break;
+    }
+    return VPT_OK;
+}
 extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(r->ctx->device));
@@ -658,17 +687,112 @@ extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
     VPT_TRY(make_args(r, u, true, &a));
     {
         Timed t(r, true);
-        switch (r->kind) {
-            case VPT_RENDERER_MIP: LAUNCH_S(K_MIP1, r, a); break;
-            case VPT_RENDERER_EAM: LAUNCH_S(K_EAM1, r, a); break;
-            case VPT_RENDERER_MCS: if (r->mcs_persistent) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
-            case VPT_RENDERER_MCM:
-                if (r->mcm_persistent) LAUNCH_MCM_PERSIST(true, r, a); else LAUNCH_S(K_MCM1, r, a);
-                r->samples_host += r->valid_pixels * (uint64_t)u->steps;
-                break;
-        }
+        VPT_TRY(launch_fused(r, a));
+        if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)u->steps;
     }
     HIP_TRY(hipGetLastError());
+    r->warmed = true;
+    return VPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame sequences: `count` render() passes per host call, per-frame uniforms in a device table, optional hipGraph replay
+// ---------------------------------------------------------------------------------------------
+struct PlayGraph {
+    hipGraph_t graph; hipGraphExec_t exec;
+    int count; bool with_gather; PassArgs key;
+    bool ran;
+};
+static void play_graph_free(PlayGraph *g) {
+    if (!g) return;
+    if (g->exec) hipGraphExecDestroy(g->exec);
+    if (g->graph) hipGraphDestroy(g->graph);
+    delete g;
+}
+// Appends the per-frame uniforms of the next `count` frames to the device ring (through a pinned staging ring, so the
+// copy is asynchronous and the host never waits) and returns the PassArgs shared by the frames.  The device frame
+// counter is monotonic: a captured graph needs no per-replay patching.
+#define VPT_FRAME_RING 2048
+static int play_args(vpt_renderer *r, const vpt_uniforms *base, int count, PassArgs *a) {
+    if (count < 1 || count > VPT_FRAME_RING / 4) return fail(VPT_ERR_INVALID, "frame count %d out of range [1, %d]", count, VPT_FRAME_RING / 4);
+    if (r->kind == VPT_RENDERER_MIP || r->kind == VPT_RENDERER_EAM) VPT_TRY(check_step(base));
+    return make_args(r, base, true, a);
+}
+// eager frames carry their uniforms in the kernel arguments
+static inline PassArgs frame_args(const PassArgs &a, const FrameVar &v) {
+    PassArgs f = a;
+    f.seed = v.seed; f.offset = v.offset; f.mix = v.mix; f.light = f3{ v.lx, v.ly, v.lz };
+    return f;
+}
+static int play_upload_table(vpt_renderer *r, const float *vars, int count, PassArgs *a) {
+    vpt_context *c = r->ctx;
+    static_assert(sizeof(FrameVar) == 8 * sizeof(float), "FrameVar is 8 floats");
+    if (!r->frame_table) {
+        HIP_TRY(hipMalloc(&r->frame_table, (size_t)VPT_FRAME_RING * sizeof(FrameVar)));
+        HIP_TRY(hipHostMalloc((void **)&r->frame_staging, (size_t)VPT_FRAME_RING * sizeof(FrameVar), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&r->frame_counter, sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(r->frame_counter, 0, sizeof(uint32_t), c->stream));
+        r->frames_played = 0;
+    }
+    // a staging slot is reused VPT_FRAME_RING frames later: never let more than half a ring be in flight
+    if ((r->frames_played % (VPT_FRAME_RING / 2)) + (uint64_t)count > VPT_FRAME_RING / 2) HIP_TRY(hipStreamSynchronize(c->stream));
+    const FrameVar *src = (const FrameVar *)vars;
+    int pos = (int)(r->frames_played % VPT_FRAME_RING);
+    int first = count < VPT_FRAME_RING - pos ? count : VPT_FRAME_RING - pos;
+    memcpy(r->frame_staging + pos, src, (size_t)first * sizeof(FrameVar));
+    HIP_TRY(hipMemcpyAsync(r->frame_table + pos, r->frame_staging + pos, (size_t)first * sizeof(FrameVar), hipMemcpyHostToDevice, c->stream));
+    if (first < count) {
+        memcpy(r->frame_staging, src + first, (size_t)(count - first) * sizeof(FrameVar));
+        HIP_TRY(hipMemcpyAsync(r->frame_table, r->frame_staging, (size_t)(count - first) * sizeof(FrameVar), hipMemcpyHostToDevice, c->stream));
+    }
+    r->frames_played += (uint64_t)count;
+    a->frame_table = r->frame_table;
+    a->frame_counter = r->frame_counter;
+    a->frame_mask = VPT_FRAME_RING - 1;
+    return VPT_OK;
+}
+static bool play_key_equal(const PassArgs &x, const PassArgs &y) { return memcmp(&x, &y, sizeof(PassArgs)) == 0; }
+
+extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int use_graph) {
+    if (!r || !base || !frame_vars) return fail(VPT_ERR_INVALID, "null argument");
+    vpt_context *c = r->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    PassArgs a;
+    VPT_TRY(play_args(r, base, count, &a));
+    if (use_graph && r->warmed) {
+        VPT_TRY(play_upload_table(r, frame_vars, count, &a));
+        PlayGraph *g = r->play_graph;
+        if (!g || g->with_gather || g->count != count || !play_key_equal(g->key, a)) {
+            if (g) { HIP_TRY(hipStreamSynchronize(c->stream)); play_graph_free(g); r->play_graph = nullptr; }
+            g = new PlayGraph(); memset(g, 0, sizeof(*g));
+            g->count = count; g->with_gather = false; g->key = a;
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+            int rc = VPT_OK;
+            for (int i = 0; i < count && rc == VPT_OK; i++) {
+                rc = launch_fused(r, a);
+                hipLaunchKernelGGL(k_advance_frame, dim3(1), dim3(1), 0, c->stream, r->frame_counter);
+            }
+            hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
+            if (rc == VPT_OK && e != hipSuccess) rc = fail(VPT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            if (rc == VPT_OK) { e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0); if (e != hipSuccess) rc = fail(VPT_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+            if (rc != VPT_OK) { play_graph_free(g); return rc; }
+            r->play_graph = g;
+        }
+        {
+            Timed t(r, true, (uint32_t)count);       // a replay is timed as a whole: events inside a graph cannot be read back
+            HIP_TRY(hipGraphLaunch(g->exec, c->stream));
+        }
+        g->ran = true;
+    } else {
+        const FrameVar *v = (const FrameVar *)frame_vars;
+        for (int i = 0; i < count; i++) {
+            Timed t(r, true);
+            VPT_TRY(launch_fused(r, frame_args(a, v[i])));
+        }
+        HIP_TRY(hipGetLastError());
+        r->warmed = true;
+    }
+    if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)base->steps * (uint64_t)count;
     return VPT_OK;
 }
 
@@ -769,7 +893,9 @@ extern "C" int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t 
         HIP_TRY(hipEventElapsedTime(&ms, r->events[i].first, r->events[i].second));
         sum += (double)ms;
     }
-    *total_ms = sum; *launches = (uint32_t)r->events_used;
+    uint32_t n = 0;
+    for (size_t i = 0; i < r->events_used; i++) n += r->event_launches[i];
+    *total_ms = sum; *launches = n;
     return VPT_OK;
 }
 
@@ -940,21 +1066,72 @@ extern "C" int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, i
     *out = g;
     return VPT_OK;
 }
+// per-launch timing (vpt_renderer_set_profiling) applies to the pipeline's kernel as well
+static void profile_events(vpt_renderer *r, hipEvent_t *t0, hipEvent_t *t1) {
+    *t0 = *t1 = nullptr;
+    if (!(r->profiling && (r->profile_seq++ % (uint64_t)r->profile_every) == 0)) return;
+    if (r->events_used == r->events.size()) {
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess) return;
+        if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return; }
+        r->events.push_back({ e0, e1 }); r->event_launches.push_back(1);
+    }
+    *t0 = r->events[r->events_used].first; *t1 = r->events[r->events_used].second;
+    r->event_launches[r->events_used] = 1; r->events_used++;
+}
+static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0, hipEvent_t t1);
 extern "C" int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u) {
     if (!g || !u) return fail(VPT_ERR_INVALID, "null argument");
     vpt_renderer *r = g->r;
-    hipStream_t cs = r->ctx->stream;
     HIP_TRY(hipSetDevice(r->ctx->device));
+    if (r->kind == VPT_RENDERER_MIP || r->kind == VPT_RENDERER_EAM) VPT_TRY(check_step(u));
+    PassArgs a;
+    VPT_TRY(make_args(r, u, true, &a));
+    hipEvent_t t0, t1;
+    profile_events(r, &t0, &t1);
+    VPT_TRY(gather_enqueue_frame(g, a, t0, t1));
+    if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)u->steps;
+    r->warmed = true;
+    return VPT_OK;
+}
+// one frame of the gather pipeline on (compute stream cs, communication stream)
+static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+    vpt_renderer *r = g->r;
+    hipStream_t cs = r->ctx->stream;
     int b = (int)(g->frames & 1);
     if (g->used[b]) HIP_TRY(hipStreamWaitEvent(cs, g->gathered[b], 0));     // the gather that last read send[b] is done
-    VPT_TRY(vpt_renderer_set_render_target(r, g->send[b], g->send_bytes));
-    VPT_TRY(vpt_renderer_render(r, u));
+    a.render = (uint2 *)g->send[b];
+    r->render_target = a.render;                                             // vpt_renderer_read(RENDER) returns the last frame's rows
+    if (t0) HIP_TRY(hipEventRecord(t0, cs));
+    VPT_TRY(launch_fused(r, a));
+    if (t1) HIP_TRY(hipEventRecord(t1, cs));
     HIP_TRY(hipEventRecord(g->rendered[b], cs));
     HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[b], 0));
     RCCL_TRY(g_rccl.AllGather(g->send[b], g->recv[b], g->send_bytes, /*ncclUint8*/ 1, g->comm, g->comm_stream));
     HIP_TRY(hipEventRecord(g->gathered[b], g->comm_stream));
     g->used[b] = true;
     g->frames++;
+    return VPT_OK;
+}
+// `count` frames by one call.  A captured hipGraph holding the RCCL all-gathers was measured 6x slower per frame than
+// this eager enqueue and unstable over many replays on ROCm 7.0 / RCCL 2.26, so the sequence is
+// always enqueued eagerly: two stream operations per frame on each of the two streams.
+extern "C" int vpt_gather_play(vpt_gather *g, const vpt_uniforms *base, const float *frame_vars, int count) {
+    if (!g || !base || !frame_vars) return fail(VPT_ERR_INVALID, "null argument");
+    vpt_renderer *r = g->r;
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    PassArgs a;
+    VPT_TRY(play_args(r, base, count, &a));
+    const FrameVar *v = (const FrameVar *)frame_vars;
+    for (int i = 0; i < count; i++) {
+        PassArgs f = frame_args(a, v[i]);
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        profile_events(r, &t0, &t1);
+        VPT_TRY(gather_enqueue_frame(g, f, t0, t1));
+    }
+    HIP_TRY(hipGetLastError());
+    r->warmed = true;
+    if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)base->steps * (uint64_t)count;
     return VPT_OK;
 }
 extern "C" int vpt_gather_synchronize(vpt_gather *g) {

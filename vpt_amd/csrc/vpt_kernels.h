@@ -72,7 +72,21 @@ struct PassArgs {
     float4 *st0, *st1, *st2, *st3;   // MCM photon state, tile order
     uint2 *render;               // RGBA16F, row-major local rows
     unsigned long long *samples; // volume-sample counter
+    // frame sequences (vpt_renderer_play / hipGraph replay): the per-frame uniforms come from a device table indexed
+    // by a device-side frame counter, so one captured launch sequence serves every replay
+    const struct FrameVar *frame_table;     // ring of frame_mask + 1 entries
+    const uint32_t *frame_counter;          // frames played so far (monotonic); entry = counter & frame_mask
+    uint32_t frame_mask;
 };
+struct FrameVar { float seed, offset, mix, pad0; float lx, ly, lz, pad1; };   // the uniforms that change per frame
+VPT_DEV void apply_frame_table(PassArgs &a) {
+    if (a.frame_table) {
+        FrameVar v = a.frame_table[*a.frame_counter & a.frame_mask];
+        a.seed = v.seed; a.offset = v.offset; a.mix = v.mix;
+        a.light = f3{ v.lx, v.ly, v.lz };
+    }
+}
+__global__ void k_advance_frame(uint32_t *counter) { *counter = *counter + 1u; }
 
 // dynamic LDS: [tf pairs: tf_w * 2 float4][TX nx][TY ny][TZ nz] (table entries 4 B, or 8 B when WIDE)
 template <bool WIDE>
@@ -172,6 +186,7 @@ VPT_DEV uint32_t mip_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, 
 // (MIPRenderer.glsl:105-109, max on unorm8), renderFrame (:141-144) in one pass.
 template <int MODE, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_mip(PassArgs a) {
+    apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
@@ -271,6 +286,7 @@ VPT_DEV uint2 eam_to_half4(uint32_t q) {   // render: EAMRenderer.glsl:151-153
 }
 template <int MODE, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_eam(PassArgs a) {
+    apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
@@ -372,6 +388,7 @@ VPT_DEV float4 mcs_mix(float4 acc, float4 frame, float inv) {   // MCSRenderer.g
 }
 template <int MODE, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
+    apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
@@ -729,6 +746,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
 template <bool FUSE_RENDER, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_integrate(PassArgs a) {
+    apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);

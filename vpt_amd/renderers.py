@@ -205,6 +205,22 @@ class AbstractRenderer(PropertyBag):
         N.check(N.lib().vpt_renderer_render_buffer_device(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def _collect_frames(self, count):
+        """draws the per-frame uniforms of the next `count` frames exactly as `count` render() calls would"""
+        vars_ = np.zeros((count, 8), dtype=np.float32)
+        u = None
+        for k in range(count):
+            u = self._prepare_frame_uniforms()
+            vars_[k, 0], vars_[k, 1], vars_[k, 2] = u.rand_seed, u.offset, u.mix
+            vars_[k, 4:7] = list(u.light_direction)
+        return u, vars_
+
+    def play(self, count, use_graph=True):
+        """`count` render() passes enqueued by one native call (optionally one hipGraph replay); same buffers as count x render()"""
+        self._bind_volume()
+        u, vars_ = self._collect_frames(count)
+        N.check(N.lib().vpt_renderer_play(self._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), count, 1 if use_graph else 0))
+
     def set_option(self, option, value):
         N.check(N.lib().vpt_renderer_set_option(self._h, int(option), int(value)))
 
