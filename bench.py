@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--mcs-persistent", type=int, default=-1, help="MCS only: 1/0 force the persistent-wave kernel on/off")
     ap.add_argument("--profile-kernel", type=int, default=8,
                     help="HIP events around every n-th launch of the dominant kernel in the timed region (1 = every launch, 0 = none)")
+    ap.add_argument("--stream-probe", type=int, default=1, help="also measure the HBM streaming-read rate (second roofline denominator)")
     ap.add_argument("--fused", type=int, default=1, help="0: run the three hooks as separate launches (profiling aid)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames enqueued per host call (vpt_*_play); 0 = 1 (frame by frame)")
@@ -235,6 +236,12 @@ def main():
         dt = time.perf_counter() - t0
         kernel_ms, launches = r.profile()
         r.set_profiling(False)
+        stream_gbs = None
+        if rank == 0 and args.stream_probe:
+            try:
+                stream_gbs = ctx.stream_read_rate(4 << 30, 10)      # 4 GiB: far beyond the 256 MB Infinity Cache
+            except Exception:                                       # reporting only
+                stream_gbs = None
         samples_local = r.sample_count()
 
         tt = torch.tensor([dt, float(samples_local)], dtype=torch.float64, device=device)
@@ -290,6 +297,8 @@ def main():
                        "samples_per_step": samples / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak_measured_stream_read": stream_gbs,
+                         "frac_of_measured": (achieved / stream_gbs) if stream_gbs else None,
                          "kernel": "k_mcm_integrate<fused render>" if args.renderer == "mcm" else "k_%s<fused>" % args.renderer,
                          "kernel_avg_ms": avg_ms, "launches": launches,
                          "bytes_per_sample": B_ALG_MCM if args.renderer == "mcm" else 8.0},

@@ -203,6 +203,9 @@ VPT_API int vpt_gather_read_frame(vpt_gather *g, void *host_dst, size_t nbytes);
 VPT_API int vpt_probe_math(vpt_context *ctx, int which, const float *in, float *out, size_t n);
 /* samples texture(uVolume, p) -> transfer function at n positions (xyz triples); out = n RGBA float4 */
 VPT_API int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n);
+/* measured HBM streaming-read rate: `iterations` grid-stride 16 B/lane reads of an nbytes scratch buffer (choose it far
+ * larger than the 256 MB Infinity Cache); the second denominator SURVEY section 8d asks for next to the 8 TB/s peak */
+VPT_API int vpt_probe_stream_read(vpt_context *ctx, size_t nbytes, int iterations, double *gb_per_s);
 
 #ifdef __cplusplus
 }

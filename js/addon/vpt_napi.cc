@@ -253,6 +253,77 @@ static napi_value RendererProfile(napi_env env, napi_callback_info info) {
     return o;
 }
 
+static napi_value RendererSetOption(napi_env env, napi_callback_info info) {
+    napi_value a[3]; vpt_renderer *r; int32_t opt, val;
+    if (!get_args(env, info, 3, a) || !get_handle(env, a[0], &r) || !get_i32(env, a[1], &opt) || !get_i32(env, a[2], &val)) return nullptr;
+    VPT_CHECK(vpt_renderer_set_option(r, opt, val));
+    return undefined(env);
+}
+// rendererPlay(handle, baseUniforms, frameVars: Float32Array of 8 floats per frame, useGraph)
+static bool get_frame_vars(napi_env env, napi_value v, const float **vars, int *count) {
+    void *p; size_t n;
+    if (!get_bytes(env, v, &p, &n)) return false;
+    if (n == 0 || n % (8 * sizeof(float)) != 0) { napi_throw_range_error(env, nullptr, "frame variables are 8 floats per frame"); return false; }
+    *vars = (const float *)p; *count = (int)(n / (8 * sizeof(float)));
+    return true;
+}
+static napi_value RendererPlay(napi_env env, napi_callback_info info) {
+    napi_value a[4]; vpt_renderer *r; const vpt_uniforms *u; const float *vars; int count; int32_t graph;
+    if (!get_args(env, info, 4, a) || !get_handle(env, a[0], &r) || !get_uniforms(env, a[1], &u, false) ||
+        !get_frame_vars(env, a[2], &vars, &count) || !get_i32(env, a[3], &graph)) return nullptr;
+    VPT_CHECK(vpt_renderer_play(r, u, vars, count, graph));
+    return undefined(env);
+}
+
+// ---- multi-GPU frame gather ---------------------------------------------------------------------------
+static napi_value GatherUniqueId(napi_env env, napi_callback_info info) {
+    (void)info;
+    void *data; napi_value ab;
+    NAPI_OK(napi_create_arraybuffer(env, 128, &data, &ab));
+    VPT_CHECK(vpt_gather_unique_id(data));
+    return ab;
+}
+static napi_value GatherCreate(napi_env env, napi_callback_info info) {
+    napi_value a[4]; vpt_renderer *r; void *id; size_t n; int32_t rank, world;
+    if (!get_args(env, info, 4, a) || !get_handle(env, a[0], &r) || !get_bytes(env, a[1], &id, &n) || !get_i32(env, a[2], &rank) ||
+        !get_i32(env, a[3], &world)) return nullptr;
+    if (n < 128) { napi_throw_range_error(env, nullptr, "the RCCL unique id is 128 bytes"); return nullptr; }
+    vpt_gather *g = nullptr;
+    VPT_CHECK(vpt_gather_create(r, id, rank, world, &g));
+    return make_external(env, g);
+}
+static napi_value GatherDestroy(napi_env env, napi_callback_info info) {
+    napi_value a[1]; vpt_gather *g;
+    if (!get_args(env, info, 1, a) || !get_handle(env, a[0], &g)) return nullptr;
+    VPT_CHECK(vpt_gather_destroy(g));
+    return undefined(env);
+}
+static napi_value GatherRender(napi_env env, napi_callback_info info) {
+    napi_value a[2]; vpt_gather *g; const vpt_uniforms *u;
+    if (!get_args(env, info, 2, a) || !get_handle(env, a[0], &g) || !get_uniforms(env, a[1], &u, false)) return nullptr;
+    VPT_CHECK(vpt_gather_render(g, u));
+    return undefined(env);
+}
+static napi_value GatherPlay(napi_env env, napi_callback_info info) {
+    napi_value a[3]; vpt_gather *g; const vpt_uniforms *u; const float *vars; int count;
+    if (!get_args(env, info, 3, a) || !get_handle(env, a[0], &g) || !get_uniforms(env, a[1], &u, false) ||
+        !get_frame_vars(env, a[2], &vars, &count)) return nullptr;
+    VPT_CHECK(vpt_gather_play(g, u, vars, count));
+    return undefined(env);
+}
+static napi_value GatherSynchronize(napi_env env, napi_callback_info info) {
+    napi_value a[1]; vpt_gather *g;
+    if (!get_args(env, info, 1, a) || !get_handle(env, a[0], &g)) return nullptr;
+    VPT_CHECK(vpt_gather_synchronize(g));
+    return undefined(env);
+}
+static napi_value GatherReadFrame(napi_env env, napi_callback_info info) {
+    napi_value a[2]; vpt_gather *g; void *dst; size_t n;
+    if (!get_args(env, info, 2, a) || !get_handle(env, a[0], &g) || !get_bytes(env, a[1], &dst, &n)) return nullptr;
+    VPT_CHECK(vpt_gather_read_frame(g, dst, n));
+    return undefined(env);
+}
+
 #define EXPORT(name, fn) do { napi_value f; napi_create_function(env, name, NAPI_AUTO_LENGTH, fn, nullptr, &f); \
                               napi_set_named_property(env, exports, name, f); } while (0)
 #define CONST(name) do { napi_set_named_property(env, exports, #name, number(env, name)); } while (0)
@@ -270,6 +341,11 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("rendererRenderFrame", RendererRenderFrame); EXPORT("rendererRender", RendererRender); EXPORT("rendererRead", RendererRead);
     EXPORT("rendererSampleCount", RendererSampleCount); EXPORT("rendererClearSampleCount", RendererClearSampleCount);
     EXPORT("rendererSetProfiling", RendererSetProfiling); EXPORT("rendererProfile", RendererProfile);
+    EXPORT("rendererSetOption", RendererSetOption); EXPORT("rendererPlay", RendererPlay);
+    EXPORT("gatherUniqueId", GatherUniqueId); EXPORT("gatherCreate", GatherCreate); EXPORT("gatherDestroy", GatherDestroy);
+    EXPORT("gatherRender", GatherRender); EXPORT("gatherPlay", GatherPlay); EXPORT("gatherSynchronize", GatherSynchronize);
+    EXPORT("gatherReadFrame", GatherReadFrame);
+    CONST(VPT_OPTION_MCS_PERSISTENT); CONST(VPT_OPTION_MCM_PERSISTENT);
     CONST(VPT_RENDERER_MIP); CONST(VPT_RENDERER_EAM); CONST(VPT_RENDERER_MCS); CONST(VPT_RENDERER_MCM);
     CONST(VPT_FILTER_NEAREST); CONST(VPT_FILTER_LINEAR); CONST(VPT_FORMAT_R8);
     CONST(VPT_BUFFER_RENDER); CONST(VPT_BUFFER_FRAME); CONST(VPT_BUFFER_ACCUM);

@@ -80,6 +80,21 @@ async function main() {
         r.destroy();
     }
 
+    // ---- one-rank RCCL gather: sharded renderer + FrameGather == plain renderer, bit for bit
+    {
+        const opts = () => ({ resolution: { width: W, height: H }, transform, rng: goldenRng() });
+        const plain = new vpt.MCMRenderer(ctx, volume, camera, null, opts());
+        const sharded = new vpt.MCMRenderer(ctx, volume, camera, null, Object.assign(opts(), { shard: { rank: 0, world: 1, rows: 8 } }));
+        plain.reset(); sharded.reset();
+        const gather = new vpt.FrameGather(sharded, vpt.FrameGather.uniqueId(), 0, 1);
+        for (let k = 0; k < 3; k++) { plain.render(); gather.render(); }
+        gather.synchronize();
+        const want = plain.getTexture(), got = gather.getFrame();
+        assert.strictEqual(got.width, W); assert.strictEqual(got.height, H);
+        assert.deepStrictEqual(got.data, want.data);
+        gather.destroy(); plain.destroy(); sharded.destroy();
+    }
+
     // ---- errors are thrown Errors carrying the native message
     {
         const r = new vpt.MIPRenderer(ctx, null, camera, null, { resolution: 32 });

@@ -5,6 +5,7 @@
 //   gl = vpt Context; environmentTexture = { data: Uint8Array RGBA8, width, height } or null (1x1 white).
 //   options.resolution: number (square, as in the reference) or { width, height }.
 //   options.rng: replaces Math.random() for the per-frame draws (fixed-seed runs).
+//   options.shard: { rank, world, rows } — this process renders only its interleaved row blocks (multi-GPU, FrameGather.js).
 const { PropertyBag } = require('../PropertyBag.js');
 const { Transform, mvpInverseMatrix } = require('../scene.js');
 const { native } = require('../native.js');
@@ -26,6 +27,7 @@ constructor(gl, volume, camera, environmentTexture, options) {
     this.rng = options.rng || Math.random;
     this.fused = options.fused !== undefined ? options.fused : true;
     this._h = null;
+    this._shard = options.shard || null;
     this._boundVolume = undefined;
     this._rebuildBuffers();
     if (environmentTexture) {
@@ -43,6 +45,7 @@ _rebuildBuffers() {                                                             
     const size = this._size();
     if (!this._h) {
         this._h = N.rendererCreate(this._gl._h, this.constructor.KIND(), size[0], size[1]);
+        if (this._shard) { N.rendererSetShard(this._h, this._shard.rank, this._shard.world, this._shard.rows || 8); }
     } else {
         N.rendererResize(this._h, size[0], size[1]);
     }
@@ -106,7 +109,9 @@ _resetFrame() {}
 _generateFrame() {}
 _integrateFrame() {}
 _renderFrame() {}
-_renderFused() {}
+// the uniforms of one whole render() pass, with the per-frame draws taken in hook order (subclasses)
+_prepareFused() { return null; }
+_renderFused() { this._bindVolume(); native().rendererRender(this._h, this._prepareFused()); }
 
 }
 

@@ -42,7 +42,7 @@ _prepareIntegrate() {                                                    // :155
 }
 _integrateFrame() { this._bindVolume(); native().rendererIntegrate(this._h, this._prepareIntegrate()); }   // :121-185
 _renderFrame() { native().rendererRenderFrame(this._h, null); }                                              // :187-199
-_renderFused() { this._bindVolume(); native().rendererRender(this._h, this._prepareIntegrate()); }
+_prepareFused() { return this._prepareIntegrate(); }
 
 }
 module.exports = { MCMRenderer };

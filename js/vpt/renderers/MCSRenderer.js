@@ -45,7 +45,7 @@ _prepareIntegrate() {                                                           
 _generateFrame() { this._bindVolume(); native().rendererGenerate(this._h, this._prepareGenerate()); }
 _integrateFrame() { native().rendererIntegrate(this._h, this._prepareIntegrate()); }
 _renderFrame() { native().rendererRenderFrame(this._h, null); }
-_renderFused() { this._bindVolume(); this._prepareGenerate(); native().rendererRender(this._h, this._prepareIntegrate()); }
+_prepareFused() { this._prepareGenerate(); return this._prepareIntegrate(); }
 
 }
 module.exports = { MCSRenderer };

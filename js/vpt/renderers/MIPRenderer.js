@@ -29,7 +29,7 @@ _prepareGenerate() {                                                    // :82-9
 _generateFrame() { this._bindVolume(); native().rendererGenerate(this._h, this._prepareGenerate()); }
 _integrateFrame() { native().rendererIntegrate(this._h, this._u); }    // :102-117
 _renderFrame() { native().rendererRenderFrame(this._h, null); }        // :119-131
-_renderFused() { this._bindVolume(); native().rendererRender(this._h, this._prepareGenerate()); }
+_prepareFused() { return this._prepareGenerate(); }
 
 }
 module.exports = { MIPRenderer };

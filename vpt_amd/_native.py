@@ -34,7 +34,7 @@ SYMBOLS = [
     "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play",
     "vpt_gather_synchronize",
     "vpt_gather_read_frame",
-    "vpt_probe_math", "vpt_probe_sample",
+    "vpt_probe_math", "vpt_probe_sample", "vpt_probe_stream_read",
 ]
 
 
@@ -97,7 +97,7 @@ def lib():
         "vpt_renderer_sample_count": [P, C.POINTER(C.c_uint64)], "vpt_renderer_clear_sample_count": [P],
         "vpt_renderer_set_profiling": [P, I],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],
-        "vpt_probe_math": [P, I, P, P, SZ], "vpt_probe_sample": [P, P, P, SZ],
+        "vpt_probe_math": [P, I, P, P, SZ], "vpt_probe_sample": [P, P, P, SZ], "vpt_probe_stream_read": [P, SZ, I, P],
         "vpt_gather_unique_id": [P], "vpt_gather_create": [P, P, I, I, PP], "vpt_gather_destroy": [P],
         "vpt_gather_render": [P, UP], "vpt_gather_synchronize": [P], "vpt_gather_read_frame": [P, P, SZ],
     }

@@ -41,3 +41,9 @@ class Context:
         out = np.empty(n, dtype=np.float32)
         N.check(N.lib().vpt_probe_math(self._h, which, values.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), n))
         return out
+
+    def stream_read_rate(self, nbytes=4 << 30, iterations=10):
+        """measured HBM streaming-read rate in GB/s (vpt_probe_stream_read)"""
+        g = C.c_double(0)
+        N.check(N.lib().vpt_probe_stream_read(self._h, int(nbytes), int(iterations), C.byref(g)))
+        return g.value

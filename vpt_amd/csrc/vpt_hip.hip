@@ -244,9 +244,8 @@ extern "C" int vpt_volume_finalize(vpt_volume *v) {
     vpt_context *c = v->ctx;
     HIP_TRY(hipSetDevice(c->device));
     int nbx = (v->nx + 3) / 4, nby = (v->ny + 3) / 4, nbz = (v->nz + 3) / 4;
-    size_t nbricks = (size_t)nbx * nby * nbz;
-    if (nbricks > 0x7fffffffu) return fail(VPT_ERR_UNSUPPORTED, "too many bricks");
-    hipLaunchKernelGGL(k_brickify, dim3((unsigned)nbricks), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, nbx, nby);
+    if (nby > 65535 || nbz > 65535) return fail(VPT_ERR_UNSUPPORTED, "too many bricks");
+    hipLaunchKernelGGL(k_brickify, dim3((unsigned)nbx, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz);
     HIP_TRY(hipGetLastError());
     v->dirty = false;
     return VPT_OK;
@@ -499,7 +498,11 @@ static size_t lds_bytes(const vpt_renderer *r) {
     const vpt_volume *v = r->vol;
     return (size_t)r->tf_w * 2 * sizeof(float4) + (size_t)(v->nx + v->ny + v->nz) * (v->wide ? 8 : 4);
 }
+#ifdef VPT_MAP_DIAGONAL
+static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)(r->tiles_x + 7) / 8u * 8u, (unsigned)((r->local_h + VPT_TILE - 1) / VPT_TILE)); }
+#else
 static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)r->tiles_x * 8u, (unsigned)r->tiles_y / 8u); }
+#endif
 template <typename K>
 static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigned) {
     size_t lds = lds_bytes(r);
@@ -950,6 +953,40 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(din); hipFree(dout);
     if (e != hipSuccess) return fail(VPT_ERR_HIP, "probe: %s", hipGetErrorString(e));
+    return VPT_OK;
+}
+
+extern "C" int vpt_probe_stream_read(vpt_context *c, size_t nbytes, int iterations, double *gb_per_s) {
+    if (!c || !gb_per_s) return fail(VPT_ERR_INVALID, "null argument");
+    if (nbytes < (1u << 20) || iterations < 1) return fail(VPT_ERR_INVALID, "need at least 1 MiB and one iteration");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t n16 = nbytes / 16;
+    uint4 *buf = nullptr; uint32_t *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&buf, n16 * 16);
+    if (e == hipSuccess) e = hipMalloc(&sink, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(buf, 0, n16 * 16, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) {
+        dim3 grid(256 * 16);                                  // 16 workgroups per CU
+        hipLaunchKernelGGL(k_stream_read, grid, dim3(VPT_BLOCK), 0, c->stream, buf, n16, sink);    // warm-up
+        e = hipEventRecord(e0, c->stream);
+        for (int i = 0; i < iterations && e == hipSuccess; i++) {
+            hipLaunchKernelGGL(k_stream_read, grid, dim3(VPT_BLOCK), 0, c->stream, buf, n16, sink);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (buf) hipFree(buf);
+    if (sink) hipFree(sink);
+    if (e != hipSuccess) return fail(VPT_ERR_HIP, "stream probe: %s", hipGetErrorString(e));
+    *gb_per_s = (double)(n16 * 16) * iterations / ((double)ms * 1e-3) / 1e9;
     return VPT_OK;
 }
 

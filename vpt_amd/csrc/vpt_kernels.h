@@ -41,8 +41,13 @@ VPT_DEV int global_row(const PixMap &m, int l) {
 // blockIdx.y = row group; the linear workgroup id (y * gridDim.x + x) is what the dispatcher deals over the XCDs and
 // gridDim.x is a multiple of 8, so blockIdx.x & 7 labels the XCD group.
 VPT_DEV Pix map_pixel(const PixMap &m) {
+#ifdef VPT_MAP_DIAGONAL
+    int xcd = (int)blockIdx.x & 7, ty = (int)blockIdx.y;
+    int tx = ((int)blockIdx.x & ~7) + ((xcd - ty) & 7);
+#else
     int xcd = (int)blockIdx.x & 7, tx = (int)blockIdx.x >> 3;
     int ty = (int)blockIdx.y * 8 + xcd;
+#endif
     int t = ty * m.tiles_x + tx;
     int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     Pix p;
@@ -796,9 +801,9 @@ __global__ void k_blit_block(uint8_t *vol, int nx, int ny, const uint8_t *blk, i
     }
 }
 // linear volume -> apron bricks in Morton order; one 128-thread workgroup per brick
-__global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, int nbx, int nby) {
-    size_t b = blockIdx.x;
-    int bx = (int)(b % nbx); size_t r = b / nbx; int by = (int)(r % nby); int bz = (int)(r / nby);
+// (3-D grid: a 1-D grid of 2048^3's 2^27 bricks x 128 threads exceeds HIP's 2^32 work-items per dimension)
+__global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz) {
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
     int t = (int)threadIdx.x;
     uint8_t v = 0;
     if (t < 125) {
@@ -807,6 +812,23 @@ __global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *b
         v = lin[((size_t)z * ny + y) * nx + x];
     }
     bricks[((size_t)morton3((uint32_t)bx, (uint32_t)by, (uint32_t)bz) << 7) + t] = v;
+}
+
+// streaming read: every lane pulls 16 B per iteration, grid-stride; the xor keeps the loads alive
+typedef unsigned int vpt_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(VPT_BLOCK) void k_stream_read(const uint4 *src_, size_t n16, uint32_t *sink) {
+    const vpt_u32x4 *src = (const vpt_u32x4 *)src_;
+    size_t stride = (size_t)gridDim.x * VPT_BLOCK;
+    vpt_u32x4 acc = { 0u, 0u, 0u, 0u };
+    size_t i = (size_t)blockIdx.x * VPT_BLOCK + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        vpt_u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        vpt_u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc ^= a ^ b ^ c ^ d;
+    }
+    for (; i < n16; i += stride) acc ^= src[i];
+    uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (v == 0x9E3779B9u) *sink = v;                      // practically never: the buffer is zero-filled
 }
 
 // probes (tests)

@@ -4,10 +4,12 @@ import numpy as np
 VOLUME_SEED = 0x5EED0001
 
 
-def sphere_volume(n, noise=0.0, seed=VOLUME_SEED, dims=None):
-    """uint8 [z][y][x]: v = 255 * clamp(1 - |p - 1/2| / 0.45) (+ noise * smooth lattice noise), p at voxel centres."""
+def sphere_volume(n, noise=0.0, seed=VOLUME_SEED, dims=None, z_range=None):
+    """uint8 [z][y][x]: v = 255 * clamp(1 - |p - 1/2| / 0.45) (+ noise * smooth lattice noise), p at voxel centres.
+    z_range = (z0, z1) returns only that slab of slices (large volumes are generated slab by slab)."""
     nz, ny, nx = dims if dims is not None else (n, n, n)
-    out = np.empty((nz, ny, nx), dtype=np.uint8)
+    z0, z1 = z_range if z_range is not None else (0, nz)
+    out = np.empty((z1 - z0, ny, nx), dtype=np.uint8)
     x = ((np.arange(nx, dtype=np.float32) + 0.5) / nx - 0.5) ** 2
     y = ((np.arange(ny, dtype=np.float32) + 0.5) / ny - 0.5) ** 2
     lat = None
@@ -15,12 +17,12 @@ def sphere_volume(n, noise=0.0, seed=VOLUME_SEED, dims=None):
         rng = np.random.Generator(np.random.PCG64(seed))
         lat = [rng.random((c, c, c), dtype=np.float32) for c in (9, 33)]
     xy = y[:, None] + x[None, :]
-    for z in range(nz):
+    for z in range(z0, z1):
         zz = ((z + 0.5) / nz - 0.5) ** 2
         v = 255.0 * np.clip(1.0 - np.sqrt(xy + np.float32(zz)) / 0.45, 0.0, 1.0)
         if lat is not None:
             v = v + noise * (_lattice_slice(lat[0], z, nz, ny, nx) * 0.65 + _lattice_slice(lat[1], z, nz, ny, nx) * 0.35 - 0.5) * (v > 0)
-        out[z] = np.clip(np.rint(v), 0, 255).astype(np.uint8)
+        out[z - z0] = np.clip(np.rint(v), 0, 255).astype(np.uint8)
     return out
 
 
