@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames enqueued per host call (vpt_*_play); 0 = 1 (frame by frame)")
     ap.add_argument("--graph", type=int, default=1, help="replay frame sequences as a captured hipGraph (with --frames-per-launch > 1)")
+    ap.add_argument("--gather-root", type=int, default=0,
+                    help="native gather: rank that receives every frame (grouped ncclSend/ncclRecv); -1 = every rank (all_gather)")
     ap.add_argument("--gather", default="native", choices=["native", "torch"],
                     help="frame gather for N > 1: 'native' = RCCL pipeline below the C ABI (vpt_gather_*), 'torch' = torch.distributed all_gather")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
@@ -160,7 +162,7 @@ def main():
             try:
                 ids = [RcclFrameGather.unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
-                native = RcclFrameGather(r, ids[0], rank, world)
+                native = RcclFrameGather(r, ids[0], rank, world, root=args.gather_root)
             except Exception as e:                       # noqa: BLE001 - reported below
                 err = repr(e)
             flag = torch.tensor([0 if native is not None else 1], dtype=torch.int32, device=device)
@@ -200,7 +202,10 @@ def main():
             else:
                 gather.wait(0); gather.wait(1)
 
+        frames_done = [0]
+
         def run_steps(nsteps):
+            frames_done[0] += nsteps
             if fpl <= 1:
                 for k in range(nsteps):
                     step(k)
@@ -258,9 +263,23 @@ def main():
             rows_np = r.global_rows()
             valid_np = rows_np >= 0
             if native is not None:
-                frame = native.frame()                              # [H][W][4] float16 on the host
-                own = r.read(N.BUFFER_RENDER)                       # the send buffer the last frame was rendered into
-                ok = bool((frame[rows_np[valid_np]].view(np.uint16) == own[valid_np].view(np.uint16)).all())
+                if native.receives():
+                    frame = native.frame()                          # [H][W][4] float16 on the host
+                    own = r.read(N.BUFFER_RENDER)                   # the buffer the last frame was rendered into
+                    ok = bool((frame[rows_np[valid_np]].view(np.uint16) == own[valid_np].view(np.uint16)).all())
+                    ok = ok and bool(np.isfinite(frame.astype(np.float32)).all()) and bool((frame[..., 3] == 1).all())
+                    # and the whole frame, rendered again UNSHARDED on this GPU with the same per-frame draws, must be
+                    # bit-identical to what the ranks produced together (outside the timed region)
+                    o2 = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng(), 'fused': bool(args.fused)}
+                    whole = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, o2)
+                    if args.extinction is not None:
+                        whole.extinction = args.extinction
+                    whole.reset()
+                    for _ in range(frames_done[0]):
+                        whole.render()
+                    same = bool((whole.getTexture().view(np.uint16) == frame.view(np.uint16)).all())
+                    whole.destroy()
+                    ok = ok and same
             else:
                 b = (args.steps - 1) & 1
                 frame = gather.frame(b)
@@ -292,7 +311,8 @@ def main():
             "config": {"workload": "%s renderer, synthetic %d^3 u8 volume (radial sphere + lattice noise), %dx%d, "
                                    "default camera, default 2x1 transfer function, extinction %g, anisotropy 0, bounces 8, "
                                    "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
-                       "parallelism": ("image rows sharded over %d GPU(s), per-frame RCCL all_gather (%s pipeline)" % (world, args.gather)) if use_dist else "single GPU",
+                       "parallelism": ("image rows sharded over %d GPU(s), per-frame RCCL %s (%s pipeline)" % (
+                           world, ("gather to rank %d" % args.gather_root) if (native is not None and args.gather_root >= 0) else "all_gather", args.gather)) if use_dist else "single GPU",
                        "frames_per_launch": fpl, "hipgraph": bool(args.graph) and fpl > 1 and native is None,
                        "samples_per_step": samples / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

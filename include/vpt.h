@@ -174,7 +174,10 @@ VPT_API int vpt_gather_unique_id(void *id128);
 /* collective: every rank of `world` calls it with the same id; the renderer must already be sharded (rank, world) */
 VPT_API int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, int world, vpt_gather **out);
 VPT_API int vpt_gather_destroy(vpt_gather *g);
-/* render() of the renderer into the next send buffer + asynchronous all_gather of it */
+/* who receives the frames: root = -1 (default) every rank (RCCL all_gather); root = k only rank k, the display rank
+ * (grouped ncclSend/ncclRecv: 1/world of the all_gather traffic).  Collective: every rank passes the same root. */
+VPT_API int vpt_gather_set_root(vpt_gather *g, int root);
+/* render() of the renderer into the next send buffer + asynchronous gather of it */
 VPT_API int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u);
 /* `count` frames of the pipeline by one call (frame_vars as for vpt_renderer_play); always enqueued eagerly — a
  * captured graph holding RCCL collectives measured slower and unstable on this stack */

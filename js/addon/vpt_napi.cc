@@ -298,6 +298,12 @@ static napi_value GatherDestroy(napi_env env, napi_callback_info info) {
     VPT_CHECK(vpt_gather_destroy(g));
     return undefined(env);
 }
+static napi_value GatherSetRoot(napi_env env, napi_callback_info info) {
+    napi_value a[2]; vpt_gather *g; int32_t root;
+    if (!get_args(env, info, 2, a) || !get_handle(env, a[0], &g) || !get_i32(env, a[1], &root)) return nullptr;
+    VPT_CHECK(vpt_gather_set_root(g, root));
+    return undefined(env);
+}
 static napi_value GatherRender(napi_env env, napi_callback_info info) {
     napi_value a[2]; vpt_gather *g; const vpt_uniforms *u;
     if (!get_args(env, info, 2, a) || !get_handle(env, a[0], &g) || !get_uniforms(env, a[1], &u, false)) return nullptr;
@@ -343,7 +349,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("rendererSetProfiling", RendererSetProfiling); EXPORT("rendererProfile", RendererProfile);
     EXPORT("rendererSetOption", RendererSetOption); EXPORT("rendererPlay", RendererPlay);
     EXPORT("gatherUniqueId", GatherUniqueId); EXPORT("gatherCreate", GatherCreate); EXPORT("gatherDestroy", GatherDestroy);
-    EXPORT("gatherRender", GatherRender); EXPORT("gatherPlay", GatherPlay); EXPORT("gatherSynchronize", GatherSynchronize);
+    EXPORT("gatherSetRoot", GatherSetRoot); EXPORT("gatherRender", GatherRender); EXPORT("gatherPlay", GatherPlay); EXPORT("gatherSynchronize", GatherSynchronize);
     EXPORT("gatherReadFrame", GatherReadFrame);
     CONST(VPT_OPTION_MCS_PERSISTENT); CONST(VPT_OPTION_MCM_PERSISTENT);
     CONST(VPT_RENDERER_MIP); CONST(VPT_RENDERER_EAM); CONST(VPT_RENDERER_MCS); CONST(VPT_RENDERER_MCM);

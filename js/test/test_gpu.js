@@ -86,7 +86,7 @@ async function main() {
         const plain = new vpt.MCMRenderer(ctx, volume, camera, null, opts());
         const sharded = new vpt.MCMRenderer(ctx, volume, camera, null, Object.assign(opts(), { shard: { rank: 0, world: 1, rows: 8 } }));
         plain.reset(); sharded.reset();
-        const gather = new vpt.FrameGather(sharded, vpt.FrameGather.uniqueId(), 0, 1);
+        const gather = new vpt.FrameGather(sharded, vpt.FrameGather.uniqueId(), 0, 1, 0);
         for (let k = 0; k < 3; k++) { plain.render(); gather.render(); }
         gather.synchronize();
         const want = plain.getTexture(), got = gather.getFrame();

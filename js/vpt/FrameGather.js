@@ -7,9 +7,11 @@ const { native } = require('./native.js');
 
 class FrameGather {
 
-constructor(renderer, id, rank, world) {
+// root: the display rank that receives every frame (grouped send/recv), or -1 = all ranks (all_gather, the default)
+constructor(renderer, id, rank, world, root) {
     this._renderer = renderer;
     this._h = native().gatherCreate(renderer._h, id, rank, world);
+    if (root !== undefined && root !== -1) { native().gatherSetRoot(this._h, root); }
 }
 
 static uniqueId() { return native().gatherUniqueId(); }

@@ -511,13 +511,16 @@ def test_play_frame_sequences_equal_render_calls(gpu_ctx, oracle, kind):
     sc.gvol.destroy()
 
 
-def test_native_rccl_gather_play(gpu_ctx, oracle):
-    """vpt_gather_play: frame sequences (kernel + cross-stream event edges + RCCL all_gather per frame) by one call (one-rank comm)"""
+@pytest.mark.parametrize("root", [-1, 0])
+def test_native_rccl_gather_play(gpu_ctx, oracle, root):
+    """vpt_gather_play: frame sequences (kernel + cross-stream event edges + RCCL gather per frame) by one call (one-rank
+    comm); root = -1 all_gather, root = 0 gather to the display rank (which renders in place into its receive slot)"""
     from vpt_amd.tiles import RcclFrameGather
     sc = Scene(gpu_ctx, oracle, 32, 100, 70, tf=colour_tf(64, 1), camera=orbit_camera(100 / 70))
     plain = sc.renderer('mcm'); plain.extinction = 9; plain.reset()
     shard = sc.renderer('mcm', shard=(0, 1, 8)); shard.extinction = 9; shard.reset()
-    g = RcclFrameGather(shard, RcclFrameGather.unique_id(), 0, 1)
+    g = RcclFrameGather(shard, RcclFrameGather.unique_id(), 0, 1, root=root)
+    assert g.receives()
     g.render(); g.render()
     for _ in range(2):
         plain.render()

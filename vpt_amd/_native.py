@@ -31,7 +31,7 @@ SYMBOLS = [
     "vpt_renderer_set_render_target",
     "vpt_renderer_set_option", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile",
-    "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play",
+    "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play", "vpt_gather_set_root",
     "vpt_gather_synchronize",
     "vpt_gather_read_frame",
     "vpt_probe_math", "vpt_probe_sample", "vpt_probe_stream_read",
@@ -90,7 +90,7 @@ def lib():
         "vpt_renderer_reset": [P, UP], "vpt_renderer_generate": [P, UP], "vpt_renderer_integrate": [P, UP],
         "vpt_renderer_render_frame": [P, UP], "vpt_renderer_render": [P, UP],
         "vpt_renderer_read": [P, I, P, SZ], "vpt_renderer_play": [P, UP, P, I, I],
-        "vpt_gather_play": [P, UP, P, I],
+        "vpt_gather_play": [P, UP, P, I], "vpt_gather_set_root": [P, I],
         "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
         "vpt_renderer_set_render_target": [P, P, SZ],
         "vpt_renderer_set_option": [P, I, I],

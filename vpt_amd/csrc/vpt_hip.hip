@@ -310,7 +310,6 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     if (r->G == 1) r->local_h = r->H;
     r->tiles_x = (r->W + VPT_TILE - 1) / VPT_TILE;
     r->tiles_y = (r->local_h + VPT_TILE - 1) / VPT_TILE;
-    r->tiles_y = (r->tiles_y + 7) / 8 * 8;                 // map_pixel deals tile rows over the 8 XCDs
     r->ntiles = r->tiles_x * r->tiles_y;
     r->npix_padded = (size_t)r->ntiles * VPT_BLOCK;
     uint64_t valid = 0;
@@ -498,11 +497,7 @@ static size_t lds_bytes(const vpt_renderer *r) {
     const vpt_volume *v = r->vol;
     return (size_t)r->tf_w * 2 * sizeof(float4) + (size_t)(v->nx + v->ny + v->nz) * (v->wide ? 8 : 4);
 }
-#ifdef VPT_MAP_DIAGONAL
-static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)(r->tiles_x + 7) / 8u * 8u, (unsigned)((r->local_h + VPT_TILE - 1) / VPT_TILE)); }
-#else
-static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)r->tiles_x * 8u, (unsigned)r->tiles_y / 8u); }
-#endif
+static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)(r->tiles_x + 7) / 8u * 8u, (unsigned)r->tiles_y); }
 template <typename K>
 static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigned) {
     size_t lds = lds_bytes(r);
@@ -1001,6 +996,10 @@ struct Rccl {
     int (*CommInitRank)(ncclComm_t_ *, int, ncclUniqueId_, int);
     int (*CommDestroy)(ncclComm_t_);
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t_, hipStream_t);
+    int (*Send)(const void *, size_t, int, int, ncclComm_t_, hipStream_t);
+    int (*Recv)(void *, size_t, int, int, ncclComm_t_, hipStream_t);
+    int (*GroupStart)(void);
+    int (*GroupEnd)(void);
     const char *(*GetErrorString)(int);
 };
 static Rccl g_rccl = {};
@@ -1014,8 +1013,13 @@ static int rccl_load() {
     g_rccl.CommInitRank = (int (*)(ncclComm_t_ *, int, ncclUniqueId_, int))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (int (*)(ncclComm_t_))dlsym(h, "ncclCommDestroy");
     g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, ncclComm_t_, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.Send = (int (*)(const void *, size_t, int, int, ncclComm_t_, hipStream_t))dlsym(h, "ncclSend");
+    g_rccl.Recv = (int (*)(void *, size_t, int, int, ncclComm_t_, hipStream_t))dlsym(h, "ncclRecv");
+    g_rccl.GroupStart = (int (*)(void))dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)(void))dlsym(h, "ncclGroupEnd");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString ||
+        !g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
         return fail(VPT_ERR_UNSUPPORTED, "RCCL library lacks an expected symbol");
     g_rccl.handle = h;
     return VPT_OK;
@@ -1026,6 +1030,7 @@ static int rccl_load() {
 struct vpt_gather {
     vpt_renderer *r;
     int rank, world;
+    int root;                          // -1: every rank receives the frame (all_gather); else only this rank does
     ncclComm_t_ comm;
     hipStream_t comm_stream;
     size_t send_bytes;                 // W * local_h * 8
@@ -1080,7 +1085,7 @@ extern "C" int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, i
     HIP_TRY(hipSetDevice(r->ctx->device));
     vpt_gather *g = new vpt_gather();
     memset(g, 0, sizeof(*g));
-    g->r = r; g->rank = rank; g->world = world;
+    g->r = r; g->rank = rank; g->world = world; g->root = -1;
     g->send_bytes = (size_t)r->W * r->local_h * 8;
     int rc = VPT_OK;
     hipError_t e = hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking);
@@ -1137,14 +1142,31 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
     hipStream_t cs = r->ctx->stream;
     int b = (int)(g->frames & 1);
     if (g->used[b]) HIP_TRY(hipStreamWaitEvent(cs, g->gathered[b], 0));     // the gather that last read send[b] is done
-    a.render = (uint2 *)g->send[b];
+    // the receiving rank of a rooted gather renders straight into its own slot of the receive buffer
+    bool in_place = g->root == g->rank;
+    a.render = in_place ? (uint2 *)((char *)g->recv[b] + (size_t)g->rank * g->send_bytes) : (uint2 *)g->send[b];
     r->render_target = a.render;                                             // vpt_renderer_read(RENDER) returns the last frame's rows
     if (t0) HIP_TRY(hipEventRecord(t0, cs));
     VPT_TRY(launch_fused(r, a));
     if (t1) HIP_TRY(hipEventRecord(t1, cs));
     HIP_TRY(hipEventRecord(g->rendered[b], cs));
     HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[b], 0));
-    RCCL_TRY(g_rccl.AllGather(g->send[b], g->recv[b], g->send_bytes, /*ncclUint8*/ 1, g->comm, g->comm_stream));
+    if (g->root < 0) {
+        RCCL_TRY(g_rccl.AllGather(g->send[b], g->recv[b], g->send_bytes, /*ncclUint8*/ 1, g->comm, g->comm_stream));
+    } else if (g->world > 1) {
+        // gather to the display rank: its 7 peers send over 7 distinct xGMI links at once
+        RCCL_TRY(g_rccl.GroupStart());
+        int ne = 0;
+        if (in_place) {
+            for (int p = 0; p < g->world && ne == 0; p++)
+                if (p != g->rank) ne = g_rccl.Recv((char *)g->recv[b] + (size_t)p * g->send_bytes, g->send_bytes, /*ncclUint8*/ 1, p, g->comm, g->comm_stream);
+        } else {
+            ne = g_rccl.Send(g->send[b], g->send_bytes, /*ncclUint8*/ 1, g->root, g->comm, g->comm_stream);
+        }
+        int ge = g_rccl.GroupEnd();
+        if (ne != 0) return fail(VPT_ERR_HIP, "ncclSend/ncclRecv failed: %s", g_rccl.GetErrorString(ne));
+        if (ge != 0) return fail(VPT_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(ge));
+    }
     HIP_TRY(hipEventRecord(g->gathered[b], g->comm_stream));
     g->used[b] = true;
     g->frames++;
@@ -1171,6 +1193,13 @@ extern "C" int vpt_gather_play(vpt_gather *g, const vpt_uniforms *base, const fl
     if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)base->steps * (uint64_t)count;
     return VPT_OK;
 }
+extern "C" int vpt_gather_set_root(vpt_gather *g, int root) {
+    if (!g) return fail(VPT_ERR_INVALID, "gather is null");
+    if (root < -1 || root >= g->world) return fail(VPT_ERR_INVALID, "root %d outside [-1, %d)", root, g->world);
+    VPT_TRY(vpt_gather_synchronize(g));                     // frames in flight keep the mode they were enqueued with
+    g->root = root;
+    return VPT_OK;
+}
 extern "C" int vpt_gather_synchronize(vpt_gather *g) {
     if (!g) return fail(VPT_ERR_INVALID, "gather is null");
     HIP_TRY(hipSetDevice(g->r->ctx->device));
@@ -1181,6 +1210,7 @@ extern "C" int vpt_gather_synchronize(vpt_gather *g) {
 extern "C" int vpt_gather_read_frame(vpt_gather *g, void *dst, size_t nbytes) {
     if (!g || !dst) return fail(VPT_ERR_INVALID, "null argument");
     if (g->frames == 0) return fail(VPT_ERR_INVALID, "no frame has been gathered yet");
+    if (g->root >= 0 && g->root != g->rank) return fail(VPT_ERR_INVALID, "rank %d does not receive frames: the gather is rooted at rank %d", g->rank, g->root);
     vpt_renderer *r = g->r;
     size_t need = (size_t)r->W * r->H * 8;
     if (nbytes < need) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, need);

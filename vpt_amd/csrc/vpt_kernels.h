@@ -2,8 +2,8 @@
 //
 // Launch shape: one thread per pixel, 256-thread workgroups covering a 16x16 pixel
 // tile as 2x2 waves of 8x8 pixels (neighbouring rays of a wave walk the same bricks).  Workgroup ids
-// are remapped so that the blocks that share an XCD (blockIdx % 8) own a contiguous band of tiles and
-// therefore a compact sub-volume in that XCD's L2.  Per-pixel buffers (frame, accumulation, MCM photon
+// are remapped so that the blocks that share an XCD (blockIdx % 8) own the tile diagonals (tx + ty) % 8
+// (map_pixel below): equal work per XCD for any image or shard shape.  Per-pixel buffers (frame, accumulation, MCM photon
 // state) are stored in THREAD order (tile-major), so every wave access is one contiguous 64*size
 // segment; only the RGBA16F render buffer — the product handed to the caller — is row-major.
 // LDS per workgroup: the transfer function as (value, difference) pairs and the three brick-offset
@@ -24,30 +24,26 @@ struct PixMap {
     int rshift;        // log2(R) when R is a power of two, else -1
     const float *ndc_x, *ndc_y;   // pixel-centre NDC per column / global row: fl(fl((2i+1)/W) - 1), W resp. H entries
 };
-struct Pix { int i, j, l, k; bool valid; };
+struct Pix { int i, j, l, k; bool valid, tile; };   // tile: the workgroup maps to a tile of the buffers (valid or padding pixel)
 
 // Workgroup -> tile.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share an XCD's L2).
-// XCD x owns the tile rows ty with ty % 8 == x and walks each of them left to right: consecutive blocks of one XCD
-// are neighbouring tiles (shared bricks hit in that XCD's L2), while every XCD gets rows from the whole image, so
-// cube-missing and cube-crossing tiles balance (a contiguous band per XCD left the centre XCDs ~1.5x the work).
-// tiles_y is padded to a multiple of 8 by the host, so the map is a bijection on [0, ntiles).
+// XCD x owns the tiles on the diagonals (tx + ty) % 8 == x: every XCD gets tiles from the whole image (cube-missing
+// and cube-crossing tiles balance; a contiguous band per XCD left the centre XCDs ~1.5x the work) and the same number
+// of tiles from EVERY tile row, so a shard that holds only a few tile rows still fills all 8 XCDs evenly (ownership
+// by whole tile rows measured 3 % slower on the full frame and 10-14 % slower on 1/2 and 1/8 shards).
 // global row of local row l of this shard
 VPT_DEV int global_row(const PixMap &m, int l) {
     if (m.G == 1) return l;
     int lb = (m.rshift >= 0) ? (l >> m.rshift) : (l / m.R);
     return (lb * m.G + m.g) * m.R + (l - lb * m.R);
 }
-// The grid is 2-D so that no integer division is needed: gridDim.x = 8 * tiles_x, blockIdx.x = tx * 8 + xcd,
-// blockIdx.y = row group; the linear workgroup id (y * gridDim.x + x) is what the dispatcher deals over the XCDs and
-// gridDim.x is a multiple of 8, so blockIdx.x & 7 labels the XCD group.
+// The grid is 2-D so that no integer division is needed: gridDim.x = tiles_x rounded up to a multiple of 8,
+// blockIdx.y = tile row; the linear workgroup id (y * gridDim.x + x) is what the dispatcher deals over the XCDs and
+// gridDim.x is a multiple of 8, so blockIdx.x & 7 labels the XCD.  Within a group of 8 adjacent tiles of a row the
+// tile of XCD x is the one with (tx + ty) % 8 == x; groups past tiles_x fail the p.i < W test.
 VPT_DEV Pix map_pixel(const PixMap &m) {
-#ifdef VPT_MAP_DIAGONAL
     int xcd = (int)blockIdx.x & 7, ty = (int)blockIdx.y;
     int tx = ((int)blockIdx.x & ~7) + ((xcd - ty) & 7);
-#else
-    int xcd = (int)blockIdx.x & 7, tx = (int)blockIdx.x >> 3;
-    int ty = (int)blockIdx.y * 8 + xcd;
-#endif
     int t = ty * m.tiles_x + tx;
     int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     Pix p;
@@ -56,6 +52,7 @@ VPT_DEV Pix map_pixel(const PixMap &m) {
     p.k = t * VPT_BLOCK + (int)threadIdx.x;
     p.j = global_row(m, p.l);
     p.valid = (p.i < m.W) && (p.l < m.local_h) && (p.j < m.H);
+    p.tile = tx < m.tiles_x;
     return p;
 }
 // pixel-centre NDC from the host-built tables (the IEEE divisions (2i+1)/W are done once per image size, not per pixel)
@@ -225,7 +222,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mip_render(PassArgs a) {
 }
 __global__ void __launch_bounds__(VPT_BLOCK) k_mip_reset(PassArgs a) {   // MIPRenderer.glsl:168-170
     Pix p = map_pixel(a.pm);
-    ((uint8_t *)a.acc)[p.k] = 0;
+    if (p.tile) ((uint8_t *)a.acc)[p.k] = 0;
 }
 
 // =============================================================================================
@@ -322,7 +319,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_eam_render(PassArgs a) {
 }
 __global__ void __launch_bounds__(VPT_BLOCK) k_eam_reset(PassArgs a) {   // EAMRenderer.glsl:177-179
     Pix p = map_pixel(a.pm);
-    ((uint32_t *)a.acc)[p.k] = 0xff000000u;
+    if (p.tile) ((uint32_t *)a.acc)[p.k] = 0xff000000u;
 }
 
 // =============================================================================================
@@ -576,7 +573,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs_render(PassArgs a) {   // MCS
 }
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcs_reset(PassArgs a) {    // MCSRenderer.glsl:238-240
     Pix p = map_pixel(a.pm);
-    ((float4 *)a.acc)[p.k] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (p.tile) ((float4 *)a.acc)[p.k] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
 }
 
 // =============================================================================================
@@ -644,6 +641,7 @@ VPT_DEV void photon_deposit(Photon &ph, f3 rad) {
 // reset/fragment main(): MCMRenderer.glsl:259-275 (seeded from the NDC position)
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
     Pix p = map_pixel(a.pm);
+    if (!p.tile) return;
     Photon ph;
     if (p.valid) {
         float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);

@@ -82,7 +82,8 @@ class RcclFrameGather:
     128-byte RCCL id obtained by ONE rank (``RcclFrameGather.unique_id()``) and shared with the others, e.g. through
     ``torch.distributed.broadcast_object_list``."""
 
-    def __init__(self, renderer, id_bytes, rank, world):
+    def __init__(self, renderer, id_bytes, rank, world, root=-1):
+        """root = -1: every rank receives each frame (all_gather); root = k: only rank k does (grouped send/recv)"""
         import ctypes as C
         from . import _native as N
         self._N, self._C = N, C
@@ -92,6 +93,16 @@ class RcclFrameGather:
         buf = C.create_string_buffer(bytes(id_bytes), 128)
         N.check(N.lib().vpt_gather_create(renderer._h, buf, rank, world, C.byref(h)))
         self._h = h
+        self.root = -1
+        if root != -1:
+            self.set_root(root)
+
+    def set_root(self, root):
+        self._N.check(self._N.lib().vpt_gather_set_root(self._h, int(root)))
+        self.root = int(root)
+
+    def receives(self):
+        return self.root < 0 or self.root == self.rank
 
     @staticmethod
     def unique_id():
