@@ -164,6 +164,43 @@ VPT_API int vpt_renderer_clear_sample_count(vpt_renderer *r);
 VPT_API int vpt_renderer_set_profiling(vpt_renderer *r, int enabled);
 VPT_API int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t *launches);
 
+/* ---- tone mappers (the classes of src/js/tonemappers/ and the shaders of src/glsl/tonemappers/).  One per-pixel pass:
+ * RGBA16F render buffer of a renderer (AbstractToneMapper.setTexture, AbstractToneMapper.js:34-36) -> RGBA8
+ * (AbstractToneMapper.js:66-79).  Source and target have the same resolution, as RenderingContext.js:184-187,223-227
+ * keeps them, so the source is read texel for texel; a sharded renderer's source is its local rows. */
+#define VPT_TONEMAPPER_ARTISTIC   0   /* ToneMapperFactory.js:13-24, in its order */
+#define VPT_TONEMAPPER_RANGE      1
+#define VPT_TONEMAPPER_REINHARD   2
+#define VPT_TONEMAPPER_REINHARD2  3
+#define VPT_TONEMAPPER_UNCHARTED2 4
+#define VPT_TONEMAPPER_FILMIC     5
+#define VPT_TONEMAPPER_UNREAL     6
+#define VPT_TONEMAPPER_ACES       7
+#define VPT_TONEMAPPER_LOTTES     8
+#define VPT_TONEMAPPER_UCHIMURA   9
+/* the gl.uniform1f values of the _renderFrame() hooks; a mapper reads only its own fields */
+struct vpt_tonemap_params {
+    float low, mid, high, saturation;   /* Artistic: ArtisticToneMapper.js:75-79 (defaults 0, 0.5, 1, 1) */
+    float min, max;                     /* Range: RangeToneMapper.js:58-59 (0, 1) */
+    float exposure;                     /* Reinhard ... Uchimura: ReinhardToneMapper.js:53 (1) */
+    float gamma;                        /* all (2.2) */
+};
+typedef struct vpt_tonemapper vpt_tonemapper;
+VPT_API int vpt_tonemapper_create(vpt_context *ctx, int kind, int width, int height, vpt_tonemapper **out);
+VPT_API int vpt_tonemapper_destroy(vpt_tonemapper *t);
+VPT_API int vpt_tonemapper_resize(vpt_tonemapper *t, int width, int height);           /* setResolution, :57-62 */
+/* setTexture: the source is the renderer's render buffer (read at render time; NULL = the 1x1 white texture of
+ * RenderingContext.js:176-181, i.e. every texel (1,1,1,1)) */
+VPT_API int vpt_tonemapper_set_source(vpt_tonemapper *t, vpt_renderer *r);
+/* setTexture with an image: [rows][width] RGBA16F copied from the host into a texture owned by the tone mapper */
+VPT_API int vpt_tonemapper_set_source_image(vpt_tonemapper *t, const void *rgba16f, int width, int rows);
+/* render(): one pass into the RGBA8 target */
+VPT_API int vpt_tonemapper_render(vpt_tonemapper *t, const struct vpt_tonemap_params *p);
+/* getTexture(): [rows][width] RGBA8 -> host (blocks); rows = the source's rows (the resolution's height when unsharded) */
+VPT_API int vpt_tonemapper_read(vpt_tonemapper *t, void *dst, size_t nbytes);
+VPT_API int vpt_tonemapper_rows(vpt_tonemapper *t, int *rows);
+VPT_API int vpt_tonemapper_output_device(vpt_tonemapper *t, void **ptr, size_t *nbytes);
+
 /* ---- multi-GPU frame gather (no reference counterpart).  One process per GPU; the image plane is sharded
  * with vpt_renderer_set_shard and every frame is all-gathered over RCCL/xGMI.  The pipeline lives below the C ABI so
  * that a frame costs the host two enqueues: kernel k+1 (context stream) overlaps the all_gather of frame k (own
@@ -203,6 +240,8 @@ VPT_API int vpt_gather_read_frame(vpt_gather *g, void *host_dst, size_t nbytes);
 #define VPT_PROBE_LOG_UNIFORM 12  /* log on the range of random_uniform */
 #define VPT_PROBE_RCPZ    13  /* rcp_nrz: reciprocal with 1/(+-0) = +-inf */
 #define VPT_PROBE_SQRT    14  /* sqrt_nr = x * rsqrt_nr(x) */
+#define VPT_PROBE_EXP     15  /* the tone mappers' exp */
+#define VPT_PROBE_POW     16  /* in = pairs (x, y): exp(y * log(x)) ; n outputs */
 VPT_API int vpt_probe_math(vpt_context *ctx, int which, const float *in, float *out, size_t n);
 /* samples texture(uVolume, p) -> transfer function at n positions (xyz triples); out = n RGBA float4 */
 VPT_API int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n);

@@ -14,8 +14,8 @@ _LIB_PATH = os.path.join(_HERE, "libvpt_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "vpt_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, n) for n in ("vpt_oracle.c", "vpt_tonemap_oracle.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libvpt_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -40,6 +40,34 @@ class Frame(C.Structure):
         ("mix", C.c_float), ("blur", C.c_float), ("inv_res", C.c_float * 2),
         ("nthreads", C.c_int32),
     ]
+
+
+class TonemapParams(C.Structure):
+    """parameters of the ten tone mappers (oracle/vpt_tonemap_oracle.c); defaults = the reference's property defaults"""
+    _fields_ = [("low", C.c_float), ("mid", C.c_float), ("high", C.c_float), ("saturation", C.c_float),
+                ("min", C.c_float), ("max", C.c_float), ("exposure", C.c_float), ("gamma", C.c_float)]
+
+
+TONEMAPPERS = ("artistic", "range", "reinhard", "reinhard2", "uncharted2", "filmic", "unreal", "aces", "lottes", "uchimura")
+
+
+def tonemap_params(**kw):
+    p = TonemapParams(low=0.0, mid=0.5, high=1.0, saturation=1.0, min=0.0, max=1.0, exposure=1.0, gamma=2.2)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, float(np.float32(v)))
+    return p
+
+
+def tonemap(kind, rgba16f, **params):
+    """kind: name from TONEMAPPERS; rgba16f: [...][4] float16 -> [...][4] uint8"""
+    src = np.ascontiguousarray(rgba16f, dtype=np.float16)
+    out = np.empty(src.shape, dtype=np.uint8)
+    p = tonemap_params(**params)
+    rc = lib().vpo_tonemap(TONEMAPPERS.index(kind), C.byref(p), _ptr(src), _ptr(out), src.size // 4)
+    assert rc == 0
+    return out
 
 
 _lib = None
@@ -82,6 +110,10 @@ def lib():
         L.vpo_unproject.restype = None; L.vpo_unproject.argtypes = [P, C.c_float, C.c_float, P, P]
         L.vpo_intersect_cube.restype = None; L.vpo_intersect_cube.argtypes = [P, P, P]
         L.vpo_max_threads.restype = C.c_int
+        L.vpo_expf.restype = C.c_float; L.vpo_expf.argtypes = [C.c_float]
+        L.vpo_powf.restype = C.c_float; L.vpo_powf.argtypes = [C.c_float, C.c_float]
+        L.vpo_f16_to_f32.restype = C.c_float; L.vpo_f16_to_f32.argtypes = [C.c_uint16]
+        L.vpo_tonemap.restype = C.c_int; L.vpo_tonemap.argtypes = [C.c_int, C.POINTER(TonemapParams), P, P, C.c_size_t]
         _lib = L
     return _lib
 

@@ -1,0 +1,181 @@
+"""GPU: the ten tone mappers (vpt_tonemapper_* through the C-ABI) against the CPU oracle, bit for bit, and against the
+committed golden fixture (no oracle).  SURVEY.md section 8f row 1."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import vpt_amd
+from vpt_amd import _native as N
+from vpt_amd.scene import Transform, Node, default_camera
+from vpt_amd.synthetic import sphere_volume, colour_tf, GoldenRatioRng
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KINDS = ['artistic', 'range', 'reinhard', 'reinhard2', 'uncharted2', 'filmic', 'unreal', 'aces', 'lottes', 'uchimura']
+
+
+def same(got, want, what):
+    g, w = np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)
+    assert g.shape == w.shape, what
+    bad = np.nonzero(g != w)[0]
+    assert bad.size == 0, "%s: %d of %d bytes differ, first at %d: got %r want %r" % (what, bad.size, g.size, bad[0], g[bad[0]], w[bad[0]])
+
+
+def test_exp_pow_probes_bit_exact(gpu_ctx, oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.linspace(-110, 95, 40001), rng.uniform(-3, 3, 20000),
+                        [0.0, -0.0, np.inf, -np.inf, np.nan, 89.0, 89.00001, -104.0, -104.00001, -87.4, -100.0, 88.7]]).astype(np.float32)
+    got = gpu_ctx.probe_math(N.PROBE_EXP, x)
+    want = np.array([L.vpo_expf(float(v)) for v in x], dtype=np.float32)
+    assert (got.view(np.uint32)[~np.isnan(want)] == want.view(np.uint32)[~np.isnan(want)]).all()
+    assert np.isnan(got[np.isnan(want)]).all()
+    base = np.concatenate([rng.uniform(0, 70, 30000), rng.uniform(0, 1, 10000) ** 4,
+                           [0.0, -0.0, 1.0, -1.0, np.inf, np.nan, 6e-8, 65504.0, 1e-30, 1e30]]).astype(np.float32)
+    expo = np.concatenate([rng.uniform(0.05, 3.0, 40000), [0.4545, 2.2, 0.0, 1.0, 0.5, 1.0, 0.4545, 2.2, 1.6, 1.33]]).astype(np.float32)
+    pairs = np.stack([base, expo], -1).reshape(-1)
+    got = gpu_ctx.probe_math(N.PROBE_POW, pairs)
+    want = np.array([L.vpo_powf(float(a), float(b)) for a, b in zip(base, expo)], dtype=np.float32)
+    nan = np.isnan(want)
+    assert np.isnan(got[nan]).all()
+    assert (got.view(np.uint32)[~nan] == want.view(np.uint32)[~nan]).all()
+
+
+def hdr_image(w, h, seed=3):
+    rng = np.random.default_rng(seed)
+    img = np.ones((h, w, 4), dtype=np.float32)
+    img[..., :3] = rng.uniform(0, 5.0, size=(h, w, 3)) ** 3 / 12.0
+    img[..., 3] = np.where(rng.uniform(size=(h, w)) < 0.9, 1.0, rng.uniform(0, 2, size=(h, w)))
+    flat = img.reshape(-1, 4)
+    specials = np.array([0.0, -0.0, -0.5, np.inf, -np.inf, np.nan, 6e-8, 6.1e-5, 65504.0, 0.004, 0.22, 0.532, 0.62, 1.0], dtype=np.float32)
+    idx = rng.choice(flat.shape[0], size=3 * specials.size, replace=False)
+    for n, i in enumerate(idx):
+        flat[i, n % 3] = specials[n // 3]
+    return img.astype(np.float16)
+
+
+PARAMS = {
+    'artistic': [{}, {'low': 0.1, 'mid': 0.3, 'high': 2.5, 'saturation': 0.4, 'gamma': 1.8}, {'low': 1.0, 'high': 1.0}],
+    'range': [{}, {'min': -0.5, 'max': 3.0, 'gamma': 1.0}, {'gamma': 0.0}],
+}
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_tonemapper_image_parity(gpu_ctx, oracle, kind):
+    """every mapper on an HDR image with zeros, negatives, inf, NaN and subnormal halfs: bit-identical to the oracle"""
+    w, h = 150, 70
+    img = hdr_image(w, h)
+    T = vpt_amd.ToneMapperFactory(kind)
+    tm = T(gpu_ctx, img, {'resolution': (w, h)})
+    for params in PARAMS.get(kind, [{}, {'exposure': 2.5, 'gamma': 1.7}, {'exposure': 0.0, 'gamma': 2.2}]):
+        for k, v in params.items():
+            setattr(tm, k, v)
+        tm.render()
+        got = tm.getTexture()
+        assert got.shape == (h, w, 4) and got.dtype == np.uint8
+        full = {p['name']: getattr(tm, p['name']) for p in tm.properties}
+        same(got, oracle.tonemap(kind, img, **full), "%s %r" % (kind, params))
+    tm.destroy()
+
+
+def test_golden_fixture_without_oracle(gpu_ctx):
+    fx = json.load(open(os.path.join(HERE, "golden", "tonemap_r01.json")))
+    src = np.array(fx["source_rgba16f_bits"], dtype=np.uint16).view(np.float16).reshape(1, -1, 4)
+    for case in fx["cases"]:
+        tm = vpt_amd.ToneMapperFactory(case["kind"])(gpu_ctx, src, {'resolution': (src.shape[1], 1)})
+        for k, v in case["params"].items():
+            setattr(tm, k, v)
+        tm.render()
+        same(tm.getTexture(), np.array(case["rgba8"], dtype=np.uint8), "fixture %s %r" % (case["kind"], case["params"]))
+        tm.destroy()
+
+
+def test_properties_mirror_the_reference(gpu_ctx):
+    a = vpt_amd.ArtisticToneMapper(gpu_ctx, None, {'resolution': 8})
+    assert [(p['name'], p['value']) for p in a.properties] == [('low', 0), ('high', 1), ('mid', 0.5), ('saturation', 1), ('gamma', 2.2)]   # ArtisticToneMapper.js:15-49
+    assert a.properties[2]['min'] == 0.00001 and a.properties[2]['max'] == 0.99999 and a.properties[2]['type'] == 'slider'
+    r = vpt_amd.RangeToneMapper(gpu_ctx, None, {'resolution': 8})
+    assert [(p['name'], p['value']) for p in r.properties] == [('min', 0), ('max', 1), ('gamma', 2.2)]                                     # RangeToneMapper.js:14-34
+    for kind in KINDS[2:]:
+        t = vpt_amd.ToneMapperFactory(kind)(gpu_ctx, None)
+        assert [(p['name'], p['value'], p.get('min')) for p in t.properties] == [('exposure', 1, 0), ('gamma', 2.2, 0)]                    # ReinhardToneMapper.js:14-29
+        assert t._size() == (512, 512)                                                                                                    # AbstractToneMapper.js:15
+        t.destroy()
+    # the placeholder texture of RenderingContext.js:176-181 (1x1 white): every texel maps white
+    a.render()
+    out = a.getTexture()
+    assert out.shape == (8, 8, 4) and (out == 255).all()
+    a.destroy(); r.destroy()
+
+
+@pytest.mark.parametrize("rkind,tkind", [("mcm", "artistic"), ("mcs", "reinhard"), ("eam", "range"), ("mip", "aces")])
+def test_renderer_to_tonemapper_chain(gpu_ctx, oracle, rkind, tkind):
+    """RenderingContext.render(): renderer.render(); toneMapper.render() — the tone mapper reads the render buffer in HBM"""
+    w, h = 112, 80
+    vol = sphere_volume(32, noise=40.0)
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, 'linear')
+    cam = default_camera(w / h)
+    r = vpt_amd.RendererFactory(rkind)(gpu_ctx, gvol, cam, None, {'resolution': (w, h), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+    r.setTransferFunction(colour_tf(64, 1))
+    if rkind in ('mcs', 'mcm'):
+        r.extinction = 8
+    r.reset()
+    tm = vpt_amd.ToneMapperFactory(tkind)(gpu_ctx, r, {'resolution': (w, h)})     # chooseToneMapper: texture = renderer.getTexture()
+    for _ in range(3):
+        r.render(); tm.render()
+    same(tm.getTexture(), oracle.tonemap(tkind, r.getTexture(), **{p['name']: p['value'] for p in tm.properties}), "%s -> %s" % (rkind, tkind))
+    # setResolution on both, as RenderingContext.js:219-228 does
+    r.setResolution((64, 48)); tm.setResolution((64, 48)); tm.setTexture(r)
+    r.render(); tm.render()
+    assert tm.getTexture().shape == (48, 64, 4)
+    same(tm.getTexture(), oracle.tonemap(tkind, r.getTexture()), "after setResolution")
+    # a mismatch is refused loudly rather than resampled
+    tm.setResolution((32, 32))
+    with pytest.raises(vpt_amd.VptError, match="resampling"):
+        tm.render()
+    tm.destroy(); r.destroy(); gvol.destroy()
+
+
+def test_sharded_source_rows(gpu_ctx, oracle):
+    """a sharded renderer's tone mapper maps the local rows; together the ranks' rows are the unsharded image"""
+    w, h = 96, 72
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, sphere_volume(24, noise=30.0), 'linear')
+    cam = default_camera(w / h)
+
+    def run(**opts):
+        o = {'resolution': (w, h), 'transform': Transform(Node()), 'rng': GoldenRatioRng()}
+        o.update(opts)
+        r = vpt_amd.MCMRenderer(gpu_ctx, gvol, cam, None, o)
+        r.extinction = 6
+        r.reset()
+        tm = vpt_amd.Reinhard2ToneMapper(gpu_ctx, r, {'resolution': (w, h)})
+        for _ in range(2):
+            r.render()
+        tm.render()
+        out = (tm.getTexture(), r.global_rows())
+        tm.destroy(); r.destroy()
+        return out
+
+    whole, _ = run()
+    got = np.zeros_like(whole)
+    for rank in range(3):
+        img, rows = run(shard=(rank, 3, 8))
+        got[rows[rows >= 0]] = img[rows >= 0]
+    same(got, whole, "3-way sharded tone map")
+    gvol.destroy()
+
+
+def test_full_size_tonemap(gpu_ctx, oracle):
+    """1920x1080: every mapper over a full frame equals the oracle on a band of rows; alpha stays 255"""
+    w, h = 1920, 1080
+    img = hdr_image(w, h, seed=9)
+    for kind in KINDS:
+        tm = vpt_amd.ToneMapperFactory(kind)(gpu_ctx, img, {'resolution': (w, h)})
+        tm.render()
+        out = tm.getTexture()
+        same(out[500:516], oracle.tonemap(kind, img[500:516]), "%s rows 500..516" % kind)
+        if kind != 'range':
+            assert (out[..., 3] == 255).all()
+        tm.destroy()

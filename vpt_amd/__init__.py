@@ -8,10 +8,16 @@ from .scene import Node, Transform, PerspectiveCamera, mat4, quat, vec3, default
 from .context import Context
 from .volume import Volume, RAWReader
 from .renderers import (AbstractRenderer, MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer, RendererFactory)
+from .tonemappers import (AbstractToneMapper, ArtisticToneMapper, RangeToneMapper, ReinhardToneMapper, Reinhard2ToneMapper,
+                          Uncharted2ToneMapper, FilmicToneMapper, UnrealToneMapper, AcesToneMapper, LottesToneMapper,
+                          UchimuraToneMapper, ToneMapperFactory)
 from ._native import VptError
 
 __all__ = [
     'PropertyBag', 'EventTarget', 'Event', 'CustomEvent', 'Node', 'Transform', 'PerspectiveCamera',
     'mat4', 'quat', 'vec3', 'default_camera', 'mvp_inverse_matrix', 'Context', 'Volume', 'RAWReader',
     'AbstractRenderer', 'MIPRenderer', 'EAMRenderer', 'MCSRenderer', 'MCMRenderer', 'RendererFactory', 'VptError',
+    'AbstractToneMapper', 'ArtisticToneMapper', 'RangeToneMapper', 'ReinhardToneMapper', 'Reinhard2ToneMapper',
+    'Uncharted2ToneMapper', 'FilmicToneMapper', 'UnrealToneMapper', 'AcesToneMapper', 'LottesToneMapper',
+    'UchimuraToneMapper', 'ToneMapperFactory',
 ]

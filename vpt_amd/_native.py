@@ -15,7 +15,9 @@ FORMAT_R8 = 0
 BUFFER_RENDER, BUFFER_FRAME, BUFFER_ACCUM = 0, 1, 2
 BUFFER_MCM_POSITION, BUFFER_MCM_DIRECTION, BUFFER_MCM_TRANSMITTANCE, BUFFER_MCM_RADIANCE = 3, 4, 5, 6
 (PROBE_LOG, PROBE_SIN, PROBE_COS, PROBE_ASIN, PROBE_ATAN2, PROBE_PCG, PROBE_UNIFORM, PROBE_F16,
- PROBE_RCP, PROBE_RSQRT, PROBE_MIN, PROBE_MAX, PROBE_LOG_UNIFORM, PROBE_RCPZ, PROBE_SQRT) = range(15)
+ PROBE_RCP, PROBE_RSQRT, PROBE_MIN, PROBE_MAX, PROBE_LOG_UNIFORM, PROBE_RCPZ, PROBE_SQRT, PROBE_EXP, PROBE_POW) = range(17)
+(TONEMAPPER_ARTISTIC, TONEMAPPER_RANGE, TONEMAPPER_REINHARD, TONEMAPPER_REINHARD2, TONEMAPPER_UNCHARTED2, TONEMAPPER_FILMIC,
+ TONEMAPPER_UNREAL, TONEMAPPER_ACES, TONEMAPPER_LOTTES, TONEMAPPER_UCHIMURA) = range(10)
 
 # every symbol include/vpt.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -35,6 +37,9 @@ SYMBOLS = [
     "vpt_gather_synchronize",
     "vpt_gather_read_frame",
     "vpt_probe_math", "vpt_probe_sample", "vpt_probe_stream_read",
+    "vpt_tonemapper_create", "vpt_tonemapper_destroy", "vpt_tonemapper_resize", "vpt_tonemapper_set_source",
+    "vpt_tonemapper_set_source_image", "vpt_tonemapper_render", "vpt_tonemapper_read", "vpt_tonemapper_rows",
+    "vpt_tonemapper_output_device",
 ]
 
 
@@ -48,6 +53,12 @@ class Uniforms(C.Structure):
         ("light_direction", C.c_float * 3),
         ("mix", C.c_float), ("blur", C.c_float),
     ]
+
+
+class TonemapParams(C.Structure):
+    """struct vpt_tonemap_params (include/vpt.h)"""
+    _fields_ = [("low", C.c_float), ("mid", C.c_float), ("high", C.c_float), ("saturation", C.c_float),
+                ("min", C.c_float), ("max", C.c_float), ("exposure", C.c_float), ("gamma", C.c_float)]
 
 
 class VptError(RuntimeError):
@@ -98,6 +109,10 @@ def lib():
         "vpt_renderer_set_profiling": [P, I],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],
         "vpt_probe_math": [P, I, P, P, SZ], "vpt_probe_sample": [P, P, P, SZ], "vpt_probe_stream_read": [P, SZ, I, P],
+        "vpt_tonemapper_create": [P, I, I, I, P], "vpt_tonemapper_destroy": [P], "vpt_tonemapper_resize": [P, I, I],
+        "vpt_tonemapper_set_source": [P, P], "vpt_tonemapper_set_source_image": [P, P, I, I],
+        "vpt_tonemapper_render": [P, C.POINTER(TonemapParams)], "vpt_tonemapper_read": [P, P, SZ],
+        "vpt_tonemapper_rows": [P, P], "vpt_tonemapper_output_device": [P, P, P],
         "vpt_gather_unique_id": [P], "vpt_gather_create": [P, P, I, I, PP], "vpt_gather_destroy": [P],
         "vpt_gather_render": [P, UP], "vpt_gather_synchronize": [P], "vpt_gather_read_frame": [P, P, SZ],
     }

@@ -37,7 +37,7 @@ class Context:
     def probe_math(self, which, values):
         import numpy as np
         values = np.ascontiguousarray(values, dtype=np.float32)
-        n = values.size // 2 if which in (N.PROBE_ATAN2, N.PROBE_MIN, N.PROBE_MAX) else values.size
+        n = values.size // 2 if which in (N.PROBE_ATAN2, N.PROBE_MIN, N.PROBE_MAX, N.PROBE_POW) else values.size
         out = np.empty(n, dtype=np.float32)
         N.check(N.lib().vpt_probe_math(self._h, which, values.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), n))
         return out

@@ -902,10 +902,10 @@ extern "C" int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t 
 // ---------------------------------------------------------------------------------------------
 extern "C" int vpt_probe_math(vpt_context *c, int which, const float *in, float *out, size_t n) {
     if (!c || !in || !out) return fail(VPT_ERR_INVALID, "null argument");
-    if (which < 0 || which > VPT_PROBE_SQRT) return fail(VPT_ERR_INVALID, "unknown probe %d", which);
+    if (which < 0 || which > VPT_PROBE_POW) return fail(VPT_ERR_INVALID, "unknown probe %d", which);
     if (n == 0) return VPT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    size_t nin = (which == VPT_PROBE_ATAN2 || which == VPT_PROBE_MIN || which == VPT_PROBE_MAX) ? 2 * n : n;
+    size_t nin = (which == VPT_PROBE_ATAN2 || which == VPT_PROBE_MIN || which == VPT_PROBE_MAX || which == VPT_PROBE_POW) ? 2 * n : n;
     float *din = nullptr, *dout = nullptr;
     HIP_TRY(hipMalloc(&din, nin * sizeof(float)));
     hipError_t e = hipMalloc(&dout, n * sizeof(float));
@@ -948,6 +948,144 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(din); hipFree(dout);
     if (e != hipSuccess) return fail(VPT_ERR_HIP, "probe: %s", hipGetErrorString(e));
+    return VPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tone mappers
+// ---------------------------------------------------------------------------------------------
+struct vpt_tonemapper {
+    vpt_context *ctx;
+    int kind, W, H;
+    vpt_renderer *source;          // bound renderer (not owned), or null
+    uint2 *image; int image_w, image_rows;    // owned source texture (set_source_image), or null
+    uint32_t *out; size_t out_pixels;         // RGBA8 target, grown on demand
+    int rows;                      // rows of the last render
+};
+extern "C" int vpt_tonemapper_create(vpt_context *c, int kind, int width, int height, vpt_tonemapper **out) {
+    if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
+    if (kind < VPT_TONEMAPPER_ARTISTIC || kind > VPT_TONEMAPPER_UCHIMURA) return fail(VPT_ERR_INVALID, "No suitable class");   // ToneMapperFactory.js:26
+    if (width < 1 || height < 1) return fail(VPT_ERR_INVALID, "bad resolution %dx%d", width, height);
+    vpt_tonemapper *t = new vpt_tonemapper();
+    memset(t, 0, sizeof(*t));
+    t->ctx = c; t->kind = kind; t->W = width; t->H = height;
+    *out = t;
+    return VPT_OK;
+}
+extern "C" int vpt_tonemapper_destroy(vpt_tonemapper *t) {
+    if (!t) return VPT_OK;
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    if (t->image) hipFree(t->image);
+    if (t->out) hipFree(t->out);
+    delete t;
+    return VPT_OK;
+}
+extern "C" int vpt_tonemapper_resize(vpt_tonemapper *t, int width, int height) {
+    if (!t) return fail(VPT_ERR_INVALID, "tone mapper is null");
+    if (width < 1 || height < 1) return fail(VPT_ERR_INVALID, "bad resolution %dx%d", width, height);
+    t->W = width; t->H = height; t->rows = 0;
+    return VPT_OK;
+}
+extern "C" int vpt_tonemapper_set_source(vpt_tonemapper *t, vpt_renderer *r) {
+    if (!t) return fail(VPT_ERR_INVALID, "tone mapper is null");
+    if (r && r->ctx->device != t->ctx->device) return fail(VPT_ERR_INVALID, "renderer and tone mapper live on different devices");
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    if (t->image) { HIP_TRY(hipStreamSynchronize(t->ctx->stream)); HIP_TRY(hipFree(t->image)); t->image = nullptr; }
+    t->source = r;
+    return VPT_OK;
+}
+extern "C" int vpt_tonemapper_set_source_image(vpt_tonemapper *t, const void *rgba16f, int width, int rows) {
+    if (!t || !rgba16f) return fail(VPT_ERR_INVALID, "null argument");
+    if (width < 1 || rows < 1) return fail(VPT_ERR_INVALID, "bad image size %dx%d", width, rows);
+    vpt_context *c = t->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (t->image) { HIP_TRY(hipFree(t->image)); t->image = nullptr; }
+    size_t bytes = (size_t)width * rows * 8;
+    HIP_TRY(hipMalloc(&t->image, bytes));
+    HIP_TRY(hipMemcpyAsync(t->image, rgba16f, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    t->image_w = width; t->image_rows = rows; t->source = nullptr;
+    return VPT_OK;
+}
+template <int KIND>
+static void launch_tonemap(vpt_tonemapper *t, const uint2 *src, size_t n, const TonemapParams &p) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;                 // grid-stride beyond 32 workgroups per CU
+    hipLaunchKernelGGL(k_tonemap<KIND>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, p);
+}
+__global__ void k_fill_u32(uint32_t *dst, size_t n, uint32_t v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+extern "C" int vpt_tonemapper_render(vpt_tonemapper *t, const struct vpt_tonemap_params *params) {
+    if (!t || !params) return fail(VPT_ERR_INVALID, "null argument");
+    vpt_context *c = t->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    static_assert(sizeof(TonemapParams) == sizeof(vpt_tonemap_params), "parameter block layout");
+    TonemapParams p; memcpy(&p, params, sizeof(p));
+    const uint2 *src = nullptr; int w = t->W, rows = t->H;
+    uint2 *white = nullptr;
+    if (t->source) {
+        vpt_renderer *r = t->source;
+        src = r->render_target ? r->render_target : r->render; w = r->W; rows = r->local_h;
+        if (r->ctx->stream != c->stream) HIP_TRY(hipStreamSynchronize(r->ctx->stream));      // different contexts: order by waiting
+    } else if (t->image) {
+        src = t->image; w = t->image_w; rows = t->image_rows;
+    }
+    if (w != t->W || (!t->source && rows != t->H) || (t->source && t->source->H != t->H))
+        return fail(VPT_ERR_UNSUPPORTED, "source is %dx%d, tone mapper %dx%d: resampling between resolutions is not implemented "
+                                         "(the reference keeps them equal, RenderingContext.js:219-228)", w, t->source ? t->source->H : rows, t->W, t->H);
+    size_t n = (size_t)w * rows;
+    if (t->out_pixels < n) {
+        if (t->out) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(t->out)); t->out = nullptr; t->out_pixels = 0; }
+        HIP_TRY(hipMalloc(&t->out, n * 4));
+        t->out_pixels = n;
+    }
+    if (!src) {                                               // the 1x1 white placeholder texture: a constant image
+        HIP_TRY(hipMalloc(&white, n * 8));
+        uint64_t one4 = 0x3c003c003c003c00ull;                // half(1) x 4
+        static_assert(sizeof(uint2) == 8, "texel size");
+        hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, c->stream, (uint32_t *)white, n * 2, (uint32_t)(one4 & 0xffffffffu));
+        src = white;
+    }
+    switch (t->kind) {
+        case VPT_TONEMAPPER_ARTISTIC:   launch_tonemap<VPT_TM_ARTISTIC>(t, src, n, p); break;
+        case VPT_TONEMAPPER_RANGE:      launch_tonemap<VPT_TM_RANGE>(t, src, n, p); break;
+        case VPT_TONEMAPPER_REINHARD:   launch_tonemap<VPT_TM_REINHARD>(t, src, n, p); break;
+        case VPT_TONEMAPPER_REINHARD2:  launch_tonemap<VPT_TM_REINHARD2>(t, src, n, p); break;
+        case VPT_TONEMAPPER_UNCHARTED2: launch_tonemap<VPT_TM_UNCHARTED2>(t, src, n, p); break;
+        case VPT_TONEMAPPER_FILMIC:     launch_tonemap<VPT_TM_FILMIC>(t, src, n, p); break;
+        case VPT_TONEMAPPER_UNREAL:     launch_tonemap<VPT_TM_UNREAL>(t, src, n, p); break;
+        case VPT_TONEMAPPER_ACES:       launch_tonemap<VPT_TM_ACES>(t, src, n, p); break;
+        case VPT_TONEMAPPER_LOTTES:     launch_tonemap<VPT_TM_LOTTES>(t, src, n, p); break;
+        default:                        launch_tonemap<VPT_TM_UCHIMURA>(t, src, n, p); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (white) { hipStreamSynchronize(c->stream); hipFree(white); }
+    if (e != hipSuccess) return fail(VPT_ERR_HIP, "tone-map launch: %s", hipGetErrorString(e));
+    t->rows = rows;
+    return VPT_OK;
+}
+extern "C" int vpt_tonemapper_rows(vpt_tonemapper *t, int *rows) {
+    if (!t || !rows) return fail(VPT_ERR_INVALID, "null argument");
+    *rows = t->rows ? t->rows : (t->source ? t->source->local_h : t->H);
+    return VPT_OK;
+}
+extern "C" int vpt_tonemapper_read(vpt_tonemapper *t, void *dst, size_t nbytes) {
+    if (!t || !dst) return fail(VPT_ERR_INVALID, "null argument");
+    if (!t->rows) return fail(VPT_ERR_INVALID, "nothing rendered yet");
+    size_t need = (size_t)t->W * t->rows * 4;
+    if (nbytes < need) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, need);
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, t->out, need, hipMemcpyDeviceToHost, t->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return VPT_OK;
+}
+extern "C" int vpt_tonemapper_output_device(vpt_tonemapper *t, void **ptr, size_t *nbytes) {
+    if (!t || !ptr || !nbytes) return fail(VPT_ERR_INVALID, "null argument");
+    if (!t->rows) return fail(VPT_ERR_INVALID, "nothing rendered yet");
+    *ptr = t->out; *nbytes = (size_t)t->W * t->rows * 4;
     return VPT_OK;
 }
 

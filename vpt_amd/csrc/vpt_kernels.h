@@ -10,6 +10,7 @@
 // tables of the volume (vpt_device.h), staged once at kernel entry.
 #pragma once
 #include "vpt_device.h"
+#include "vpt_tonemap.h"
 
 #define VPT_TILE        16
 #define VPT_BLOCK       256
@@ -850,6 +851,8 @@ __global__ void k_probe_math(int which, const float *in, float *out, size_t n) {
         case 12: r = vpt_logf_uniform(in[t]); break;
         case 13: r = rcp_nrz(in[t]); break;
         case 14: r = sqrt_nr(in[t]); break;
+        case 15: r = vpt_expf(in[t]); break;
+        case 16: r = vpt_powf(in[2 * t], in[2 * t + 1]); break;
     }
     out[t] = r;
 }
