@@ -275,6 +275,62 @@ static napi_value RendererPlay(napi_env env, napi_callback_info info) {
     return undefined(env);
 }
 
+// ---- tone mappers -------------------------------------------------------------------------------------
+static napi_value TonemapperCreate(napi_env env, napi_callback_info info) {
+    napi_value a[4]; vpt_context *c; int32_t kind, w, h;
+    if (!get_args(env, info, 4, a) || !get_handle(env, a[0], &c) || !get_i32(env, a[1], &kind) || !get_i32(env, a[2], &w) ||
+        !get_i32(env, a[3], &h)) return nullptr;
+    vpt_tonemapper *t = nullptr;
+    VPT_CHECK(vpt_tonemapper_create(c, kind, w, h, &t));
+    return make_external(env, t);
+}
+static napi_value TonemapperDestroy(napi_env env, napi_callback_info info) {
+    napi_value a[1]; vpt_tonemapper *t;
+    if (!get_args(env, info, 1, a) || !get_handle(env, a[0], &t)) return nullptr;
+    VPT_CHECK(vpt_tonemapper_destroy(t));
+    return undefined(env);
+}
+static napi_value TonemapperResize(napi_env env, napi_callback_info info) {
+    napi_value a[3]; vpt_tonemapper *t; int32_t w, h;
+    if (!get_args(env, info, 3, a) || !get_handle(env, a[0], &t) || !get_i32(env, a[1], &w) || !get_i32(env, a[2], &h)) return nullptr;
+    VPT_CHECK(vpt_tonemapper_resize(t, w, h));
+    return undefined(env);
+}
+static napi_value TonemapperSetSource(napi_env env, napi_callback_info info) {
+    napi_value a[2]; vpt_tonemapper *t; vpt_renderer *r;
+    if (!get_args(env, info, 2, a) || !get_handle(env, a[0], &t) || !get_handle(env, a[1], &r, true)) return nullptr;
+    VPT_CHECK(vpt_tonemapper_set_source(t, r));
+    return undefined(env);
+}
+static napi_value TonemapperSetSourceImage(napi_env env, napi_callback_info info) {
+    napi_value a[4]; vpt_tonemapper *t; void *data; size_t n; int32_t w, rows;
+    if (!get_args(env, info, 4, a) || !get_handle(env, a[0], &t) || !get_bytes(env, a[1], &data, &n) || !get_i32(env, a[2], &w) ||
+        !get_i32(env, a[3], &rows)) return nullptr;
+    if (w < 1 || rows < 1 || n < (size_t)w * (size_t)rows * 8) { napi_throw_range_error(env, nullptr, "image data shorter than width*rows*8"); return nullptr; }
+    VPT_CHECK(vpt_tonemapper_set_source_image(t, data, w, rows));
+    return undefined(env);
+}
+// tonemapperRender(handle, params: Float32Array(8) = low, mid, high, saturation, min, max, exposure, gamma)
+static napi_value TonemapperRender(napi_env env, napi_callback_info info) {
+    napi_value a[2]; vpt_tonemapper *t; void *p; size_t n;
+    if (!get_args(env, info, 2, a) || !get_handle(env, a[0], &t) || !get_bytes(env, a[1], &p, &n)) return nullptr;
+    if (n < sizeof(vpt_tonemap_params)) { napi_throw_range_error(env, nullptr, "parameter block is smaller than struct vpt_tonemap_params"); return nullptr; }
+    VPT_CHECK(vpt_tonemapper_render(t, (const vpt_tonemap_params *)p));
+    return undefined(env);
+}
+static napi_value TonemapperRows(napi_env env, napi_callback_info info) {
+    napi_value a[1]; vpt_tonemapper *t; int rows = 0;
+    if (!get_args(env, info, 1, a) || !get_handle(env, a[0], &t)) return nullptr;
+    VPT_CHECK(vpt_tonemapper_rows(t, &rows));
+    return number(env, rows);
+}
+static napi_value TonemapperRead(napi_env env, napi_callback_info info) {
+    napi_value a[2]; vpt_tonemapper *t; void *dst; size_t n;
+    if (!get_args(env, info, 2, a) || !get_handle(env, a[0], &t) || !get_bytes(env, a[1], &dst, &n)) return nullptr;
+    VPT_CHECK(vpt_tonemapper_read(t, dst, n));
+    return undefined(env);
+}
+
 // ---- multi-GPU frame gather ---------------------------------------------------------------------------
 static napi_value GatherUniqueId(napi_env env, napi_callback_info info) {
     (void)info;
@@ -348,6 +404,12 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("rendererSampleCount", RendererSampleCount); EXPORT("rendererClearSampleCount", RendererClearSampleCount);
     EXPORT("rendererSetProfiling", RendererSetProfiling); EXPORT("rendererProfile", RendererProfile);
     EXPORT("rendererSetOption", RendererSetOption); EXPORT("rendererPlay", RendererPlay);
+    EXPORT("tonemapperCreate", TonemapperCreate); EXPORT("tonemapperDestroy", TonemapperDestroy); EXPORT("tonemapperResize", TonemapperResize);
+    EXPORT("tonemapperSetSource", TonemapperSetSource); EXPORT("tonemapperSetSourceImage", TonemapperSetSourceImage);
+    EXPORT("tonemapperRender", TonemapperRender); EXPORT("tonemapperRows", TonemapperRows); EXPORT("tonemapperRead", TonemapperRead);
+    CONST(VPT_TONEMAPPER_ARTISTIC); CONST(VPT_TONEMAPPER_RANGE); CONST(VPT_TONEMAPPER_REINHARD); CONST(VPT_TONEMAPPER_REINHARD2);
+    CONST(VPT_TONEMAPPER_UNCHARTED2); CONST(VPT_TONEMAPPER_FILMIC); CONST(VPT_TONEMAPPER_UNREAL); CONST(VPT_TONEMAPPER_ACES);
+    CONST(VPT_TONEMAPPER_LOTTES); CONST(VPT_TONEMAPPER_UCHIMURA);
     EXPORT("gatherUniqueId", GatherUniqueId); EXPORT("gatherCreate", GatherCreate); EXPORT("gatherDestroy", GatherDestroy);
     EXPORT("gatherSetRoot", GatherSetRoot); EXPORT("gatherRender", GatherRender); EXPORT("gatherPlay", GatherPlay); EXPORT("gatherSynchronize", GatherSynchronize);
     EXPORT("gatherReadFrame", GatherReadFrame);

@@ -95,6 +95,35 @@ async function main() {
         gather.destroy(); plain.destroy(); sharded.destroy();
     }
 
+    // ---- tone mappers: the committed contract fixture (tests/golden/tonemap_r01.json), then renderer -> tone mapper in HBM
+    {
+        const fx = JSON.parse(require('fs').readFileSync(require('path').join(__dirname, '../../tests/golden/tonemap_r01.json'), 'utf8'));
+        const src = Uint16Array.from(fx.source_rgba16f_bits);
+        const n = src.length / 4;
+        for (const c of fx.cases) {
+            const T = vpt.ToneMapperFactory(c.kind);
+            const tm = new T(ctx, { data: src, width: n, height: 1 }, { resolution: { width: n, height: 1 } });
+            Object.keys(c.params).forEach(k => { tm[k] = c.params[k]; });
+            tm.render();
+            const out = tm.getTexture();
+            assert.strictEqual(out.data.length, c.rgba8.length);
+            assert.deepStrictEqual(Array.from(out.data), c.rgba8, 'tone mapper ' + c.kind + ' ' + JSON.stringify(c.params));
+            tm.destroy();
+        }
+        assert.throws(() => vpt.ToneMapperFactory('linear'), /No suitable class/);           // ToneMapperFactory.js:26
+        const r = new vpt.MCMRenderer(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });
+        r.reset();
+        const tm = new (vpt.ToneMapperFactory('artistic'))(ctx, r, { resolution: { width: W, height: H } });   // RenderingContext.js:169-188
+        assert.deepStrictEqual(tm.properties.map(p => p.name), ['low', 'high', 'mid', 'saturation', 'gamma']);
+        for (let k = 0; k < 3; k++) { r.render(); tm.render(); }                                               // RenderingContext.js:196-197
+        const out = tm.getTexture();
+        assert.strictEqual(out.width, W); assert.strictEqual(out.height, H);
+        let lit = 0;
+        for (let i = 0; i < W * H; i++) { assert.strictEqual(out.data[4 * i + 3], 255); if (out.data[4 * i] > 0) { lit++; } }
+        assert.ok(lit > W * H / 2);
+        tm.destroy(); r.destroy();
+    }
+
     // ---- errors are thrown Errors carrying the native message
     {
         const r = new vpt.MIPRenderer(ctx, null, camera, null, { resolution: 32 });
