@@ -200,6 +200,14 @@ VPT_API int vpt_tonemapper_render(vpt_tonemapper *t, const struct vpt_tonemap_pa
 VPT_API int vpt_tonemapper_read(vpt_tonemapper *t, void *dst, size_t nbytes);
 VPT_API int vpt_tonemapper_rows(vpt_tonemapper *t, int *rows);
 VPT_API int vpt_tonemapper_output_device(vpt_tonemapper *t, void **ptr, size_t *nbytes);
+/* Range and the eight curve mappers can run through a 65 536-entry byte table (every output byte depends on one
+ * half-precision input): bit-identical output, byte gathers instead of log/exp/divisions.  AUTO (default) uses it for
+ * images of >= 262 144 pixels or when the table of the current parameters already exists; Artistic never does. */
+#define VPT_TONEMAPPER_OPTION_TABLE  0
+#define VPT_TONEMAPPER_TABLE_NEVER   0
+#define VPT_TONEMAPPER_TABLE_ALWAYS  1
+#define VPT_TONEMAPPER_TABLE_AUTO    2
+VPT_API int vpt_tonemapper_set_option(vpt_tonemapper *t, int option, int value);
 
 /* ---- multi-GPU frame gather (no reference counterpart).  One process per GPU; the image plane is sharded
  * with vpt_renderer_set_shard and every frame is all-gathered over RCCL/xGMI.  The pipeline lives below the C ABI so

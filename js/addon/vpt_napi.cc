@@ -318,6 +318,12 @@ static napi_value TonemapperRender(napi_env env, napi_callback_info info) {
     VPT_CHECK(vpt_tonemapper_render(t, (const vpt_tonemap_params *)p));
     return undefined(env);
 }
+static napi_value TonemapperSetOption(napi_env env, napi_callback_info info) {
+    napi_value a[3]; vpt_tonemapper *t; int32_t opt, val;
+    if (!get_args(env, info, 3, a) || !get_handle(env, a[0], &t) || !get_i32(env, a[1], &opt) || !get_i32(env, a[2], &val)) return nullptr;
+    VPT_CHECK(vpt_tonemapper_set_option(t, opt, val));
+    return undefined(env);
+}
 static napi_value TonemapperRows(napi_env env, napi_callback_info info) {
     napi_value a[1]; vpt_tonemapper *t; int rows = 0;
     if (!get_args(env, info, 1, a) || !get_handle(env, a[0], &t)) return nullptr;
@@ -406,6 +412,8 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("rendererSetOption", RendererSetOption); EXPORT("rendererPlay", RendererPlay);
     EXPORT("tonemapperCreate", TonemapperCreate); EXPORT("tonemapperDestroy", TonemapperDestroy); EXPORT("tonemapperResize", TonemapperResize);
     EXPORT("tonemapperSetSource", TonemapperSetSource); EXPORT("tonemapperSetSourceImage", TonemapperSetSourceImage);
+    EXPORT("tonemapperSetOption", TonemapperSetOption); CONST(VPT_TONEMAPPER_OPTION_TABLE); CONST(VPT_TONEMAPPER_TABLE_NEVER);
+    CONST(VPT_TONEMAPPER_TABLE_ALWAYS); CONST(VPT_TONEMAPPER_TABLE_AUTO);
     EXPORT("tonemapperRender", TonemapperRender); EXPORT("tonemapperRows", TonemapperRows); EXPORT("tonemapperRead", TonemapperRead);
     CONST(VPT_TONEMAPPER_ARTISTIC); CONST(VPT_TONEMAPPER_RANGE); CONST(VPT_TONEMAPPER_REINHARD); CONST(VPT_TONEMAPPER_REINHARD2);
     CONST(VPT_TONEMAPPER_UNCHARTED2); CONST(VPT_TONEMAPPER_FILMIC); CONST(VPT_TONEMAPPER_UNREAL); CONST(VPT_TONEMAPPER_ACES);

@@ -72,11 +72,15 @@ def test_tonemapper_image_parity(gpu_ctx, oracle, kind):
     for params in PARAMS.get(kind, [{}, {'exposure': 2.5, 'gamma': 1.7}, {'exposure': 0.0, 'gamma': 2.2}]):
         for k, v in params.items():
             setattr(tm, k, v)
-        tm.render()
-        got = tm.getTexture()
-        assert got.shape == (h, w, 4) and got.dtype == np.uint8
         full = {p['name']: getattr(tm, p['name']) for p in tm.properties}
-        same(got, oracle.tonemap(kind, img, **full), "%s %r" % (kind, params))
+        want = oracle.tonemap(kind, img, **full)
+        # direct evaluation per pixel, then the 65 536-entry byte-table form (a no-op for Artistic); twice: the cached table
+        for mode in (N.TONEMAPPER_TABLE_NEVER, N.TONEMAPPER_TABLE_ALWAYS, N.TONEMAPPER_TABLE_ALWAYS):
+            tm.set_option(N.TONEMAPPER_OPTION_TABLE, mode)
+            tm.render()
+            got = tm.getTexture()
+            assert got.shape == (h, w, 4) and got.dtype == np.uint8
+            same(got, want, "%s %r table mode %d" % (kind, params, mode))
     tm.destroy()
 
 
@@ -173,9 +177,12 @@ def test_full_size_tonemap(gpu_ctx, oracle):
     img = hdr_image(w, h, seed=9)
     for kind in KINDS:
         tm = vpt_amd.ToneMapperFactory(kind)(gpu_ctx, img, {'resolution': (w, h)})
-        tm.render()
+        tm.render()                                            # AUTO: the table form at this size (except Artistic)
         out = tm.getTexture()
         same(out[500:516], oracle.tonemap(kind, img[500:516]), "%s rows 500..516" % kind)
+        tm.set_option(N.TONEMAPPER_OPTION_TABLE, N.TONEMAPPER_TABLE_NEVER)
+        tm.render()
+        same(tm.getTexture(), out, "%s direct vs table over the whole frame" % kind)
         if kind != 'range':
             assert (out[..., 3] == 255).all()
         tm.destroy()

@@ -16,6 +16,7 @@ BUFFER_RENDER, BUFFER_FRAME, BUFFER_ACCUM = 0, 1, 2
 BUFFER_MCM_POSITION, BUFFER_MCM_DIRECTION, BUFFER_MCM_TRANSMITTANCE, BUFFER_MCM_RADIANCE = 3, 4, 5, 6
 (PROBE_LOG, PROBE_SIN, PROBE_COS, PROBE_ASIN, PROBE_ATAN2, PROBE_PCG, PROBE_UNIFORM, PROBE_F16,
  PROBE_RCP, PROBE_RSQRT, PROBE_MIN, PROBE_MAX, PROBE_LOG_UNIFORM, PROBE_RCPZ, PROBE_SQRT, PROBE_EXP, PROBE_POW) = range(17)
+TONEMAPPER_OPTION_TABLE, TONEMAPPER_TABLE_NEVER, TONEMAPPER_TABLE_ALWAYS, TONEMAPPER_TABLE_AUTO = 0, 0, 1, 2
 (TONEMAPPER_ARTISTIC, TONEMAPPER_RANGE, TONEMAPPER_REINHARD, TONEMAPPER_REINHARD2, TONEMAPPER_UNCHARTED2, TONEMAPPER_FILMIC,
  TONEMAPPER_UNREAL, TONEMAPPER_ACES, TONEMAPPER_LOTTES, TONEMAPPER_UCHIMURA) = range(10)
 
@@ -39,7 +40,7 @@ SYMBOLS = [
     "vpt_probe_math", "vpt_probe_sample", "vpt_probe_stream_read",
     "vpt_tonemapper_create", "vpt_tonemapper_destroy", "vpt_tonemapper_resize", "vpt_tonemapper_set_source",
     "vpt_tonemapper_set_source_image", "vpt_tonemapper_render", "vpt_tonemapper_read", "vpt_tonemapper_rows",
-    "vpt_tonemapper_output_device",
+    "vpt_tonemapper_output_device", "vpt_tonemapper_set_option",
 ]
 
 
@@ -112,7 +113,7 @@ def lib():
         "vpt_tonemapper_create": [P, I, I, I, P], "vpt_tonemapper_destroy": [P], "vpt_tonemapper_resize": [P, I, I],
         "vpt_tonemapper_set_source": [P, P], "vpt_tonemapper_set_source_image": [P, P, I, I],
         "vpt_tonemapper_render": [P, C.POINTER(TonemapParams)], "vpt_tonemapper_read": [P, P, SZ],
-        "vpt_tonemapper_rows": [P, P], "vpt_tonemapper_output_device": [P, P, P],
+        "vpt_tonemapper_rows": [P, P], "vpt_tonemapper_output_device": [P, P, P], "vpt_tonemapper_set_option": [P, I, I],
         "vpt_gather_unique_id": [P], "vpt_gather_create": [P, P, I, I, PP], "vpt_gather_destroy": [P],
         "vpt_gather_render": [P, UP], "vpt_gather_synchronize": [P], "vpt_gather_read_frame": [P, P, SZ],
     }

@@ -961,6 +961,8 @@ struct vpt_tonemapper {
     uint2 *image; int image_w, image_rows;    // owned source texture (set_source_image), or null
     uint32_t *out; size_t out_pixels;         // RGBA8 target, grown on demand
     int rows;                      // rows of the last render
+    int table_mode;                // VPT_TONEMAPPER_TABLE_*
+    uint8_t *table; bool table_valid; TonemapParams table_params;   // byte table of the current parameters (vpt_tonemap.h)
 };
 extern "C" int vpt_tonemapper_create(vpt_context *c, int kind, int width, int height, vpt_tonemapper **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
@@ -968,7 +970,7 @@ extern "C" int vpt_tonemapper_create(vpt_context *c, int kind, int width, int he
     if (width < 1 || height < 1) return fail(VPT_ERR_INVALID, "bad resolution %dx%d", width, height);
     vpt_tonemapper *t = new vpt_tonemapper();
     memset(t, 0, sizeof(*t));
-    t->ctx = c; t->kind = kind; t->W = width; t->H = height;
+    t->ctx = c; t->kind = kind; t->W = width; t->H = height; t->table_mode = VPT_TONEMAPPER_TABLE_AUTO;
     *out = t;
     return VPT_OK;
 }
@@ -978,6 +980,7 @@ extern "C" int vpt_tonemapper_destroy(vpt_tonemapper *t) {
     hipStreamSynchronize(t->ctx->stream);
     if (t->image) hipFree(t->image);
     if (t->out) hipFree(t->out);
+    if (t->table) hipFree(t->table);
     delete t;
     return VPT_OK;
 }
@@ -1013,7 +1016,29 @@ template <int KIND>
 static void launch_tonemap(vpt_tonemapper *t, const uint2 *src, size_t n, const TonemapParams &p) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;                 // grid-stride beyond 32 workgroups per CU
-    hipLaunchKernelGGL(k_tonemap<KIND>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, p);
+    // table form (vpt_tonemap.h): not for Artistic (its channels are coupled through the saturation mix); in AUTO mode only
+    // when the image is large enough to pay for evaluating 65 536 entries, or the table of these parameters already exists
+    bool current = t->table && t->table_valid && memcmp(&t->table_params, &p, sizeof(p)) == 0;
+    bool use_table = KIND != VPT_TM_ARTISTIC &&
+                     (t->table_mode == VPT_TONEMAPPER_TABLE_ALWAYS || (t->table_mode == VPT_TONEMAPPER_TABLE_AUTO && (current || n >= 4 * 65536)));
+    if (use_table && !t->table && hipMalloc(&t->table, VPT_TM_TABLE_ENTRIES + 63) != hipSuccess) { t->table = nullptr; use_table = false; (void)hipGetLastError(); }
+    if (!use_table) {
+        hipLaunchKernelGGL(k_tonemap<KIND>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, p);
+        return;
+    }
+    if (!current) {
+        hipLaunchKernelGGL(k_tonemap_table<KIND>, dim3(256), dim3(256), 0, t->ctx->stream, t->table, p);
+        t->table_params = p; t->table_valid = true;
+    }
+    if (KIND == VPT_TM_RANGE) hipLaunchKernelGGL(k_tonemap_apply_table<true>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, t->table);
+    else hipLaunchKernelGGL(k_tonemap_apply_table<false>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, t->table);
+}
+extern "C" int vpt_tonemapper_set_option(vpt_tonemapper *t, int option, int value) {
+    if (!t) return fail(VPT_ERR_INVALID, "tone mapper is null");
+    if (option != VPT_TONEMAPPER_OPTION_TABLE) return fail(VPT_ERR_INVALID, "unknown tone mapper option %d", option);
+    if (value < VPT_TONEMAPPER_TABLE_NEVER || value > VPT_TONEMAPPER_TABLE_AUTO) return fail(VPT_ERR_INVALID, "bad value %d", value);
+    t->table_mode = value;
+    return VPT_OK;
 }
 __global__ void k_fill_u32(uint32_t *dst, size_t n, uint32_t v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;

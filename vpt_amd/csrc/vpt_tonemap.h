@@ -115,6 +115,30 @@ VPT_DEV uint32_t tonemap_texel(uint2 texel, const TonemapParams &p) {
                          vpt_powf(tm_curve<KIND>(c.z * p.exposure), e), vpt_powf(1.0f, e));
 }
 
+// ---- table form -------------------------------------------------------------------------------------------------
+// For Range and the eight curve mappers every output byte is a function of ONE half-precision input (and the pass's
+// uniforms): a 65 536-entry byte table, filled by evaluating exactly the code above on every half bit pattern, turns
+// the pass into byte gathers — bit-identical by construction, and HBM-bound instead of VALU-bound.
+// table[h] = the colour-channel byte for input half h; entry 65 536 = the alpha byte of the curve mappers.
+#define VPT_TM_TABLE_ENTRIES 65537
+template <int KIND>
+__global__ void __launch_bounds__(256) k_tonemap_table(uint8_t *table, TonemapParams p) {
+    uint32_t h = blockIdx.x * 256u + threadIdx.x;             // 256 workgroups
+    uint32_t packed = tonemap_texel<KIND>(make_uint2(h | (h << 16), h | (h << 16)), p);
+    table[h] = (uint8_t)(packed & 0xffu);
+    if (h == 0) table[65536] = (uint8_t)(packed >> 24);       // Range never reads it: its alpha goes through table[h]
+}
+template <bool ALPHA_FROM_TABLE>
+__global__ void __launch_bounds__(256) k_tonemap_apply_table(const uint2 *src, uint32_t *dst, size_t n, const uint8_t *table) {
+    uint32_t alpha = (uint32_t)table[65536] << 24;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint2 t = src[i];
+        uint32_t r = table[t.x & 0xffffu], g = table[t.x >> 16], b = table[t.y & 0xffffu];
+        uint32_t a = ALPHA_FROM_TABLE ? ((uint32_t)table[t.y >> 16] << 24) : alpha;
+        dst[i] = r | (g << 8) | (b << 16) | a;
+    }
+}
+
 // n texels, grid-stride; src RGBA16F, dst RGBA8 (both row-major, same pixel order)
 template <int KIND>
 __global__ void __launch_bounds__(256) k_tonemap(const uint2 *src, uint32_t *dst, size_t n, TonemapParams p) {

@@ -80,6 +80,10 @@ class AbstractToneMapper(PropertyBag):
             self._resolution = resolution
             self._rebuildBuffers()
 
+    def set_option(self, option, value):
+        """extension: N.TONEMAPPER_OPTION_TABLE -> N.TONEMAPPER_TABLE_NEVER / _ALWAYS / _AUTO"""
+        N.check(N.lib().vpt_tonemapper_set_option(self._h, int(option), int(value)))
+
     def _params(self):
         return N.TonemapParams(low=0.0, mid=0.5, high=1.0, saturation=1.0, min=0.0, max=1.0, exposure=1.0, gamma=2.2)
 
