@@ -1,45 +1,9 @@
 'use strict';
-// src/js/Volume.js:3-127 on HIP device memory, and the in-memory form of src/js/readers/RAWReader.js:3-70.
+// src/js/Volume.js:3-127 on HIP device memory; fed by a reader (js/vpt/readers/readers.js).
 const { EventTarget, CustomEvent } = require('./EventTarget.js');
 const { native } = require('./native.js');
 
-const GL_RED = 6403, GL_R8 = 33321, GL_UNSIGNED_BYTE = 5121;
-
-class RAWReader {
-
-constructor(data, options) {
-    options = options || {};
-    this.width = options.width || 0;
-    this.height = options.height || 0;
-    this.depth = options.depth || 0;
-    this._data = data instanceof Uint8Array ? data : new Uint8Array(data);
-}
-
-async readMetadata() {
-    const metadata = {
-        meta: { version: 1 },
-        modalities: [{
-            name: 'default',
-            dimensions: { width: this.width, height: this.height, depth: this.depth },
-            transform: { matrix: [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1] },
-            format: GL_RED, internalFormat: GL_R8, type: GL_UNSIGNED_BYTE,
-            placements: [],
-        }],
-        blocks: [],
-    };
-    for (let i = 0; i < this.depth; i++) {
-        metadata.modalities[0].placements.push({ index: i, position: { x: 0, y: 0, z: i } });
-        metadata.blocks.push({ url: 'default', format: 'raw', dimensions: { width: this.width, height: this.height, depth: 1 } });
-    }
-    return metadata;
-}
-
-async readBlock(block) {
-    const sliceBytes = this.width * this.height;
-    return this._data.subarray(block * sliceBytes, (block + 1) * sliceBytes);
-}
-
-}
+const { RAWReader, GL_RED, GL_UNSIGNED_BYTE } = require('./readers/readers.js');
 
 class Volume extends EventTarget {
 

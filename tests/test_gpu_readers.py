@@ -1,0 +1,87 @@
+"""GPU: volumes that arrive through the readers (BVP blocks with partial x-y extents, file-backed loaders) land in HBM
+exactly as a whole-array upload does (Volume.readModality's texSubImage3D placements, Volume.js:63-71)."""
+import io
+import json
+import zipfile
+
+import numpy as np
+import pytest
+
+import vpt_amd
+from vpt_amd import _native as N
+from vpt_amd.loaders import BlobLoader, FileLoader
+from vpt_amd.readers import BVPReader, RAWReader
+from vpt_amd.scene import Transform, Node, default_camera
+from vpt_amd.synthetic import sphere_volume, GoldenRatioRng
+
+pytestmark = pytest.mark.gpu
+
+
+def make_bvp(vol, cuts):
+    """vol [z][y][x] u8 -> stored-zip BVP bytes, cut into blocks at the given (x, y, z) split points"""
+    d, h, w = vol.shape
+    xs, ys, zs = ([0] + list(c) + [n] for c, n in zip(cuts, (w, h, d)))
+    blocks, placements = [], []
+    bio = io.BytesIO()
+    with zipfile.ZipFile(bio, "w", compression=zipfile.ZIP_STORED) as z:
+        for zi in range(len(zs) - 1):
+            for yi in range(len(ys) - 1):
+                for xi in range(len(xs) - 1):
+                    x0, x1, y0, y1, z0, z1 = xs[xi], xs[xi + 1], ys[yi], ys[yi + 1], zs[zi], zs[zi + 1]
+                    name = "blocks/%d_%d_%d.raw" % (xi, yi, zi)
+                    z.writestr(name, np.ascontiguousarray(vol[z0:z1, y0:y1, x0:x1]).tobytes())
+                    placements.append({"index": len(blocks), "position": {"x": x0, "y": y0, "z": z0}})
+                    blocks.append({"url": name, "format": "raw", "dimensions": {"width": x1 - x0, "height": y1 - y0, "depth": z1 - z0}})
+        manifest = {"meta": {"version": 1},
+                    "modalities": [{"name": "default", "dimensions": {"width": w, "height": h, "depth": d},
+                                    "transform": {"matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]},
+                                    "format": 6403, "internalFormat": 33321, "type": 5121, "placements": placements}],
+                    "blocks": blocks}
+        z.writestr("manifest.json", json.dumps(manifest))
+    return bio.getvalue()
+
+
+def render_mip(ctx, gvol, w=120, h=90, frames=2):
+    r = vpt_amd.MIPRenderer(ctx, gvol, default_camera(w / h), None, {'resolution': (w, h), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+    r.steps = 50
+    r.reset()
+    for _ in range(frames):
+        r.render()
+    out = (r.read(N.BUFFER_ACCUM), r.getTexture())
+    r.destroy()
+    return out
+
+
+@pytest.mark.parametrize("loader_kind", ["blob", "file"])
+def test_bvp_volume_equals_whole_array_upload(gpu_ctx, tmp_path, loader_kind):
+    vol = sphere_volume(0, noise=35.0, dims=(37, 45, 52))                       # odd sizes: blocks end mid-brick
+    archive = make_bvp(vol, cuts=((20, 33), (17,), (5, 30)))                   # 3 x 2 x 3 blocks, partial x-y extents
+    if loader_kind == "file":
+        p = tmp_path / "v.bvp"; p.write_bytes(archive)
+        loader = FileLoader(str(p))
+    else:
+        loader = BlobLoader(archive)
+    seen = []
+    v = vpt_amd.Volume(gpu_ctx, BVPReader(loader))
+    v.addEventListener('progress', lambda e: seen.append(e.detail))
+    assert v.getTexture() is None                                                # Volume.js:107-113
+    v.load()
+    v.setFilter('linear')
+    assert v.ready and len(seen) == 18 and seen[-1] == 1
+    whole = vpt_amd.Volume.from_array(gpu_ctx, vol, 'linear')
+    a, b = render_mip(gpu_ctx, v), render_mip(gpu_ctx, whole)
+    assert (a[0] == b[0]).all() and (a[1].view(np.uint16) == b[1].view(np.uint16)).all()
+    with pytest.raises(RuntimeError, match="Modality 'nope' does not exist"):   # Volume.js:40
+        v.readModality('nope')
+    v.destroy(); whole.destroy()
+
+
+def test_raw_reader_from_file(gpu_ctx, tmp_path):
+    vol = sphere_volume(0, noise=20.0, dims=(20, 24, 28))
+    p = tmp_path / "v.raw"; p.write_bytes(vol.tobytes())
+    v = vpt_amd.Volume(gpu_ctx, RAWReader(FileLoader(str(p)), {'width': 28, 'height': 24, 'depth': 20}))
+    v.load(); v.setFilter('linear')
+    whole = vpt_amd.Volume.from_array(gpu_ctx, vol, 'linear')
+    a, b = render_mip(gpu_ctx, v), render_mip(gpu_ctx, whole)
+    assert (a[0] == b[0]).all()
+    v.destroy(); whole.destroy()

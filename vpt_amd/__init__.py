@@ -6,7 +6,9 @@ constructing a Context does, and raises if it is missing (no CPU fallback)."""
 from .property_bag import PropertyBag, EventTarget, Event, CustomEvent
 from .scene import Node, Transform, PerspectiveCamera, mat4, quat, vec3, default_camera, mvp_inverse_matrix
 from .context import Context
-from .volume import Volume, RAWReader
+from .volume import Volume
+from .loaders import AbstractLoader, BlobLoader, FileLoader, LoaderFactory
+from .readers import AbstractReader, RAWReader, ZIPReader, BVPReader, ReaderFactory
 from .renderers import (AbstractRenderer, MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer, RendererFactory)
 from .tonemappers import (AbstractToneMapper, ArtisticToneMapper, RangeToneMapper, ReinhardToneMapper, Reinhard2ToneMapper,
                           Uncharted2ToneMapper, FilmicToneMapper, UnrealToneMapper, AcesToneMapper, LottesToneMapper,
@@ -16,6 +18,7 @@ from ._native import VptError
 __all__ = [
     'PropertyBag', 'EventTarget', 'Event', 'CustomEvent', 'Node', 'Transform', 'PerspectiveCamera',
     'mat4', 'quat', 'vec3', 'default_camera', 'mvp_inverse_matrix', 'Context', 'Volume', 'RAWReader',
+    'AbstractLoader', 'BlobLoader', 'FileLoader', 'LoaderFactory', 'AbstractReader', 'ZIPReader', 'BVPReader', 'ReaderFactory',
     'AbstractRenderer', 'MIPRenderer', 'EAMRenderer', 'MCSRenderer', 'MCMRenderer', 'RendererFactory', 'VptError',
     'AbstractToneMapper', 'ArtisticToneMapper', 'RangeToneMapper', 'ReinhardToneMapper', 'Reinhard2ToneMapper',
     'Uncharted2ToneMapper', 'FilmicToneMapper', 'UnrealToneMapper', 'AcesToneMapper', 'LottesToneMapper',

@@ -1,6 +1,5 @@
-"""Volume — src/js/Volume.js:3-127 re-hosted on HIP device memory, plus the RAW reader
-(src/js/readers/RAWReader.js:15-70) in its in-memory form so that the upload path can be driven the
-way RenderingContext.setVolume does (RenderingContext.js:124-134)."""
+"""Volume — src/js/Volume.js:3-127 re-hosted on HIP device memory; driven by a reader (vpt_amd/readers.py) the way
+RenderingContext.setVolume does (RenderingContext.js:124-134)."""
 import ctypes as C
 
 import numpy as np
@@ -8,41 +7,7 @@ import numpy as np
 from . import _native as N
 from .property_bag import EventTarget, CustomEvent
 
-# WebGL2 enums carried by reader metadata (RAWReader.js:36-38)
-GL_RED, GL_R8, GL_UNSIGNED_BYTE = 6403, 33321, 5121
-
-
-class RAWReader:
-    """RAWReader.js:3-70: a raw u8 volume exposed as one placement per z slice.  ``data`` is any bytes-like
-    or uint8 array of width*height*depth bytes (the reference reads it through a loader's byte ranges)."""
-
-    def __init__(self, data, options=None):
-        options = options or {}
-        self.width = options.get('width', 0)
-        self.height = options.get('height', 0)
-        self.depth = options.get('depth', 0)
-        self._data = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.reshape(-1)
-        if self._data.dtype != np.uint8:
-            raise TypeError('RAWReader expects uint8 data')
-
-    def readMetadata(self):
-        modality = {
-            'name': 'default',
-            'dimensions': {'width': self.width, 'height': self.height, 'depth': self.depth},
-            'transform': {'matrix': [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]},
-            'format': GL_RED, 'internalFormat': GL_R8, 'type': GL_UNSIGNED_BYTE,
-            'placements': [],
-        }
-        blocks = []
-        for i in range(self.depth):
-            modality['placements'].append({'index': i, 'position': {'x': 0, 'y': 0, 'z': i}})
-            blocks.append({'url': 'default', 'format': 'raw',
-                           'dimensions': {'width': self.width, 'height': self.height, 'depth': 1}})
-        return {'meta': {'version': 1}, 'modalities': [modality], 'blocks': blocks}
-
-    def readBlock(self, block):
-        slice_bytes = self.width * self.height
-        return self._data[block * slice_bytes:(block + 1) * slice_bytes]
+from .readers import RAWReader, GL_RED, GL_R8, GL_UNSIGNED_BYTE      # noqa: F401  (re-exported: the in-memory RAW form lives in readers.py)
 
 
 class Volume(EventTarget):
