@@ -124,6 +124,28 @@ async function main() {
         tm.destroy(); r.destroy();
     }
 
+    // ---- the caller's sequence through the headless RenderingContext (RenderingContext.js:123-133,152-210)
+    {
+        const rc = new vpt.RenderingContext({ resolution: { width: W, height: H }, rng: goldenRng() });
+        let last = 0;
+        rc.addEventListener('progress', e => { last = e.detail; });
+        await rc.setVolume(new vpt.RAWReader(vol, { width: n, height: n, depth: n }));
+        assert.strictEqual(last, 1);
+        rc.render();                                                   // nothing chosen yet: a no-op
+        rc.chooseRenderer('mcm'); rc.chooseToneMapper('reinhard');
+        for (let k = 0; k < 3; k++) { rc.render(); }
+        const f = rc.getFrame();
+        assert.strictEqual(f.width, W); assert.strictEqual(f.height, H);
+        let lit = 0;
+        for (let i = 0; i < W * H; i++) { assert.strictEqual(f.data[4 * i + 3], 255); if (f.data[4 * i] > 0) { lit++; } }
+        assert.ok(lit > W * H / 2);
+        rc.resolution = { width: 40, height: 32 }; rc.resize(40, 32);
+        rc.chooseRenderer('mip'); rc.setFilter('nearest');
+        rc.render();
+        assert.strictEqual(rc.getFrame().data.length, 40 * 32 * 4);
+        rc.destroy();
+    }
+
     // ---- errors are thrown Errors carrying the native message
     {
         const r = new vpt.MIPRenderer(ctx, null, camera, null, { resolution: 32 });

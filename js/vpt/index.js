@@ -6,4 +6,4 @@ module.exports = Object.assign({},
     require('./renderers/AbstractRenderer.js'), require('./renderers/MIPRenderer.js'), require('./renderers/EAMRenderer.js'),
     require('./renderers/MCSRenderer.js'), require('./renderers/MCMRenderer.js'), require('./renderers/RendererFactory.js'),
     require('./tonemappers/AbstractToneMapper.js'), require('./tonemappers/ArtisticToneMapper.js'), require('./tonemappers/RangeToneMapper.js'),
-    require('./tonemappers/CurveToneMappers.js'), require('./tonemappers/ToneMapperFactory.js'));
+    require('./tonemappers/CurveToneMappers.js'), require('./tonemappers/ToneMapperFactory.js'), require('./RenderingContext.js'));

@@ -80,6 +80,13 @@ setTransferFunction(transferFunction) {
     native().rendererSetTransferFunction(this._h, transferFunction.data, transferFunction.width, transferFunction.height);
 }
 
+// the reference re-fills the context-owned environment texture in place (RenderingContext.js:135-140); here the
+// renderer holds a device copy, so the context hands the new image down
+setEnvironmentMap(image) {
+    this._environmentTexture = image;
+    native().rendererSetEnvironment(this._h, image.data, image.width, image.height);
+}
+
 setResolution(resolution) {                                                                  // :106-112
     if (resolution !== this._resolution) {
         this._resolution = resolution;

@@ -186,3 +186,35 @@ def test_full_size_tonemap(gpu_ctx, oracle):
         if kind != 'range':
             assert (out[..., 3] == 255).all()
         tm.destroy()
+
+
+def test_rendering_context_sequence(gpu_ctx, oracle):
+    """the caller's sequence (RenderingContext.js:123-133,152-210,216-229): setVolume -> chooseRenderer -> chooseToneMapper ->
+    N x render(), resolution change, renderer / tone mapper swaps, filter change — the frame equals the oracle chain"""
+    from vpt_amd.readers import RAWReader
+    vol = sphere_volume(24, noise=30.0)
+    rc = vpt_amd.RenderingContext({'resolution': (88, 64), 'rng': GoldenRatioRng()})
+    seen = []
+    rc.addEventListener('progress', lambda e: seen.append(e.detail))
+    rc.resize(88, 64)
+    rc.setVolume(RAWReader(vol, {'width': 24, 'height': 24, 'depth': 24}))
+    assert seen and seen[-1] == 1
+    rc.render()                                                   # no renderer / tone mapper yet: a no-op (:191-193)
+    rc.chooseToneMapper('artistic')                               # before any renderer: the white placeholder
+    rc.chooseRenderer('mcm')
+    rc.renderer.extinction = 7
+    rc.renderer.reset()
+    for _ in range(3):
+        rc.render()
+    frame = rc.getFrame()
+    assert frame.shape == (64, 88, 4)
+    same(frame, oracle.tonemap('artistic', rc.renderer.getTexture()), "context frame")
+    assert (frame[..., 3] == 255).all() and (frame[..., :3] > 0).any()
+    rc.resolution = (48, 40); rc.resize(48, 40)
+    rc.render()
+    assert rc.getFrame().shape == (40, 48, 4)
+    rc.chooseToneMapper('aces'); rc.chooseRenderer('eam'); rc.setFilter('nearest')
+    rc.camera.transform.localTranslation = [0.3, 0.2, 1.8]        # 'change' -> renderer.reset() (:42-46)
+    rc.render(); rc.render()
+    same(rc.getFrame(), oracle.tonemap('aces', rc.renderer.getTexture()), "after swaps")
+    rc.destroy()

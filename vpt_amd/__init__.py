@@ -13,6 +13,7 @@ from .renderers import (AbstractRenderer, MIPRenderer, EAMRenderer, MCSRenderer,
 from .tonemappers import (AbstractToneMapper, ArtisticToneMapper, RangeToneMapper, ReinhardToneMapper, Reinhard2ToneMapper,
                           Uncharted2ToneMapper, FilmicToneMapper, UnrealToneMapper, AcesToneMapper, LottesToneMapper,
                           UchimuraToneMapper, ToneMapperFactory)
+from .rendering_context import RenderingContext
 from ._native import VptError
 
 __all__ = [
@@ -22,5 +23,5 @@ __all__ = [
     'AbstractRenderer', 'MIPRenderer', 'EAMRenderer', 'MCSRenderer', 'MCMRenderer', 'RendererFactory', 'VptError',
     'AbstractToneMapper', 'ArtisticToneMapper', 'RangeToneMapper', 'ReinhardToneMapper', 'Reinhard2ToneMapper',
     'Uncharted2ToneMapper', 'FilmicToneMapper', 'UnrealToneMapper', 'AcesToneMapper', 'LottesToneMapper',
-    'UchimuraToneMapper', 'ToneMapperFactory',
+    'UchimuraToneMapper', 'ToneMapperFactory', 'RenderingContext',
 ]

@@ -77,6 +77,12 @@ class AbstractRenderer(PropertyBag):
         assert tex.ndim == 3 and tex.shape[2] == 4, 'environment texture is [h][w][4] RGBA8'
         N.check(N.lib().vpt_renderer_set_environment(self._h, tex.ctypes.data_as(C.c_void_p), tex.shape[1], tex.shape[0]))
 
+    def setEnvironmentMap(self, image):
+        """the reference re-fills the context-owned environment texture in place (RenderingContext.js:135-140); the
+        renderer holds a device copy here, so the context hands the new image down"""
+        self._environmentTexture = image
+        self._upload_environment(image)
+
     def _bind_volume(self):
         tex = self._volume.getTexture() if self._volume is not None else None
         if tex is not self._bound_volume:
