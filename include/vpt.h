@@ -37,6 +37,8 @@ extern "C" {
 #define VPT_RENDERER_EAM 1
 #define VPT_RENDERER_MCS 2
 #define VPT_RENDERER_MCM 3
+#define VPT_RENDERER_ISO   4   /* src/js/renderers/ISORenderer.js, src/glsl/renderers/ISORenderer.glsl */
+#define VPT_RENDERER_DEPTH 5   /* src/js/renderers/DepthRenderer.js, src/glsl/renderers/DepthRenderer.glsl */
 
 /* Volume.js:115-125 setFilter('linear' | 'nearest') */
 #define VPT_FILTER_NEAREST 0
@@ -47,8 +49,8 @@ extern "C" {
 
 /* Buffers readable through vpt_renderer_read (SingleBuffer.js / DoubleBuffer.js attachments) */
 #define VPT_BUFFER_RENDER 0      /* RGBA16F, 8 B/pixel  (AbstractRenderer.js:142-155, getTexture() :114-116) */
-#define VPT_BUFFER_FRAME  1      /* MIP R8 | EAM RGBA8 | MCS RGBA32F  (_getFrameBufferSpec) */
-#define VPT_BUFFER_ACCUM  2      /* MIP R8 | EAM RGBA8 | MCS RGBA32F  (_getAccumulationBufferSpec, read side) */
+#define VPT_BUFFER_FRAME  1      /* MIP R8 | EAM RGBA8 | MCS RGBA32F | ISO RGBA16F | Depth R32F  (_getFrameBufferSpec) */
+#define VPT_BUFFER_ACCUM  2      /* same formats  (_getAccumulationBufferSpec, read side) */
 #define VPT_BUFFER_MCM_POSITION      3   /* RGBA32F [pos.xyz, 0]            (MCMRenderer.js:214-263) */
 #define VPT_BUFFER_MCM_DIRECTION     4   /* RGBA32F [dir.xyz, bounces]      */
 #define VPT_BUFFER_MCM_TRANSMITTANCE 5   /* RGBA32F [transmittance.rgb, 0]  */
@@ -69,14 +71,18 @@ typedef struct vpt_uniforms {
     float    mvp_inverse[16];   /* uMvpInverseMatrix, column-major (gl-matrix layout) */
     float    rand_seed;         /* uRandSeed */
     float    offset;            /* uOffset            (MIP, EAM) */
-    float    step_size;         /* uStepSize = 1/steps (MIP) or 1/slices (EAM) */
-    float    extinction;        /* uExtinction        (EAM, MCS, MCM) */
+    float    step_size;         /* uStepSize = 1/steps (MIP) or 1/slices (EAM, Depth); ISO: fl(1/float(uSteps)), the shader's own division */
+    float    extinction;        /* uExtinction        (EAM, MCS, MCM, Depth) */
     float    anisotropy;        /* uAnisotropy        (MCM) */
     uint32_t max_bounces;       /* uMaxBounces        (MCM) */
-    uint32_t steps;             /* uSteps             (MCM) */
-    float    light_direction[3];/* uScatteringDirection (MCS) */
-    float    mix;               /* uMix (EAM: 1/frameNumber) | uInvFrameNumber (MCS) */
+    uint32_t steps;             /* uSteps             (MCM, ISO) */
+    float    light_direction[3];/* uScatteringDirection (MCS) | uLight (ISO, model space, normalised: ISORenderer.js:152-166) */
+    float    mix;               /* uMix (EAM, Depth: 1/frameNumber) | uInvFrameNumber (MCS) */
     float    blur;              /* uBlur              (MCM, always 0 in the reference: MCMRenderer.js:93,157) */
+    float    isovalue;          /* uIsovalue          (ISO, ISORenderer.js:100) */
+    float    gradient_step;     /* uGradientStep      (ISO, 0.005: ISORenderer.js:168) */
+    float    threshold;         /* uThreshold         (Depth, DepthRenderer.js:112) */
+    float    reserved;          /* keeps the block at 128 bytes */
 } vpt_uniforms;
 
 /* ---- context: replaces the WebGL2RenderingContext the reference passes as `gl` (RenderingContext.js:66-106) */

@@ -146,6 +146,34 @@ async function main() {
         rc.destroy();
     }
 
+    // ---- ISO and Depth through the Node host (uniform block offsets 112..124): hits, misses and shading present
+    {
+        const iso = new vpt.ISORenderer(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });
+        assert.deepStrictEqual(iso.properties.map(p => p.name), ['steps', 'isovalue', 'light', 'transferFunction']);
+        iso.isovalue = 0.3;
+        iso.reset(); iso.render(); iso.render();
+        const closest = new Uint16Array(W * H * 4);
+        iso.read(N.VPT_BUFFER_ACCUM, closest);
+        let hits = 0, misses = 0;
+        for (let i = 0; i < W * H; i++) { if (closest[4 * i + 3] === 0xbc00) { misses++; } else if (closest[4 * i + 3] < 0x3c01) { hits++; } }
+        assert.ok(hits > 50 && misses > 0 && hits + misses === W * H, 'iso hits ' + hits + ' misses ' + misses);
+        const img = iso.getTexture().data;
+        let shaded = 0;
+        for (let i = 0; i < W * H; i++) { if (img[4 * i] !== 0x3c00 && img[4 * i] !== 0) { shaded++; } }
+        assert.ok(shaded > 0);
+        assert.ok(iso.sampleCount() >= 2 * hits * 50);
+        iso.destroy();
+        const dep = new vpt.DepthRenderer(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });
+        assert.deepStrictEqual(dep.properties.map(p => p.name), ['extinction', 'slices', 'threshold', 'random', 'transferFunction']);
+        dep.reset(); dep.render(); dep.render();
+        const d = new Float32Array(W * H);
+        dep.read(N.VPT_BUFFER_ACCUM, d);
+        let pos = 0, neg = 0;
+        for (let i = 0; i < W * H; i++) { if (d[i] > 0) { pos++; } else if (d[i] < 0) { neg++; } }
+        assert.ok(pos > 50 && neg > 0, 'depth pos ' + pos + ' neg ' + neg);
+        dep.destroy();
+    }
+
     // ---- errors are thrown Errors carrying the native message
     {
         const r = new vpt.MIPRenderer(ctx, null, camera, null, { resolution: 32 });

@@ -19,6 +19,10 @@ for (const c of fixture.cases) {
     const m = vpt.mvpInverseMatrix(cam, t);
     const bits = Array.from(new Uint32Array(m.buffer));
     assert.deepStrictEqual(bits, c.inverse_bits, c.name);
+    for (const key of ['iso_light', 'iso_light2']) {                                    // ISORenderer.js:152-166
+        const l = vpt.isoLightDirection(cam, t, c[key]);
+        assert.deepStrictEqual(Array.from(new Uint32Array(l.buffer)), c[key + '_bits'], c.name + ' ' + key);
+    }
 }
 const bag = new vpt.PropertyBag();
 bag.registerProperties([{ name: 'steps', value: 64 }]);
@@ -27,7 +31,8 @@ let seen = null;
 bag.addEventListener('change', e => { seen = e.detail; });
 bag.dispatchEvent(new vpt.CustomEvent('change', { detail: { name: 'steps', value: 8 } }));
 assert.deepStrictEqual(seen, { name: 'steps', value: 8 });
-assert.throws(() => vpt.RendererFactory('iso'), /No suitable class/);
+assert.throws(() => vpt.RendererFactory('lao'), /No suitable class/);
+assert.strictEqual(vpt.RendererFactory('iso'), vpt.ISORenderer); assert.strictEqual(vpt.RendererFactory('depth'), vpt.DepthRenderer);
 assert.strictEqual(vpt.RendererFactory('mcm'), vpt.MCMRenderer);
 // the addon loads and reports the struct size the JS side packs
 const { native } = require('../vpt/native.js');

@@ -8,6 +8,22 @@ const vec3 = {
     clone(a) { const o = new Float32Array(3); o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; return o; },
     negate(out, a) { out[0] = -a[0]; out[1] = -a[1]; out[2] = -a[2]; return out; },
     inverse(out, a) { out[0] = 1.0 / a[0]; out[1] = 1.0 / a[1]; out[2] = 1.0 / a[2]; return out; },
+    transformMat4(out, a, m) {
+        const x = a[0], y = a[1], z = a[2];
+        let w = m[3] * x + m[7] * y + m[11] * z + m[15];
+        w = w || 1.0;
+        out[0] = (m[0] * x + m[4] * y + m[8] * z + m[12]) / w;
+        out[1] = (m[1] * x + m[5] * y + m[9] * z + m[13]) / w;
+        out[2] = (m[2] * x + m[6] * y + m[10] * z + m[14]) / w;
+        return out;
+    },
+    normalize(out, a) {
+        const x = a[0], y = a[1], z = a[2];
+        let len = x * x + y * y + z * z;
+        if (len > 0) { len = 1 / Math.sqrt(len); }
+        out[0] = a[0] * len; out[1] = a[1] * len; out[2] = a[2] * len;
+        return out;
+    },
 };
 const quat = {
     create() { const o = new Float32Array(4); o[3] = 1; return o; },

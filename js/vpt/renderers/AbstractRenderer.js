@@ -11,7 +11,8 @@ const { Transform, mvpInverseMatrix } = require('../scene.js');
 const { native } = require('../native.js');
 
 // byte layout of struct vpt_uniforms (include/vpt.h)
-const U = { MVP: 0, SEED: 64, OFFSET: 68, STEP: 72, EXTINCTION: 76, ANISOTROPY: 80, BOUNCES: 84, STEPS: 88, LIGHT: 92, MIX: 104, BLUR: 108, SIZE: 112 };
+const U = { MVP: 0, SEED: 64, OFFSET: 68, STEP: 72, EXTINCTION: 76, ANISOTROPY: 80, BOUNCES: 84, STEPS: 88, LIGHT: 92, MIX: 104, BLUR: 108,
+            ISOVALUE: 112, GRADIENT_STEP: 116, THRESHOLD: 120, SIZE: 128 };
 
 class AbstractRenderer extends PropertyBag {
 

@@ -1,9 +1,11 @@
 'use strict';
-// src/js/renderers/RendererFactory.js:10-23 ('iso' | 'lao' | 'dos' | 'depth' are outside this path)
+// src/js/renderers/RendererFactory.js:10-23 ('lao' and 'dos' are not built)
 const { MIPRenderer } = require('./MIPRenderer.js');
 const { EAMRenderer } = require('./EAMRenderer.js');
 const { MCSRenderer } = require('./MCSRenderer.js');
 const { MCMRenderer } = require('./MCMRenderer.js');
+const { ISORenderer } = require('./ISORenderer.js');
+const { DepthRenderer } = require('./DepthRenderer.js');
 
 function RendererFactory(which) {
     switch (which) {
@@ -11,6 +13,8 @@ function RendererFactory(which) {
         case 'eam': return EAMRenderer;
         case 'mcs': return MCSRenderer;
         case 'mcm': return MCMRenderer;
+        case 'iso': return ISORenderer;
+        case 'depth': return DepthRenderer;
         default: throw new Error('No suitable class');
     }
 }

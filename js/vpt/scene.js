@@ -123,4 +123,19 @@ function mvpInverseMatrix(camera, volumeTransform) {
     return matrix;
 }
 
-module.exports = { Component, Transform, Node, PerspectiveCamera, defaultCamera, mvpInverseMatrix };
+// ISORenderer.js:152-166: the light direction (view space) taken into model space and normalised
+function isoLightDirection(camera, volumeTransform, light) {
+    const centerMatrix = mat4.fromTranslation(mat4.create(), [-0.5, -0.5, -0.5]);
+    const modelMatrix = volumeTransform.globalMatrix;
+    const viewMatrix = camera.transform.inverseGlobalMatrix;
+    const matrix = mat4.create();
+    mat4.multiply(matrix, centerMatrix, matrix);
+    mat4.multiply(matrix, modelMatrix, matrix);
+    mat4.multiply(matrix, viewMatrix, matrix);
+    mat4.invert(matrix, matrix);
+    const out = vec3.transformMat4(vec3.create(), light, matrix);
+    vec3.normalize(out, out);
+    return out;
+}
+
+module.exports = { Component, Transform, Node, PerspectiveCamera, defaultCamera, mvpInverseMatrix, isoLightDirection };

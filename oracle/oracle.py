@@ -39,6 +39,7 @@ class Frame(C.Structure):
         ("light_dir", C.c_float * 3),
         ("mix", C.c_float), ("blur", C.c_float), ("inv_res", C.c_float * 2),
         ("nthreads", C.c_int32),
+        ("isovalue", C.c_float), ("gradient_step", C.c_float), ("threshold", C.c_float),
     ]
 
 
@@ -101,6 +102,14 @@ def lib():
             f = getattr(L, "vpo_%s_integrate" % name); f.restype = None; f.argtypes = [FP, P, P]
             f = getattr(L, "vpo_%s_render" % name); f.restype = None; f.argtypes = [FP, P, P]
             f = getattr(L, "vpo_%s_reset" % name); f.restype = None; f.argtypes = [FP, P]
+        L.vpo_iso_generate.restype = C.c_uint64; L.vpo_iso_generate.argtypes = [SP, FP, P]
+        L.vpo_iso_integrate.restype = None; L.vpo_iso_integrate.argtypes = [FP, P, P]
+        L.vpo_iso_render.restype = C.c_uint64; L.vpo_iso_render.argtypes = [SP, FP, P, P]
+        L.vpo_iso_reset.restype = None; L.vpo_iso_reset.argtypes = [FP, P]
+        g = L.vpo_depth_generate; g.restype = C.c_uint64; g.argtypes = [SP, FP, P]
+        L.vpo_depth_integrate.restype = None; L.vpo_depth_integrate.argtypes = [FP, P, P]
+        L.vpo_depth_render.restype = None; L.vpo_depth_render.argtypes = [FP, P, P]
+        L.vpo_depth_reset.restype = None; L.vpo_depth_reset.argtypes = [FP, P]
         L.vpo_mcm_reset.restype = None; L.vpo_mcm_reset.argtypes = [FP, P, P, P, P]
         L.vpo_mcm_integrate.restype = C.c_uint64; L.vpo_mcm_integrate.argtypes = [SP, FP, P, P, P, P]
         L.vpo_mcm_render.restype = None; L.vpo_mcm_render.argtypes = [FP, P, P]
@@ -148,7 +157,7 @@ class OracleScene:
 
 def make_frame(width, height, mvp_inv, *, seed=0.0, offset=0.0, steps=64, extinction=1.0, anisotropy=0.0,
                max_bounces=8, mcm_steps=8, light_dir=(0.0, 0.0, 1.0), mix=1.0, blur=0.0, y0=0, y1=None,
-               nthreads=1):
+               nthreads=1, isovalue=0.5, gradient_step=0.005, threshold=0.1):
     f = Frame()
     f.width, f.height = width, height
     f.y0 = y0; f.y1 = height if y1 is None else y1
@@ -164,6 +173,8 @@ def make_frame(width, height, mvp_inv, *, seed=0.0, offset=0.0, steps=64, extinc
     f.mix = float(np.float32(mix)); f.blur = float(np.float32(blur))
     f.inv_res[0] = float(np.float32(1.0 / width)); f.inv_res[1] = float(np.float32(1.0 / height))
     f.nthreads = nthreads
+    f.isovalue = float(np.float32(isovalue)); f.gradient_step = float(np.float32(gradient_step))
+    f.threshold = float(np.float32(threshold))
     return f
 
 
@@ -179,6 +190,10 @@ class OracleRenderer:
             self.frame = np.zeros(4 * n, np.uint8); self.acc = np.zeros(4 * n, np.uint8)
         elif kind == "mcs":
             self.frame = np.zeros(4 * n, np.float32); self.acc = np.zeros(4 * n, np.float32)
+        elif kind == "iso":
+            self.frame = np.zeros(4 * n, np.uint16); self.acc = np.zeros(4 * n, np.uint16)      # RGBA16F bits
+        elif kind == "depth":
+            self.frame = np.zeros(n, np.float32); self.acc = np.zeros(n, np.float32)            # R32F
         elif kind == "mcm":
             self.state = [np.zeros(4 * n, np.float32) for _ in range(4)]
         else:
@@ -213,6 +228,8 @@ class OracleRenderer:
         L = lib()
         if self.kind == "mcm":
             L.vpo_mcm_render(C.byref(fr), _ptr(self.state[3]), _ptr(self.out))
+        elif self.kind == "iso":                      # the ISO render pass samples the volume (gradient + material)
+            self.samples += L.vpo_iso_render(C.byref(self.scene.c), C.byref(fr), _ptr(self.acc), _ptr(self.out))
         else:
             getattr(L, "vpo_%s_render" % self.kind)(C.byref(fr), _ptr(self.acc), _ptr(self.out))
 

@@ -68,6 +68,9 @@ typedef struct {
     float blur;                 /* uBlur */
     float inv_res[2];           /* uInverseResolution */
     int32_t nthreads;           /* OpenMP threads over rows (<=1: scalar) */
+    float isovalue;             /* uIsovalue (ISORenderer.js:100) */
+    float gradient_step;        /* uGradientStep (ISORenderer.js:168: 0.005) */
+    float threshold;            /* uThreshold (DepthRenderer.js:112) */
 } vpo_frame;
 
 /* ------------------------------------------------------------------------------------------
@@ -600,6 +603,150 @@ VPO_API void vpo_eam_reset(const vpo_frame *fr, uint8_t *acc) {
             uint8_t *px = acc + 4 * ((size_t)j * fr->width + i);
             px[0] = 0; px[1] = 0; px[2] = 0; px[3] = 255;
         }
+}
+
+/* ==========================================================================================
+ * ISO  (ISORenderer.glsl) — SURVEY section 8f row 3.  frame / accumulation: RGBA16F "closest hit" (xyz, t)
+ * (ISORenderer.js:165-197), so every stored value is a half; render shades it into the RGBA16F render buffer.
+ * ======================================================================================== */
+float vpo_f16_to_f32(uint16_t h);                                         /* vpt_tonemap_oracle.c */
+static inline void store_half4(uint16_t *px, float x, float y, float z, float w) {
+    px[0] = vpo_f32_to_f16(x); px[1] = vpo_f32_to_f16(y); px[2] = vpo_f32_to_f16(z); px[3] = vpo_f32_to_f16(w);
+}
+/* generate/fragment main(): ISORenderer.glsl:52-76 — back-to-front march, the LAST hit written is the closest one.
+ * fr->steps = uSteps, fr->step = fl(1 / float(uSteps)) (the shader's own IEEE division, :64). */
+VPO_API uint64_t vpo_iso_generate(const vpo_scene *sc, const vpo_frame *fr, uint16_t *frame) {
+    scene_tables t; tables_init(&t, sc);
+    uint64_t ns = 0; int nth = clamp_threads(fr);
+    FOR_ROWS(fr) {
+        for (int32_t i = 0; i < fr->width; i++) {
+            v3 rf, rt;
+            unproject(pixel_ndc(i, fr->width), pixel_ndc(j, fr->height), fr->mvp_inv, &rf, &rt);
+            v3 dir = sub3(rt, rf);
+            v2 tb = intersect_cube(rf, dir);
+            tb.x = vmax(tb.x, 0.0f); tb.y = vmax(tb.y, 0.0f);
+            v4 closest = { -1.0f, -1.0f, -1.0f, -1.0f };
+            if (!(tb.x >= tb.y)) {
+                v3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
+                float tt = 1.0f - fr->offset * fr->step;
+                for (uint32_t s = 0; s < fr->steps; s++) {
+                    v3 pos = mix3(from, to, tt);
+                    float value = sample_volume_color(&t, pos, &ns).w;
+                    if (value >= fr->isovalue) { closest.x = pos.x; closest.y = pos.y; closest.z = pos.z; closest.w = tt; }
+                    tt -= fr->step;
+                }
+            }
+            store_half4(frame + 4 * ((size_t)j * fr->width + i), closest.x, closest.y, closest.z, closest.w);
+        }
+    }
+    tables_free(&t);
+    return ns;
+}
+/* integrate: ISORenderer.glsl:111-121 — keep the hit with the smaller positive t */
+VPO_API void vpo_iso_integrate(const vpo_frame *fr, uint16_t *acc, const uint16_t *frame) {
+    for (int32_t j = fr->y0; j < fr->y1; j++)
+        for (int32_t i = 0; i < fr->width; i++) {
+            size_t k = 4 * ((size_t)j * fr->width + i);
+            float fw = vpo_f16_to_f32(frame[k + 3]), aw = vpo_f16_to_f32(acc[k + 3]);
+            int take_frame = (fw > 0.0f && aw > 0.0f) ? (fw < aw) : (fw > 0.0f);
+            if (take_frame) memcpy(acc + k, frame + k, 8);
+        }
+}
+/* gradient(): ISORenderer.glsl:165-177 — central differences of the transfer function's alpha */
+static v3 iso_gradient(const scene_tables *t, v3 p, float h, uint64_t *ns) {
+    v3 px = { p.x + h, p.y, p.z }, py = { p.x, p.y + h, p.z }, pz = { p.x, p.y, p.z + h };
+    v3 nx = { p.x - h, p.y, p.z }, ny = { p.x, p.y - h, p.z }, nz = { p.x, p.y, p.z - h };
+    v3 pos = { sample_volume_color(t, px, ns).w, sample_volume_color(t, py, ns).w, sample_volume_color(t, pz, ns).w };
+    v3 neg = { sample_volume_color(t, nx, ns).w, sample_volume_color(t, ny, ns).w, sample_volume_color(t, nz, ns).w };
+    float d = 2.0f * h;
+    v3 g = { (pos.x - neg.x) / d, (pos.y - neg.y) / d, (pos.z - neg.z) / d };
+    return g;
+}
+/* render/fragment main(): ISORenderer.glsl:179-191.  fr->light_dir = uLight (model space, normalised by the host,
+ * ISORenderer.js:152-166). */
+VPO_API uint64_t vpo_iso_render(const vpo_scene *sc, const vpo_frame *fr, const uint16_t *acc, uint16_t *out) {
+    scene_tables t; tables_init(&t, sc);
+    uint64_t ns = 0; int nth = clamp_threads(fr);
+    v3 light = { fr->light_dir[0], fr->light_dir[1], fr->light_dir[2] };
+    FOR_ROWS(fr) {
+        for (int32_t i = 0; i < fr->width; i++) {
+            size_t k = 4 * ((size_t)j * fr->width + i);
+            float w = vpo_f16_to_f32(acc[k + 3]);
+            if (w > 0.0f) {
+                v3 pos = { vpo_f16_to_f32(acc[k]), vpo_f16_to_f32(acc[k + 1]), vpo_f16_to_f32(acc[k + 2]) };
+                v3 normal = normalize3(iso_gradient(&t, pos, fr->gradient_step, &ns));
+                float lambert = vmax(dot3(normal, light), 0.0f);
+                v4 material = sample_volume_color(&t, pos, &ns);
+                store_half4(out + k, material.x * lambert, material.y * lambert, material.z * lambert, 1.0f);
+            } else {
+                store_half4(out + k, 1.0f, 1.0f, 1.0f, 1.0f);
+            }
+        }
+    }
+    tables_free(&t);
+    return ns;
+}
+/* reset: ISORenderer.glsl:215-217 */
+VPO_API void vpo_iso_reset(const vpo_frame *fr, uint16_t *acc) {
+    for (int32_t j = fr->y0; j < fr->y1; j++)
+        for (int32_t i = 0; i < 4 * fr->width; i++) acc[(size_t)j * 4 * fr->width + i] = 0xbc00u;      /* half(-1) */
+}
+
+/* ==========================================================================================
+ * Depth  (DepthRenderer.glsl) — SURVEY section 8f row 3.  frame / accumulation: R32F (DepthRenderer.js:165-189).
+ * ======================================================================================== */
+/* generate/fragment main(): DepthRenderer.glsl:53-79 */
+VPO_API uint64_t vpo_depth_generate(const vpo_scene *sc, const vpo_frame *fr, float *frame) {
+    scene_tables t; tables_init(&t, sc);
+    uint64_t ns = 0; int nth = clamp_threads(fr);
+    FOR_ROWS(fr) {
+        for (int32_t i = 0; i < fr->width; i++) {
+            v3 rf, rt;
+            unproject(pixel_ndc(i, fr->width), pixel_ndc(j, fr->height), fr->mvp_inv, &rf, &rt);
+            v3 dir = sub3(rt, rf);
+            v2 tb = intersect_cube(rf, dir);
+            tb.x = vmax(tb.x, 0.0f); tb.y = vmax(tb.y, 0.0f);
+            float depth = -1.0f;
+            if (!(tb.x >= tb.y)) {
+                v3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
+                float ray_step_length = length3(sub3(from, to)) * fr->step;
+                float tt = fr->step * fr->offset;
+                float accumulator = 0.0f;
+                while (tt < 1.0f && accumulator < fr->threshold) {
+                    v3 pos = mix3(from, to, tt);
+                    float a = sample_volume_color(&t, pos, &ns).w;
+                    accumulator += (1.0f - accumulator) * a * ray_step_length * fr->extinction;
+                    tt += fr->step;
+                }
+                if (!(accumulator < fr->threshold)) depth = mixf(tb.x, tb.y, tt);
+            }
+            frame[(size_t)j * fr->width + i] = depth;
+        }
+    }
+    tables_free(&t);
+    return ns;
+}
+/* integrate: DepthRenderer.glsl:114-118 — mix(accumulator, frame, uMix), the R32F target keeps .r */
+VPO_API void vpo_depth_integrate(const vpo_frame *fr, float *acc, const float *frame) {
+    for (int32_t j = fr->y0; j < fr->y1; j++)
+        for (int32_t i = 0; i < fr->width; i++) {
+            size_t k = (size_t)j * fr->width + i;
+            acc[k] = mixf(acc[k], frame[k], fr->mix);
+        }
+}
+/* render: DepthRenderer.glsl:150-153 */
+VPO_API void vpo_depth_render(const vpo_frame *fr, const float *acc, uint16_t *out) {
+    for (int32_t j = fr->y0; j < fr->y1; j++)
+        for (int32_t i = 0; i < fr->width; i++) {
+            size_t k = (size_t)j * fr->width + i;
+            uint16_t h = vpo_f32_to_f16(acc[k]);
+            out[4 * k + 0] = h; out[4 * k + 1] = h; out[4 * k + 2] = h; out[4 * k + 3] = 0x3c00u;
+        }
+}
+/* reset: DepthRenderer.glsl:177-179 — vec4(0, 0, 0, 1) into an R32F target */
+VPO_API void vpo_depth_reset(const vpo_frame *fr, float *acc) {
+    for (int32_t j = fr->y0; j < fr->y1; j++)
+        for (int32_t i = 0; i < fr->width; i++) acc[(size_t)j * fr->width + i] = 0.0f;
 }
 
 /* ==========================================================================================

@@ -27,6 +27,9 @@ def scenes():
         dict(name="eam", kind="eam", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=3, kw=dict(steps=48, extinction=60.0)),
         dict(name="mcs", kind="mcs", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=3, kw=dict(extinction=12.0, light_dir=(0.48, 0.6, 0.64))),
         dict(name="mcm_iso", kind="mcm", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=4, kw=dict(extinction=8.0, anisotropy=0.0, max_bounces=3, mcm_steps=6)),
+        dict(name="iso", kind="iso", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=3,
+             kw=dict(steps=40, mcm_steps=40, isovalue=0.35, gradient_step=0.005, light_dir=(0.32444283, -0.48666424, -0.81110704))),
+        dict(name="depth", kind="depth", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=3, kw=dict(steps=48, extinction=60.0, threshold=0.15)),
         dict(name="mcm_hg", kind="mcm", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=4, kw=dict(extinction=8.0, anisotropy=0.5, max_bounces=3, mcm_steps=6)),
     ], default_matrix
 

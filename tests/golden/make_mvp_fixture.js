@@ -45,6 +45,21 @@ function mvpInverse(c) {
     return { forward: forward, inverse: matrix };
 }
 
+// ISORenderer.js:152-166: the light direction (view space) taken into model space and normalised
+function isoLight(c, light) {
+    const centerMatrix = mat4.fromTranslation(mat4.create(), [-0.5, -0.5, -0.5]);
+    const modelMatrix = localMatrix(c.model);
+    const viewMatrix = inverseLocalMatrix(c.camera);
+    const matrix = mat4.create();
+    mat4.multiply(matrix, centerMatrix, matrix);
+    mat4.multiply(matrix, modelMatrix, matrix);
+    mat4.multiply(matrix, viewMatrix, matrix);
+    mat4.invert(matrix, matrix);
+    const l = vec3.transformMat4(vec3.create(), light, matrix);
+    vec3.normalize(l, l);
+    return l;
+}
+
 function qAxis(axis, rad) { return Array.from(quat.setAxisAngle(quat.create(), axis, rad)); }
 const ident = { rotation: [0, 0, 0, 1], translation: [0, 0, 0], scale: [1, 1, 1] };
 const cases = [
@@ -66,6 +81,8 @@ for (const c of cases) {
         name: c.name, fovy: c.fovy, aspect: c.aspect, near: c.near, far: c.far,
         camera: c.camera, model: c.model,
         forward_bits: bits(r.forward), inverse_bits: bits(r.inverse),
+        iso_light: [2, -3, -5], iso_light_bits: bits(isoLight(c, [2, -3, -5])),                 // ISORenderer.js:35-39 default
+        iso_light2: [0.25, 1.5, 0.1], iso_light2_bits: bits(isoLight(c, [0.25, 1.5, 0.1])),
     });
 }
 fs.writeFileSync(path.join(__dirname, 'mvp_inverse.json'), JSON.stringify(out, null, 1));

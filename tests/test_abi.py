@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_header_is_plain_c():
     """the boundary is a C ABI: compiles as C11 with gcc, no C++/torch types"""
-    src = '#include "vpt.h"\nint main(void){ vpt_uniforms u; (void)u; return sizeof(vpt_uniforms) == 112 ? 0 : 1; }\n'
+    src = '#include "vpt.h"\nint main(void){ vpt_uniforms u; (void)u; return sizeof(vpt_uniforms) == 128 ? 0 : 1; }\n'
     exe = "/tmp/vpt_abi_check"
     subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe],
                    input=src.encode(), check=True)
@@ -40,8 +40,9 @@ def test_header_is_plain_c():
 
 def test_uniforms_struct_layout_matches_binding():
     from vpt_amd import _native as N
-    assert C.sizeof(N.Uniforms) == 112
+    assert C.sizeof(N.Uniforms) == 128
     assert N.Uniforms.rand_seed.offset == 64 and N.Uniforms.light_direction.offset == 92 and N.Uniforms.blur.offset == 108
+    assert N.Uniforms.isovalue.offset == 112 and N.Uniforms.gradient_step.offset == 116 and N.Uniforms.threshold.offset == 120
 
 
 def test_version_and_error_strings_without_gpu():

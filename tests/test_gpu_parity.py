@@ -330,7 +330,7 @@ def test_native_rccl_gather_single_rank(gpu_ctx, oracle):
 
 def test_errors_are_loud(gpu_ctx):
     with pytest.raises(RuntimeError, match="No suitable class"):
-        vpt_amd.RendererFactory('iso')
+        vpt_amd.RendererFactory('lao')
     r = vpt_amd.MIPRenderer(gpu_ctx, None, default_camera(), None, {'resolution': 32})
     r.reset()
     with pytest.raises(vpt_amd.VptError, match="no ready volume"):
@@ -470,6 +470,8 @@ def test_gpu_matches_committed_contract_digests(gpu_ctx):
         u.max_bounces = kw.get("max_bounces", 8); u.steps = kw.get("mcm_steps", 8)
         for i, v in enumerate(kw.get("light_dir", (0.0, 0.0, 1.0))):
             u.light_direction[i] = float(np.float32(v))
+        u.isovalue = float(np.float32(kw.get("isovalue", 0.5))); u.gradient_step = float(np.float32(kw.get("gradient_step", 0.005)))
+        u.threshold = float(np.float32(kw.get("threshold", 0.1)))
         N.check(L.vpt_renderer_reset(r._h, C.byref(u)))
         for k in range(sc["frames"]):
             u.rand_seed = seq(k + 2); u.offset = seq(k + 2); u.mix = float(np.float32(1.0 / (k + 1)))

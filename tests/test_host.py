@@ -24,7 +24,8 @@ def test_renderer_factory_names():
     assert vpt_amd.RendererFactory('eam') is vpt_amd.EAMRenderer
     assert vpt_amd.RendererFactory('mcs') is vpt_amd.MCSRenderer
     assert vpt_amd.RendererFactory('mcm') is vpt_amd.MCMRenderer
-    for name in ('iso', 'lao', 'dos', 'depth', 'nope'):
+    assert vpt_amd.RendererFactory('iso') is vpt_amd.ISORenderer and vpt_amd.RendererFactory('depth') is vpt_amd.DepthRenderer
+    for name in ('lao', 'dos', 'nope'):
         with pytest.raises(RuntimeError, match='No suitable class'):      # RendererFactory.js:21
             vpt_amd.RendererFactory(name)
 

@@ -42,6 +42,11 @@ def test_mvp_inverse_matches_gl_matrix_fixture():
         t.localScale = c["model"]["scale"]
         m = mvp_inverse_matrix(cam, t)
         assert (m.view(np.uint32) == np.array(c["inverse_bits"], dtype=np.uint32)).all(), c["name"]
+        # ISORenderer.js:152-166: vec3.transformMat4 + vec3.normalize of the light direction
+        from vpt_amd.scene import iso_light_direction
+        for key in ("iso_light", "iso_light2"):
+            l = iso_light_direction(cam, t, c[key])
+            assert (l.view(np.uint32) == np.array(c[key + "_bits"], dtype=np.uint32)).all(), (c["name"], key)
 
 
 def test_default_scene_unprojects_to_survey_values(oracle):

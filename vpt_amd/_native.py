@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libvpt_hip.so")
 OK = 0
 OPTION_MCS_PERSISTENT = 0
 OPTION_MCM_PERSISTENT = 1
-RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM = 0, 1, 2, 3
+RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH = 0, 1, 2, 3, 4, 5
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 FORMAT_R8 = 0
 BUFFER_RENDER, BUFFER_FRAME, BUFFER_ACCUM = 0, 1, 2
@@ -53,6 +53,7 @@ class Uniforms(C.Structure):
         ("max_bounces", C.c_uint32), ("steps", C.c_uint32),
         ("light_direction", C.c_float * 3),
         ("mix", C.c_float), ("blur", C.c_float),
+        ("isovalue", C.c_float), ("gradient_step", C.c_float), ("threshold", C.c_float), ("reserved", C.c_float),
     ]
 
 

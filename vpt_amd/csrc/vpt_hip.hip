@@ -12,6 +12,7 @@
 
 #include "../../include/vpt.h"
 #include "vpt_kernels.h"
+#include "vpt_kernels_iso_depth.h"
 #include "vpt_srgb_lut.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -99,6 +100,8 @@ static size_t frame_elem(int kind) {
         case VPT_RENDERER_MIP: return 1;
         case VPT_RENDERER_EAM: return 4;
         case VPT_RENDERER_MCS: return 16;
+        case VPT_RENDERER_ISO: return 8;      // RGBA16F (ISORenderer.js:165-197)
+        case VPT_RENDERER_DEPTH: return 4;    // R32F (DepthRenderer.js:165-189)
         default: return 0;
     }
 }
@@ -377,7 +380,7 @@ extern "C" int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba
 }
 extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int height, vpt_renderer **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
-    if (kind < VPT_RENDERER_MIP || kind > VPT_RENDERER_MCM) return fail(VPT_ERR_INVALID, "No suitable class");  // RendererFactory.js:21
+    if (kind < VPT_RENDERER_MIP || kind > VPT_RENDERER_DEPTH) return fail(VPT_ERR_INVALID, "No suitable class");  // RendererFactory.js:21
     if (width < 1 || height < 1 || width > 32768 || height > 32768) return fail(VPT_ERR_INVALID, "resolution %dx%d out of range", width, height);
     HIP_TRY(hipSetDevice(c->device));
     vpt_renderer *r = new vpt_renderer();
@@ -483,6 +486,7 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         a->max_bounces = u->max_bounces; a->steps = u->steps;
         a->light = f3{ u->light_direction[0], u->light_direction[1], u->light_direction[2] };
         a->mix = u->mix; a->blur = u->blur;
+        a->isovalue = u->isovalue; a->gradient_step = u->gradient_step; a->threshold = u->threshold;
     }
     a->inv_w = (float)(1.0 / (double)r->W);     // gl.uniform2f(uInverseResolution, 1/res, 1/res): MCMRenderer.js:91,155
     a->inv_h = (float)(1.0 / (double)r->H);
@@ -522,6 +526,11 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
 #define K_EAM1(V) (k_eam<1, V | VPT_V_ALIGNED>)
 #define K_MCS0(V) (k_mcs<0, V>)
 #define K_MCS1(V) (k_mcs<1, V>)
+#define K_ISO0(V) (k_iso<0, V>)
+#define K_ISO1(V) (k_iso<1, V>)
+#define K_ISOR(V) (k_iso_render<V>)
+#define K_DEPTH0(V) (k_depth<0, V>)
+#define K_DEPTH1(V) (k_depth<1, V>)
 #define K_MCM0(V) (k_mcm_integrate<false, V>)
 #define K_MCM1(V) (k_mcm_integrate<true, V>)
 
@@ -580,6 +589,11 @@ static int check_step(const vpt_uniforms *u) {
     return VPT_OK;
 }
 
+static int check_iso(const vpt_uniforms *u) {
+    if (u->steps < 1 || u->steps > 65536) return fail(VPT_ERR_INVALID, "ISO steps %u outside [1, 65536]", u->steps);   // ISORenderer.js:20-25: min 1
+    return VPT_OK;
+}
+
 struct Timed {   // HIP events around the dominant kernel (or around one graph replay of `launches` of them)
     vpt_renderer *r; bool on; size_t idx;
     Timed(vpt_renderer *r_, bool dominant, uint32_t launches = 1) : r(r_), on(r_->profiling && dominant), idx(0) {
@@ -611,6 +625,8 @@ extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_EAM: LAUNCH(k_eam_reset, r, a, 0); break;
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_reset, r, a, 0); break;
         case VPT_RENDERER_MCM: LAUNCH(k_mcm_reset, r, a, 0); break;
+        case VPT_RENDERER_ISO: LAUNCH(k_iso_reset, r, a, 0); break;
+        case VPT_RENDERER_DEPTH: LAUNCH(k_depth_reset, r, a, 0); break;
     }
     HIP_TRY(hipGetLastError());
     return VPT_OK;
@@ -620,6 +636,7 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
     if (r->kind == VPT_RENDERER_MCM) return VPT_OK;                 // MCMRenderer.js:118-119: empty
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind != VPT_RENDERER_MCS) VPT_TRY(check_step(u));
+    if (r->kind == VPT_RENDERER_ISO) VPT_TRY(check_iso(u));
     PassArgs a;
     VPT_TRY(make_args(r, u, true, &a));
     {
@@ -627,6 +644,8 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
         switch (r->kind) {
             case VPT_RENDERER_MIP: LAUNCH_S(K_MIP0, r, a); break;
             case VPT_RENDERER_EAM: LAUNCH_S(K_EAM0, r, a); break;
+            case VPT_RENDERER_ISO: LAUNCH_S(K_ISO0, r, a); break;
+            case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH0, r, a); break;
             case VPT_RENDERER_MCS: if (r->mcs_persistent) LAUNCH_MCS_PERSIST(0, r, a); else LAUNCH_S(K_MCS0, r, a); break;
         }
     }
@@ -642,6 +661,8 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_MIP: LAUNCH(k_mip_integrate, r, a, 0); break;
         case VPT_RENDERER_EAM: LAUNCH(k_eam_integrate, r, a, 0); break;
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_integrate, r, a, 0); break;
+        case VPT_RENDERER_ISO: LAUNCH(k_iso_integrate, r, a, 0); break;
+        case VPT_RENDERER_DEPTH: LAUNCH(k_depth_integrate, r, a, 0); break;
         case VPT_RENDERER_MCM: {
             Timed t(r, true);
             if (r->mcm_persistent) LAUNCH_MCM_PERSIST(false, r, a); else LAUNCH_S(K_MCM0, r, a);
@@ -654,9 +675,12 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
 extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
     HIP_TRY(hipSetDevice(r->ctx->device));
+    if (r->kind == VPT_RENDERER_ISO && !u) return fail(VPT_ERR_INVALID, "ISO renderFrame needs uniforms (uLight, uGradientStep)");
     PassArgs a;
-    VPT_TRY(make_args(r, u, false, &a));
+    VPT_TRY(make_args(r, u, r->kind == VPT_RENDERER_ISO, &a));     // the ISO render pass samples the volume
     switch (r->kind) {
+        case VPT_RENDERER_ISO: LAUNCH_S(K_ISOR, r, a); break;
+        case VPT_RENDERER_DEPTH: LAUNCH(k_depth_render, r, a, 0); break;
         case VPT_RENDERER_MIP: LAUNCH(k_mip_render, r, a, 0); break;
         case VPT_RENDERER_EAM: LAUNCH(k_eam_render, r, a, 0); break;
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_render, r, a, 0); break;
@@ -670,6 +694,8 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
     switch (r->kind) {
         case VPT_RENDERER_MIP: LAUNCH_S(K_MIP1, r, a); break;
         case VPT_RENDERER_EAM: LAUNCH_S(K_EAM1, r, a); break;
+        case VPT_RENDERER_ISO: LAUNCH_S(K_ISO1, r, a); break;
+        case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH1, r, a); break;
         case VPT_RENDERER_MCS: if (r->mcs_persistent) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
         case VPT_RENDERER_MCM:
             if (r->mcm_persistent) LAUNCH_MCM_PERSIST(true, r, a); else LAUNCH_S(K_MCM1, r, a);
@@ -680,7 +706,8 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
 extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(r->ctx->device));
-    if (r->kind == VPT_RENDERER_MIP || r->kind == VPT_RENDERER_EAM) VPT_TRY(check_step(u));
+    if (r->kind == VPT_RENDERER_MIP || r->kind == VPT_RENDERER_EAM || r->kind == VPT_RENDERER_ISO || r->kind == VPT_RENDERER_DEPTH) VPT_TRY(check_step(u));
+    if (r->kind == VPT_RENDERER_ISO) VPT_TRY(check_iso(u));
     PassArgs a;
     VPT_TRY(make_args(r, u, true, &a));
     {

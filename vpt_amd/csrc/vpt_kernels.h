@@ -70,6 +70,7 @@ struct PassArgs {
     uint32_t max_bounces, steps;
     f3 light;
     float mix, blur, inv_w, inv_h;
+    float isovalue, gradient_step, threshold;   // ISO / Depth (vpt_kernels_iso_depth.h)
     void *frame;                 // tile order
     void *acc;                   // tile order (ping-pong collapsed: each pixel reads and writes only itself)
     float4 *st0, *st1, *st2, *st3;   // MCM photon state, tile order

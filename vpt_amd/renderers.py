@@ -182,6 +182,10 @@ class AbstractRenderer(PropertyBag):
                 arr = np.empty((rows, w), dtype=np.uint8)
             elif self._KIND == N.RENDERER_EAM:
                 arr = np.empty((rows, w, 4), dtype=np.uint8)
+            elif self._KIND == N.RENDERER_ISO:
+                arr = np.empty((rows, w, 4), dtype=np.float16)
+            elif self._KIND == N.RENDERER_DEPTH:
+                arr = np.empty((rows, w), dtype=np.float32)
             else:
                 arr = np.empty((rows, w, 4), dtype=np.float32)
         else:
@@ -457,13 +461,122 @@ class MCMRenderer(AbstractRenderer):
         N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
 
 
-for _cls in (MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer):
+
+class ISORenderer(AbstractRenderer):
+    """src/js/renderers/ISORenderer.js:13-199"""
+    _KIND = N.RENDERER_ISO
+
+    def __init__(self, gl, volume, camera, environmentTexture, options=None):
+        super().__init__(gl, volume, camera, environmentTexture, options)
+        self.registerProperties([                                  # :17-46
+            {'name': 'steps', 'label': 'Steps', 'type': 'spinner', 'value': 50, 'min': 1},
+            {'name': 'isovalue', 'label': 'Isovalue', 'type': 'slider', 'value': 0.5, 'min': 0, 'max': 1},
+            {'name': 'light', 'label': 'Light direction', 'type': 'vector-spinner', 'value': [2, -3, -5]},
+            dict(_TF_PROPERTY),
+        ])
+        _install_change_handler(self, ('isovalue', 'transferFunction'))      # :48-61 (steps and light do NOT reset)
+
+    def _resetFrame(self):                                         # :75-82
+        N.check(N.lib().vpt_renderer_reset(self._h, None))
+
+    def _prepare_generate(self):                                   # :84-116
+        u = self._new_uniforms()
+        u.steps = int(self.steps)
+        u.step_size = _f32(np.float32(1.0) / np.float32(int(self.steps)))   # the shader's 1.0 / float(uSteps), ISORenderer.glsl:64
+        u.offset = _f32(self.rng())
+        u.isovalue = _f32(self.isovalue)
+        self._u = u
+        return u
+
+    def _prepare_render(self):                                     # :136-171
+        from .scene import iso_light_direction
+        light = iso_light_direction(self._camera, self._volumeTransform, self.light)
+        for i in range(3):
+            self._u.light_direction[i] = float(light[i])
+        self._u.gradient_step = _f32(0.005)                        # :168
+        return self._u
+
+    def _generateFrame(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_generate(self._h, C.byref(self._prepare_generate())))
+
+    def _integrateFrame(self):                                     # :118-134
+        N.check(N.lib().vpt_renderer_integrate(self._h, C.byref(self._u)))
+
+    def _renderFrame(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_render_frame(self._h, C.byref(self._prepare_render())))
+
+    def _prepare_frame_uniforms(self):
+        self._prepare_generate()
+        return self._prepare_render()
+
+    def _renderFused(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
+
+
+class DepthRenderer(AbstractRenderer):
+    """src/js/renderers/DepthRenderer.js:13-191"""
+    _KIND = N.RENDERER_DEPTH
+
+    def __init__(self, gl, volume, camera, environmentTexture, options=None):
+        super().__init__(gl, volume, camera, environmentTexture, options)
+        self.registerProperties([                                  # :17-53
+            {'name': 'extinction', 'label': 'Extinction', 'type': 'spinner', 'value': 100, 'min': 0},
+            {'name': 'slices', 'label': 'Slices', 'type': 'spinner', 'value': 64, 'min': 1},
+            {'name': 'threshold', 'label': 'Threshold', 'type': 'slider', 'value': 0.1, 'min': 0, 'max': 1},
+            {'name': 'random', 'label': 'Random', 'type': 'checkbox', 'value': False},
+            dict(_TF_PROPERTY),
+        ])
+        _install_change_handler(self, ('extinction', 'slices', 'threshold', 'random', 'transferFunction'))   # :55-70
+        self._frameNumber = 0
+
+    def _resetFrame(self):                                         # :86-95
+        N.check(N.lib().vpt_renderer_reset(self._h, None))
+        self._frameNumber = 0
+
+    def _prepare_generate(self):                                   # :97-131
+        u = self._new_uniforms()
+        u.step_size = _f32(1 / self.slices)
+        u.extinction = _f32(self.extinction)
+        u.threshold = _f32(self.threshold)
+        u.offset = _f32(self.rng()) if self.random else 0.0
+        self._frameNumber += 1
+        self._u = u
+        return u
+
+    def _prepare_integrate(self):                                  # :146
+        self._u.mix = _f32(1 / self._frameNumber)
+        return self._u
+
+    def _generateFrame(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_generate(self._h, C.byref(self._prepare_generate())))
+
+    def _integrateFrame(self):                                     # :133-149
+        N.check(N.lib().vpt_renderer_integrate(self._h, C.byref(self._prepare_integrate())))
+
+    def _renderFrame(self):                                        # :151-163
+        N.check(N.lib().vpt_renderer_render_frame(self._h, None))
+
+    def _prepare_frame_uniforms(self):
+        self._prepare_generate()
+        return self._prepare_integrate()
+
+    def _renderFused(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
+
+
+for _cls in (MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer, ISORenderer, DepthRenderer):
     _cls._BASE = _cls
 
 
 def RendererFactory(which):
-    """src/js/renderers/RendererFactory.js:10-23 ('iso', 'lao', 'dos', 'depth' are outside this path)."""
-    classes = {'mip': MIPRenderer, 'eam': EAMRenderer, 'mcs': MCSRenderer, 'mcm': MCMRenderer}
+    """src/js/renderers/RendererFactory.js:10-23 ('lao' and 'dos' are not built)."""
+    classes = {'mip': MIPRenderer, 'eam': EAMRenderer, 'mcs': MCSRenderer, 'mcm': MCMRenderer,
+               'iso': ISORenderer, 'depth': DepthRenderer}
     if which not in classes:
         raise RuntimeError('No suitable class')
     return classes[which]

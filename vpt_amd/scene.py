@@ -36,6 +36,28 @@ class vec3:
         out[0], out[1], out[2] = 1.0 / float(a[0]), 1.0 / float(a[1]), 1.0 / float(a[2])
         return out
 
+    @staticmethod
+    def transformMat4(out, a, m):
+        """gl-matrix 3.4.1 vec3.transformMat4: homogeneous transform with w = 1, divided by the resulting w (or 1 if 0)"""
+        x, y, z = float(a[0]), float(a[1]), float(a[2])
+        m = [float(v) for v in m]
+        w = m[3] * x + m[7] * y + m[11] * z + m[15]
+        w = w or 1.0
+        out[0] = (m[0] * x + m[4] * y + m[8] * z + m[12]) / w
+        out[1] = (m[1] * x + m[5] * y + m[9] * z + m[13]) / w
+        out[2] = (m[2] * x + m[6] * y + m[10] * z + m[14]) / w
+        return out
+
+    @staticmethod
+    def normalize(out, a):
+        """gl-matrix 3.4.1 vec3.normalize"""
+        x, y, z = float(a[0]), float(a[1]), float(a[2])
+        length = x * x + y * y + z * z
+        if length > 0:
+            length = 1 / math.sqrt(length)
+        out[0], out[1], out[2] = x * length, y * length, z * length
+        return out
+
 
 class quat:
     @staticmethod
@@ -360,6 +382,21 @@ def default_camera(aspect=1.0):
     cam.aspect = aspect
     node.components.append(cam)
     return node
+
+
+def iso_light_direction(camera, volume_transform, light):
+    """ISORenderer.js:152-166: the light direction is given in view space; take it to model space and normalise."""
+    centerMatrix = mat4.fromTranslation(mat4.create(), [-0.5, -0.5, -0.5])
+    modelMatrix = volume_transform.globalMatrix
+    viewMatrix = camera.transform.inverseGlobalMatrix
+    matrix = mat4.create()
+    mat4.multiply(matrix, centerMatrix, matrix)
+    mat4.multiply(matrix, modelMatrix, matrix)
+    mat4.multiply(matrix, viewMatrix, matrix)
+    mat4.invert(matrix, matrix)
+    out = vec3.transformMat4(vec3.create(), light, matrix)
+    vec3.normalize(out, out)
+    return out
 
 
 def mvp_inverse_matrix(camera, volume_transform):
