@@ -1,0 +1,141 @@
+"""GPU: randomised differential test — random volumes (1..48 voxels per axis, non-cubic), image sizes (1..200 pixels, odd),
+cameras (outside, inside, grazing, looking away), transfer functions (1..256 wide, 1..3 rows), environment maps,
+filters and renderer parameters (zero extinction, zero bounces, one step, strong anisotropy ...), several frames
+each — every buffer of every pass must equal the CPU oracle bit for bit.  Seeds are fixed: the cases never change."""
+import math
+
+import numpy as np
+import pytest
+
+import vpt_amd
+from vpt_amd import _native as N
+from vpt_amd.scene import Node, Transform, PerspectiveCamera, quat, mvp_inverse_matrix, iso_light_direction
+from vpt_amd.synthetic import GoldenRatioRng
+
+pytestmark = pytest.mark.gpu
+
+MCM_BUFFERS = [N.BUFFER_MCM_POSITION, N.BUFFER_MCM_DIRECTION, N.BUFFER_MCM_TRANSMITTANCE, N.BUFFER_MCM_RADIANCE]
+KINDS = ["mip", "eam", "mcs", "mcm", "iso", "depth"]
+
+
+def same_bits(got, want, what):
+    g = np.ascontiguousarray(got).view(np.uint8).reshape(-1); w = np.ascontiguousarray(want).view(np.uint8).reshape(-1)
+    assert g.shape == w.shape, what
+    bad = np.nonzero(g != w)[0]
+    assert bad.size == 0, "%s: %d of %d bytes differ, first at byte %d" % (what, bad.size, g.size, bad[0])
+
+
+def random_camera(rng, aspect):
+    """a camera somewhere around (or inside) the unit cube's model space [-0.5, 0.5]^3, random orientation and lens"""
+    node = Node()
+    mode = rng.integers(0, 4)
+    if mode == 0:                                    # orbiting, looking roughly at the centre
+        yaw, pitch, dist = rng.uniform(-math.pi, math.pi), rng.uniform(-1.2, 1.2), rng.uniform(0.9, 3.0)
+    elif mode == 1:                                  # inside the volume
+        yaw, pitch, dist = rng.uniform(-math.pi, math.pi), rng.uniform(-1.2, 1.2), rng.uniform(0.0, 0.45)
+    elif mode == 2:                                  # close to a face: grazing rays
+        yaw, pitch, dist = rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(0.5, 0.6)
+    else:                                            # far away, narrow part of the image covered
+        yaw, pitch, dist = rng.uniform(-math.pi, math.pi), rng.uniform(-0.5, 0.5), rng.uniform(4.0, 9.0)
+    qy = quat.setAxisAngle(quat.create(), [0, 1, 0], yaw)
+    qx = quat.setAxisAngle(quat.create(), [1, 0, 0], pitch)
+    q = quat.multiply(quat.create(), qy, qx)
+    if rng.uniform() < 0.25:                         # looking somewhere else entirely
+        q = quat.multiply(quat.create(), q, quat.setAxisAngle(quat.create(), [0, 1, 0], rng.uniform(0.5, 2.5)))
+    node.transform.localRotation = q
+    cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+    off = rng.uniform(-0.2, 0.2, size=3) if mode != 2 else np.zeros(3)
+    node.transform.localTranslation = [dist * sy * cp + off[0], -dist * sp + off[1], dist * cy * cp + off[2]]
+    cam = PerspectiveCamera(node, {'fovy': float(rng.uniform(0.3, 1.6)), 'aspect': aspect,
+                                   'near': float(rng.choice([0.01, 0.1, 0.5])), 'far': float(rng.choice([10.0, 100.0]))})
+    node.components.append(cam)
+    return node
+
+
+def random_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    dims = tuple(int(v) for v in rng.integers(1, 49, size=3))                      # (nz, ny, nx)
+    if seed % 7 == 0:
+        dims = (1, 1, 1)
+    style = rng.integers(0, 3)
+    if style == 0:
+        vol = rng.integers(0, 256, size=dims, dtype=np.uint8)
+    elif style == 1:
+        z, y, x = np.meshgrid(*[np.linspace(-1, 1, n) for n in dims], indexing='ij')
+        vol = np.clip(255 * (1.0 - np.sqrt(x * x + y * y + z * z) / 1.1) + rng.normal(0, 12, size=dims), 0, 255).astype(np.uint8)
+    else:
+        vol = np.full(dims, int(rng.integers(0, 256)), dtype=np.uint8)
+    w, h = int(rng.integers(1, 200)), int(rng.integers(1, 140))
+    tf_w, tf_h = int(rng.choice([1, 2, 3, 7, 64, 256])), int(rng.choice([1, 1, 3]))
+    tf = rng.integers(0, 256, size=(tf_h, tf_w, 4), dtype=np.uint8)
+    if rng.uniform() < 0.3:
+        tf = None
+    env = rng.integers(0, 256, size=(int(rng.integers(1, 6)), int(rng.integers(1, 9)), 4), dtype=np.uint8) if rng.uniform() < 0.4 else None
+    filt = "nearest" if rng.uniform() < 0.3 else "linear"
+    model = Transform(Node())
+    if rng.uniform() < 0.5:
+        model.localScale = [float(v) for v in rng.uniform(0.5, 1.8, size=3)]
+        model.localTranslation = [float(v) for v in rng.uniform(-0.2, 0.2, size=3)]
+        model.localRotation = quat.setAxisAngle(quat.create(), [0.3, 0.8, 0.52], float(rng.uniform(-1, 1)))
+    return rng, vol, (w, h), tf, env, filt, model
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scene(gpu_ctx, oracle, kind, seed):
+    rng, vol, (w, h), tf, env, filt, model = random_case(seed * 6 + KINDS.index(kind))
+    camera = random_camera(rng, w / h)
+    m = mvp_inverse_matrix(camera, model)
+    osc = oracle.OracleScene(vol, filt, tf=tf, env=env)
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, filt)
+    fused = bool(rng.integers(0, 2))
+    start = int(rng.integers(1, 50))
+    r = vpt_amd.RendererFactory(kind)(gpu_ctx, gvol, camera, env, {'resolution': (w, h), 'transform': model, 'rng': GoldenRatioRng(start), 'fused': fused})
+    if tf is not None:
+        r.setTransferFunction(tf)
+    if kind == "mip":
+        r.steps = int(rng.choice([1, 2, 3, 17, 64, 100]))
+    elif kind == "eam":
+        r.slices = int(rng.choice([1, 5, 33, 64])); r.extinction = float(rng.choice([0.0, 1.0, 40.0, 300.0])); r.random = bool(rng.integers(0, 2))
+    elif kind == "mcs":
+        r.extinction = float(rng.choice([0.0, 0.5, 5.0, 60.0]))
+    elif kind == "mcm":
+        r.extinction = float(rng.choice([0.0, 1.0, 7.0, 80.0])); r.anisotropy = float(rng.choice([0.0, 0.0, 0.9, -0.7, 1e-6]))
+        r.bounces = int(rng.choice([0, 1, 8])); r.steps = int(rng.choice([1, 3, 8]))
+    elif kind == "iso":
+        r.steps = int(rng.choice([1, 2, 7, 50])); r.isovalue = float(rng.choice([0.0, 0.2, 0.5, 1.0])); r.light = [float(v) for v in rng.uniform(-3, 3, size=3)]
+    elif kind == "depth":
+        r.slices = int(rng.choice([1, 9, 64])); r.extinction = float(rng.choice([0.0, 10.0, 100.0])); r.threshold = float(rng.choice([0.0, 0.1, 0.9])); r.random = bool(rng.integers(0, 2))
+    o = oracle.OracleRenderer(kind, osc, w, h)
+    what = "%s seed %d (%dx%d image, volume %s, %s, fused=%s)" % (kind, seed, w, h, vol.shape, filt, fused)
+
+    def frame_of(u):
+        fr = oracle.make_frame(w, h, np.array(list(u.mvp_inverse), np.float32))
+        fr.seed = u.rand_seed; fr.offset = u.offset; fr.step = u.step_size
+        fr.extinction = u.extinction; fr.anisotropy = u.anisotropy; fr.max_bounces = u.max_bounces; fr.steps = u.steps
+        for i in range(3):
+            fr.light_dir[i] = u.light_direction[i]
+        fr.mix = u.mix; fr.blur = u.blur
+        fr.isovalue = u.isovalue; fr.gradient_step = u.gradient_step; fr.threshold = u.threshold
+        return fr
+
+    r.reset()
+    if kind == "mcm":
+        o.reset(oracle.make_frame(w, h, m, seed=np.float32(GoldenRatioRng(start)())))      # MCMRenderer.js:93: the reset's own draw
+        for b, s in zip(MCM_BUFFERS, o.state):
+            same_bits(r.read(b), s, what + " reset buffer %d" % b)
+    else:
+        o.reset(oracle.make_frame(w, h, m))
+    for k in range(3):
+        r.render()
+        o.render(frame_of(r._u))
+        if kind == "mcm":
+            for b, s in zip(MCM_BUFFERS, o.state):
+                same_bits(r.read(b), s, what + " state %d pass %d" % (b, k))
+        else:
+            if not fused:
+                same_bits(r.read(N.BUFFER_FRAME), o.frame, what + " frame %d" % k)
+            same_bits(r.read(N.BUFFER_ACCUM), o.acc, what + " accumulation %d" % k)
+        same_bits(r.getTexture().view(np.uint16), o.out, what + " render %d" % k)
+    assert r.sample_count() == o.samples, what
+    r.destroy(); gvol.destroy()

@@ -217,7 +217,15 @@ VPT_DEV f3 random_sphere(uint32_t &state) {
 // ---- render-target conversions --------------------------------------------------------------
 VPT_DEV uint32_t to_unorm8(float f) { return (uint32_t)rintf(vclamp01(f) * 255.0f); }   // NaN -> 0 (maxNum)
 VPT_DEV float from_unorm8(uint32_t c) { return (float)c / 255.0f; }
-VPT_DEV uint16_t to_half_bits(float f) { return __half_as_ushort(__float2half_rn(f)); }
+// RGBA16F write: RNE conversion of the ALREADY ROUNDED fp32 value (a shader outputs fp32; the render target converts).
+// Written as an opaque instruction: given `(half)fma(a, b, c)` or `(half)(a * b)` the compiler otherwise selects
+// v_fma_mixlo_f16, which rounds the exact result ONCE to half — a different value in the rare double-rounding cases
+// (found by tests/test_gpu_fuzz.py: 1 pixel in 5760 of a Depth frame).
+VPT_DEV uint16_t to_half_bits(float f) {
+    uint32_t h;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(f));
+    return (uint16_t)h;
+}
 
 // ---- ray set-up -----------------------------------------------------------------------------
 struct Mat4 { float m[16]; };
