@@ -20,7 +20,7 @@ KINDS = ["mip", "eam", "mcs", "mcm", "iso", "depth"]
 
 def same_bits(got, want, what):
     g = np.ascontiguousarray(got).view(np.uint8).reshape(-1); w = np.ascontiguousarray(want).view(np.uint8).reshape(-1)
-    assert g.shape == w.shape, what
+    assert g.shape == w.shape, "%s: shapes %r vs %r" % (what, np.shape(got), np.shape(want))
     bad = np.nonzero(g != w)[0]
     assert bad.size == 0, "%s: %d of %d bytes differ, first at byte %d" % (what, bad.size, g.size, bad[0])
 
@@ -90,7 +90,17 @@ def test_random_scene(gpu_ctx, oracle, kind, seed):
     gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, filt)
     fused = bool(rng.integers(0, 2))
     start = int(rng.integers(1, 50))
-    r = vpt_amd.RendererFactory(kind)(gpu_ctx, gvol, camera, env, {'resolution': (w, h), 'transform': model, 'rng': GoldenRatioRng(start), 'fused': fused})
+    opts = {'resolution': (w, h), 'transform': model, 'rng': GoldenRatioRng(start), 'fused': fused}
+    if rng.uniform() < 0.3:                           # one rank of a row-sharded run: its rows must be the oracle's rows
+        world = int(rng.integers(2, 6))
+        opts['shard'] = (int(rng.integers(0, world)), world, int(rng.choice([1, 3, 8, 16])))
+    r = vpt_amd.RendererFactory(kind)(gpu_ctx, gvol, camera, env, opts)
+    rows = r.global_rows()
+    valid = rows >= 0
+
+    def same_rows(got, want, msg):
+        same_bits(np.ascontiguousarray(got).reshape(len(rows), -1)[valid], np.ascontiguousarray(want).reshape(h, -1)[rows[valid]], msg)
+
     if tf is not None:
         r.setTransferFunction(tf)
     if kind == "mip":
@@ -107,7 +117,7 @@ def test_random_scene(gpu_ctx, oracle, kind, seed):
     elif kind == "depth":
         r.slices = int(rng.choice([1, 9, 64])); r.extinction = float(rng.choice([0.0, 10.0, 100.0])); r.threshold = float(rng.choice([0.0, 0.1, 0.9])); r.random = bool(rng.integers(0, 2))
     o = oracle.OracleRenderer(kind, osc, w, h)
-    what = "%s seed %d (%dx%d image, volume %s, %s, fused=%s)" % (kind, seed, w, h, vol.shape, filt, fused)
+    what = "%s seed %d (%dx%d image, volume %s, %s, fused=%s, shard=%s)" % (kind, seed, w, h, vol.shape, filt, fused, opts.get('shard'))
 
     def frame_of(u):
         fr = oracle.make_frame(w, h, np.array(list(u.mvp_inverse), np.float32))
@@ -123,7 +133,7 @@ def test_random_scene(gpu_ctx, oracle, kind, seed):
     if kind == "mcm":
         o.reset(oracle.make_frame(w, h, m, seed=np.float32(GoldenRatioRng(start)())))      # MCMRenderer.js:93: the reset's own draw
         for b, s in zip(MCM_BUFFERS, o.state):
-            same_bits(r.read(b), s, what + " reset buffer %d" % b)
+            same_rows(r.read(b), s, what + " reset buffer %d" % b)
     else:
         o.reset(oracle.make_frame(w, h, m))
     for k in range(3):
@@ -131,11 +141,12 @@ def test_random_scene(gpu_ctx, oracle, kind, seed):
         o.render(frame_of(r._u))
         if kind == "mcm":
             for b, s in zip(MCM_BUFFERS, o.state):
-                same_bits(r.read(b), s, what + " state %d pass %d" % (b, k))
+                same_rows(r.read(b), s, what + " state %d pass %d" % (b, k))
         else:
             if not fused:
-                same_bits(r.read(N.BUFFER_FRAME), o.frame, what + " frame %d" % k)
-            same_bits(r.read(N.BUFFER_ACCUM), o.acc, what + " accumulation %d" % k)
-        same_bits(r.getTexture().view(np.uint16), o.out, what + " render %d" % k)
-    assert r.sample_count() == o.samples, what
+                same_rows(r.read(N.BUFFER_FRAME), o.frame, what + " frame %d" % k)
+            same_rows(r.read(N.BUFFER_ACCUM), o.acc, what + " accumulation %d" % k)
+        same_rows(r.getTexture().view(np.uint16), o.out, what + " render %d" % k)
+    if 'shard' not in opts:
+        assert r.sample_count() == o.samples, what
     r.destroy(); gvol.destroy()
