@@ -159,6 +159,11 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * segments (LDS tables staged once per workgroup), 2 = the same with the next segment's photon state prefetched under
  * the current segment's events.  Measured 4-8 % slower than one workgroup per tile (register pressure), kept as options. */
 #define VPT_OPTION_MCM_PERSISTENT 1
+/* VPT_OPTION_MCM_STAGGER: phase staggering of the MCM integrate kernel (timing only, results identical).  value =
+ * quantum in 10 ns ticks (bits 0..23) | pattern << 24; the workgroups resident at launch start g * quantum late
+ * (g = 0..3), which takes the chip's waves out of lockstep so that photon-state streaming overlaps event compute
+ * (DESIGN.md section 5).  0 = off. */
+#define VPT_OPTION_MCM_STAGGER 2
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
 /* volume samples executed since creation / last clear (SURVEY §8d metric) */
 VPT_API int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count);

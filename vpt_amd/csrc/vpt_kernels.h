@@ -71,6 +71,7 @@ struct PassArgs {
     f3 light;
     float mix, blur, inv_w, inv_h;
     float isovalue, gradient_step, threshold;   // ISO / Depth (vpt_kernels_iso_depth.h)
+    uint32_t stagger_ticks, stagger_blocks, stagger_pattern;   // MCM phase staggering (k_mcm_integrate), 0 = off
     void *frame;                 // tile order
     void *acc;                   // tile order (ping-pong collapsed: each pixel reads and writes only itself)
     float4 *st0, *st1, *st2, *st3;   // MCM photon state, tile order
@@ -751,11 +752,31 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
 template <bool FUSE_RENDER, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_integrate(PassArgs a) {
+    // Phase staggering.  Every wave of this kernel does load-state -> `steps` events -> store-state and takes the same
+    // time, so the resident waves of the whole chip run in lockstep: all load (HBM saturated, VALU idle), then all
+    // compute (HBM idle); measured frame time = stream time + compute time (42 us + 12 us * steps), no overlap.
+    // Delaying the first-round workgroups by g * quantum (g = 0..3) offsets the phases of four groups of waves; later
+    // workgroups inherit the offset because a slot is refilled when its workgroup retires.  Timing only: results unchanged.
+    if (a.stagger_ticks) {
+        uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin < a.stagger_blocks) {
+            uint32_t g = a.stagger_pattern ? ((lin >> 3) & 3u) : ((lin >> 8) & 3u);
+            uint64_t until = wall_clock64() + (uint64_t)g * a.stagger_ticks;          // 100 MHz constant clock
+            while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     apply_frame_table(a);
+#if defined(VPT_EXP) && VPT_EXP == 1
+    return;                                               // experiment: launch cost only
+#endif
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
+#if defined(VPT_EXP) && VPT_EXP == 2
+    if (a.steps == 12345u) a.st0[p.k] = make_float4(t.tf[0].x, 0, 0, 0);   // experiment: launch + LDS staging only
+    return;
+#endif
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     float4 s0 = a.st0[p.k], s1 = a.st1[p.k], s2 = a.st2[p.k], s3 = a.st3[p.k];
     Photon ph;
