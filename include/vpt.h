@@ -264,6 +264,11 @@ VPT_API int vpt_gather_read_frame(vpt_gather *g, void *host_dst, size_t nbytes);
 VPT_API int vpt_probe_math(vpt_context *ctx, int which, const float *in, float *out, size_t n);
 /* samples texture(uVolume, p) -> transfer function at n positions (xyz triples); out = n RGBA float4 */
 VPT_API int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n);
+/* the row re-assembly of a gathered frame (k_assemble_rows, used by vpt_gather_read_frame) run on host data:
+ * gathered = [world][local_rows][width] RGBA16F as the ranks' send buffers arrive, out = [height][width].  Lets a
+ * one-GPU box check the multi-rank assembly against an unsharded frame. */
+VPT_API int vpt_probe_assemble_rows(vpt_context *ctx, const void *gathered, int width, int height, int local_rows,
+                                    int world, int rows_per_block, void *out);
 /* measured HBM streaming-read rate: `iterations` grid-stride 16 B/lane reads of an nbytes scratch buffer (choose it far
  * larger than the 256 MB Infinity Cache); the second denominator SURVEY section 8d asks for next to the 8 TB/s peak */
 VPT_API int vpt_probe_stream_read(vpt_context *ctx, size_t nbytes, int iterations, double *gb_per_s);

@@ -538,3 +538,35 @@ def test_native_rccl_gather_play(gpu_ctx, oracle, root):
     assert_same_bits(shard.read(N.BUFFER_MCM_RADIANCE), plain.read(N.BUFFER_MCM_RADIANCE), "state")
     assert shard.sample_count() == plain.sample_count()
     g.destroy(); plain.destroy(); shard.destroy(); sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("world,rows", [(2, 8), (3, 5), (8, 8), (5, 16)])
+def test_multi_rank_frame_assembly(gpu_ctx, oracle, world, rows):
+    """what vpt_gather_read_frame does with a frame gathered from `world` ranks, emulated on one GPU: the ranks' send
+    buffers (local rows incl. padding) stacked as the gather delivers them, re-ordered by k_assemble_rows == unsharded frame"""
+    sc = Scene(gpu_ctx, oracle, 32, 100, 70, tf=colour_tf(64, 1), camera=orbit_camera(100 / 70))
+
+    def run(**opts):
+        r = sc.renderer('mcm', **opts)
+        r.extinction = 9
+        r.reset()
+        for _ in range(2):
+            r.render()
+        out = r.getTexture()
+        r.destroy()
+        return out
+
+    whole = run()
+    parts = [run(shard=(rank, world, rows)) for rank in range(world)]
+    assert len({p.shape for p in parts}) == 1                      # every rank pads to the same row count (equal-size gather)
+    gathered = np.ascontiguousarray(np.stack(parts))
+    out = np.empty_like(whole)
+    N.check(N.lib().vpt_probe_assemble_rows(gpu_ctx._h, gathered.ctypes.data_as(C.c_void_p), sc.w, sc.h, parts[0].shape[0], world, rows,
+                                            out.ctypes.data_as(C.c_void_p)))
+    assert_same_bits(out, whole, "assembled %d-rank frame" % world)
+    # the torch host's index table describes the same permutation
+    from vpt_amd.tiles import gather_index, local_rows
+    idx = gather_index(sc.h, world, rows)
+    flat = gathered.reshape(world * parts[0].shape[0], sc.w, 4)
+    assert_same_bits(flat[idx], whole, "gather_index permutation")
+    sc.gvol.destroy()

@@ -1245,6 +1245,31 @@ __global__ void k_assemble_rows(const uint2 *gathered, uint2 *out, int W, int H,
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < W; i += (int)(gridDim.x * blockDim.x)) out[(size_t)j * W + i] = src[i];
 }
 
+extern "C" int vpt_probe_assemble_rows(vpt_context *c, const void *gathered, int width, int height, int local_rows, int world,
+                                       int rows_per_block, void *out) {
+    if (!c || !gathered || !out) return fail(VPT_ERR_INVALID, "null argument");
+    if (width < 1 || height < 1 || local_rows < 1 || world < 1 || rows_per_block < 1) return fail(VPT_ERR_INVALID, "bad geometry");
+    // every global row must exist in its owner's block of the gathered buffer
+    int blocks = (height + rows_per_block - 1) / rows_per_block;
+    int max_local = ((blocks + world - 1) / world) * rows_per_block;
+    if (local_rows < max_local) return fail(VPT_ERR_INVALID, "local_rows %d < %d needed for %d rows over %d ranks", local_rows, max_local, height, world);
+    HIP_TRY(hipSetDevice(c->device));
+    size_t in_bytes = (size_t)world * local_rows * width * 8, out_bytes = (size_t)width * height * 8;
+    void *din = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&din, in_bytes));
+    hipError_t e = hipMalloc(&dout, out_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(din, gathered, in_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_assemble_rows, dim3((unsigned)((width + 255) / 256), (unsigned)height), dim3(256), 0, c->stream,
+                           (const uint2 *)din, (uint2 *)dout, width, height, local_rows, world, rows_per_block);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(din); if (dout) hipFree(dout);
+    if (e != hipSuccess) return fail(VPT_ERR_HIP, "assemble probe: %s", hipGetErrorString(e));
+    return VPT_OK;
+}
 extern "C" int vpt_gather_unique_id(void *id128) {
     if (!id128) return fail(VPT_ERR_INVALID, "id is null");
     VPT_TRY(rccl_load());
