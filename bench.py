@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--fused", type=int, default=1, help="0: run the three hooks as separate launches (profiling aid)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames enqueued per host call (vpt_*_play); 0 = 1 (frame by frame)")
+    ap.add_argument("--fused-passes", type=int, default=0,
+                    help="MCM, single GPU, with --frames-per-launch F: one launch runs F passes with the photon state in registers")
     ap.add_argument("--graph", type=int, default=1, help="replay frame sequences as a captured hipGraph (with --frames-per-launch > 1)")
     ap.add_argument("--gather-root", type=int, default=0,
                     help="native gather: rank that receives every frame (grouped ncclSend/ncclRecv); -1 = every rank (all_gather)")
@@ -184,7 +186,7 @@ def main():
             if native is not None:
                 native.play(n)                       # eager: graphs holding RCCL collectives are slower here
             else:
-                r.play(n, use_graph=bool(args.graph) and n == fpl)   # one cached graph: only full-size chunks replay it
+                r.play(n, use_graph=bool(args.graph) and n == fpl, fused=bool(args.fused_passes))   # one cached graph: only full-size chunks replay it
 
         def step(k):
             if native is not None:
@@ -313,7 +315,8 @@ def main():
                                    "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
                        "parallelism": ("image rows sharded over %d GPU(s), per-frame RCCL %s (%s pipeline)" % (
                            world, ("gather to rank %d" % args.gather_root) if (native is not None and args.gather_root >= 0) else "all_gather", args.gather)) if use_dist else "single GPU",
-                       "frames_per_launch": fpl, "hipgraph": bool(args.graph) and fpl > 1 and native is None,
+                       "frames_per_launch": fpl, "hipgraph": bool(args.graph) and fpl > 1 and native is None and not args.fused_passes,
+                       "fused_passes": bool(args.fused_passes) and fpl > 1,
                        "samples_per_step": samples / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

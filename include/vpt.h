@@ -139,10 +139,15 @@ VPT_API int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u);
 
 /* Frame sequences: `count` consecutive render() passes enqueued by ONE call.  `base` holds the uniforms the frames
  * share; frame_vars holds count x 8 floats {rand_seed, offset, mix, 0, light.x, light.y, light.z, 0} — the uniforms
- * that change per frame — which are uploaded to a device table read by the kernels through a device-side frame
- * counter.  With use_graph != 0 the launch sequence is captured once into a hipGraph and replayed (launch-bound
- * regimes: small per-GPU shards).  Results are identical to `count` calls of vpt_renderer_render. */
-VPT_API int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int use_graph);
+ * that change per frame.  mode VPT_PLAY_EAGER: count launches with the per-frame uniforms in their arguments.
+ * VPT_PLAY_GRAPH: the launch sequence is captured once into a hipGraph and replayed (uniforms from a device table read
+ * through a device-side frame counter).  VPT_PLAY_FUSED (MCM only): ONE launch runs all `count` passes of a pixel
+ * back to back with the photon state in registers — no state round trip through HBM between passes.  In every mode
+ * the buffers afterwards are identical to `count` calls of vpt_renderer_render. */
+#define VPT_PLAY_EAGER 0
+#define VPT_PLAY_GRAPH 1
+#define VPT_PLAY_FUSED 2
+VPT_API int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int mode);
 
 /* read-back (the reference never reads back; it hands getTexture() to the tone mapper). Row-major, local rows. */
 VPT_API int vpt_renderer_read(vpt_renderer *r, int buffer, void *host_dst, size_t nbytes);

@@ -508,6 +508,19 @@ def test_play_frame_sequences_equal_render_calls(gpu_ctx, oracle, kind):
     graph.play(4, use_graph=True); graph.play(4, use_graph=True)     # second call replays the cached graph
     assert_same_bits(graph.getTexture(), want_img, "%s graph play" % kind); assert_same_bits(graph.read(buf), want_buf, "%s graph play buffer" % kind)
     assert graph.sample_count() == want_ns
+    if kind == "mcm":
+        fusedr = make()
+        fusedr.play(4, fused=True); fusedr.play(1, fused=True); fusedr.render(); fusedr.play(4, fused=True)      # 10 passes, mixed with a plain render()
+        assert_same_bits(fusedr.getTexture(), want_img, "mcm fused passes"); assert_same_bits(fusedr.read(buf), want_buf, "mcm fused passes buffer")
+        for b in MCM_BUFFERS:
+            assert_same_bits(fusedr.read(b), ref.read(b), "mcm fused passes state %d" % b)
+        assert fusedr.sample_count() == want_ns
+        fusedr.play(2, use_graph=True); ref.render(); ref.render()          # the graph path's device frame counter stayed in step
+        assert_same_bits(fusedr.read(buf), ref.read(buf), "graph replay after fused passes")
+        fusedr.destroy()
+    else:
+        with pytest.raises(vpt_amd.VptError, match="MCM renderer only"):
+            eager.play(2, fused=True)
     for r in (ref, eager, graph):
         r.destroy()
     sc.gvol.destroy()

@@ -10,6 +10,7 @@ OK = 0
 OPTION_MCS_PERSISTENT = 0
 OPTION_MCM_PERSISTENT = 1
 OPTION_MCM_STAGGER = 2
+PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED = 0, 1, 2
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH = 0, 1, 2, 3, 4, 5
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 FORMAT_R8 = 0

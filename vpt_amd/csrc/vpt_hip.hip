@@ -779,6 +779,14 @@ static int play_upload_table(vpt_renderer *r, const float *vars, int count, Pass
     a->frame_mask = VPT_FRAME_RING - 1;
     return VPT_OK;
 }
+template <typename K>
+static int launch_multi(K kernel, vpt_renderer *r, const PassArgs &a, uint32_t npasses) {
+    size_t lds = lds_bytes(r);
+    if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a, npasses);
+    return VPT_OK;
+}
 static bool play_key_equal(const PassArgs &x, const PassArgs &y) { return memcmp(&x, &y, sizeof(PassArgs)) == 0; }
 
 extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int use_graph) {
@@ -787,7 +795,7 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
     HIP_TRY(hipSetDevice(c->device));
     PassArgs a;
     VPT_TRY(play_args(r, base, count, &a));
-    if (use_graph && r->warmed) {
+    if (use_graph == VPT_PLAY_GRAPH && r->warmed) {
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
         PlayGraph *g = r->play_graph;
         if (!g || g->with_gather || g->count != count || !play_key_equal(g->key, a)) {
@@ -811,6 +819,21 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
             HIP_TRY(hipGraphLaunch(g->exec, c->stream));
         }
         g->ran = true;
+    } else if (use_graph == VPT_PLAY_FUSED) {
+        if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "fused passes are implemented for the MCM renderer only");
+        VPT_TRY(play_upload_table(r, frame_vars, count, &a));
+        {
+            Timed t(r, true, (uint32_t)count);
+            switch ((r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0)) {
+                case 0: VPT_TRY(launch_multi(k_mcm_multi<0>, r, a, (uint32_t)count)); break;
+                case 1: VPT_TRY(launch_multi(k_mcm_multi<1>, r, a, (uint32_t)count)); break;
+                case 2: VPT_TRY(launch_multi(k_mcm_multi<2>, r, a, (uint32_t)count)); break;
+                default: VPT_TRY(launch_multi(k_mcm_multi<3>, r, a, (uint32_t)count)); break;
+            }
+        }
+        hipLaunchKernelGGL(k_advance_frames, dim3(1), dim3(1), 0, c->stream, r->frame_counter, (uint32_t)count);   // keeps the graph path's counter in step
+        HIP_TRY(hipGetLastError());
+        r->warmed = true;
     } else {
         const FrameVar *v = (const FrameVar *)frame_vars;
         for (int i = 0; i < count; i++) {

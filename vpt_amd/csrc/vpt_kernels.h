@@ -794,6 +794,40 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     if (FUSE_RENDER)
         a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f);
 }
+// `npasses` whole render() passes of one pixel in ONE launch (vpt_renderer_play, VPT_PLAY_FUSED): the photon state
+// stays in registers between passes — one 64 B read + 64 B write per pixel for the whole sequence instead of per pass —
+// and the launch / staging cost is paid once.  Pass f re-seeds from the f-th entry of the frame table exactly as
+// launch f of the unfused sequence would; the render buffer receives the last pass's radiance, which is all that is
+// left of the unfused sequence's render buffer as well.
+template <int V>
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_multi(PassArgs a, uint32_t npasses) {
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
+    float4 s0 = a.st0[p.k], s1 = a.st1[p.k], s2 = a.st2[p.k], s3 = a.st3[p.k];
+    Photon ph;
+    ph.position = f3{ s0.x, s0.y, s0.z };
+    ph.direction = f3{ s1.x, s1.y, s1.z };
+    ph.bounces = (uint32_t)(s1.w + 0.5f);
+    ph.transmittance = f3{ s2.x, s2.y, s2.z };
+    ph.radiance = f3{ s3.x, s3.y, s3.z };
+    ph.samples = (uint32_t)(s3.w + 0.5f);
+    uint32_t base = *a.frame_counter;
+    for (uint32_t f = 0; f < npasses; f++) {
+        a.seed = a.frame_table[(base + f) & a.frame_mask].seed;
+        mcm_events<V>(a, t, ph, px, py);
+        // the unfused sequence stores the counters as floats between passes and re-reads them with uint(w + 0.5):
+        // identical for every count below 2^24
+    }
+    a.st0[p.k] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
+    a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
+    a.st2[p.k] = make_float4(ph.transmittance.x, ph.transmittance.y, ph.transmittance.z, 0.0f);
+    a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
+    a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f);
+}
+__global__ void k_advance_frames(uint32_t *counter, uint32_t n) { *counter = *counter + n; }
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_render(PassArgs a) {   // MCMRenderer.glsl:204-206
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;

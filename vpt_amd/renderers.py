@@ -225,11 +225,13 @@ class AbstractRenderer(PropertyBag):
             vars_[k, 4:7] = list(u.light_direction)
         return u, vars_
 
-    def play(self, count, use_graph=True):
-        """`count` render() passes enqueued by one native call (optionally one hipGraph replay); same buffers as count x render()"""
+    def play(self, count, use_graph=True, fused=False):
+        """`count` render() passes enqueued by one native call: eager launches, one hipGraph replay (use_graph), or — MCM —
+        one launch running all passes with the photon state in registers (fused); same buffers as count x render()"""
         self._bind_volume()
         u, vars_ = self._collect_frames(count)
-        N.check(N.lib().vpt_renderer_play(self._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), count, 1 if use_graph else 0))
+        mode = N.PLAY_FUSED if fused else (N.PLAY_GRAPH if use_graph else N.PLAY_EAGER)
+        N.check(N.lib().vpt_renderer_play(self._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), count, mode))
 
     def set_option(self, option, value):
         N.check(N.lib().vpt_renderer_set_option(self._h, int(option), int(value)))
