@@ -110,6 +110,11 @@ def cpu_baseline_js(vol, args, matrix):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: RCCL prints its version banner to stdout when a communicator comes up,
+    # so everything before the result goes to stderr's descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch                       # first: its libamdhip64 is the one libvpt_hip.so binds to
     import torch.distributed as dist
@@ -184,7 +189,7 @@ def main():
         def step_many(n):
             """n frames by one native call: per-frame uniforms in a device table, optionally one hipGraph replay"""
             if native is not None:
-                native.play(n)                       # eager: graphs holding RCCL collectives are slower here (DESIGN.md section 7)
+                native.play(n, fused=bool(args.fused_passes))   # no graph mode: graphs holding RCCL collectives are slower here (DESIGN.md section 7)
             else:
                 r.play(n, use_graph=bool(args.graph) and n == fpl, fused=bool(args.fused_passes))   # one cached graph: only full-size chunks replay it
 
@@ -337,7 +342,10 @@ def main():
             except Exception as e:
                 out["cpu_baseline_js"] = {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
             out["host_cores"] = len(os.sched_getaffinity(0))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if native is not None:
         native.destroy()
     r.destroy(); gvol.destroy(); ctx.destroy()

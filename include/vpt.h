@@ -240,9 +240,11 @@ VPT_API int vpt_gather_destroy(vpt_gather *g);
 VPT_API int vpt_gather_set_root(vpt_gather *g, int root);
 /* render() of the renderer into the next send buffer + asynchronous gather of it */
 VPT_API int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u);
-/* `count` frames of the pipeline by one call (frame_vars as for vpt_renderer_play); always enqueued eagerly — a
- * captured graph holding RCCL collectives measured slower and unstable on this stack */
-VPT_API int vpt_gather_play(vpt_gather *g, const vpt_uniforms *base, const float *frame_vars, int count);
+/* `count` passes of the pipeline by one call (frame_vars as for vpt_renderer_play).  VPT_PLAY_EAGER: count frames, each
+ * rendered and gathered; VPT_PLAY_FUSED (MCM): the count passes run in one launch and the resulting frame is gathered
+ * once.  No graph mode — a captured graph holding RCCL collectives measured slower and unstable on this stack
+ * (DESIGN.md section 7). */
+VPT_API int vpt_gather_play(vpt_gather *g, const vpt_uniforms *base, const float *frame_vars, int count, int mode);
 /* blocks until every enqueued frame has been rendered and gathered */
 VPT_API int vpt_gather_synchronize(vpt_gather *g);
 /* the most recently gathered frame, rows put back in order: [height][width] RGBA16F -> host (blocks) */

@@ -373,10 +373,10 @@ static napi_value GatherRender(napi_env env, napi_callback_info info) {
     return undefined(env);
 }
 static napi_value GatherPlay(napi_env env, napi_callback_info info) {
-    napi_value a[3]; vpt_gather *g; const vpt_uniforms *u; const float *vars; int count;
-    if (!get_args(env, info, 3, a) || !get_handle(env, a[0], &g) || !get_uniforms(env, a[1], &u, false) ||
-        !get_frame_vars(env, a[2], &vars, &count)) return nullptr;
-    VPT_CHECK(vpt_gather_play(g, u, vars, count));
+    napi_value a[4]; vpt_gather *g; const vpt_uniforms *u; const float *vars; int count; int32_t mode;
+    if (!get_args(env, info, 4, a) || !get_handle(env, a[0], &g) || !get_uniforms(env, a[1], &u, false) ||
+        !get_frame_vars(env, a[2], &vars, &count) || !get_i32(env, a[3], &mode)) return nullptr;
+    VPT_CHECK(vpt_gather_play(g, u, vars, count, mode));
     return undefined(env);
 }
 static napi_value GatherSynchronize(napi_env env, napi_callback_info info) {
@@ -421,7 +421,8 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("gatherUniqueId", GatherUniqueId); EXPORT("gatherCreate", GatherCreate); EXPORT("gatherDestroy", GatherDestroy);
     EXPORT("gatherSetRoot", GatherSetRoot); EXPORT("gatherRender", GatherRender); EXPORT("gatherPlay", GatherPlay); EXPORT("gatherSynchronize", GatherSynchronize);
     EXPORT("gatherReadFrame", GatherReadFrame);
-    CONST(VPT_OPTION_MCS_PERSISTENT); CONST(VPT_OPTION_MCM_PERSISTENT);
+    CONST(VPT_OPTION_MCS_PERSISTENT); CONST(VPT_OPTION_MCM_PERSISTENT); CONST(VPT_OPTION_MCM_STAGGER);
+    CONST(VPT_PLAY_EAGER); CONST(VPT_PLAY_GRAPH); CONST(VPT_PLAY_FUSED);
     CONST(VPT_RENDERER_MIP); CONST(VPT_RENDERER_EAM); CONST(VPT_RENDERER_MCS); CONST(VPT_RENDERER_MCM);
     CONST(VPT_RENDERER_ISO); CONST(VPT_RENDERER_DEPTH);
     CONST(VPT_FILTER_NEAREST); CONST(VPT_FILTER_LINEAR); CONST(VPT_FORMAT_R8);

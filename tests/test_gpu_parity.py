@@ -548,6 +548,10 @@ def test_native_rccl_gather_play(gpu_ctx, oracle, root):
     for _ in range(4):
         plain.render()
     assert_same_bits(g.frame(), plain.getTexture(), "odd-length sequence then single frame")
+    g.play(5, fused=True)                                   # five passes in one launch, one gather
+    for _ in range(5):
+        plain.render()
+    assert_same_bits(g.frame(), plain.getTexture(), "fused passes then one gather")
     assert_same_bits(shard.read(N.BUFFER_MCM_RADIANCE), plain.read(N.BUFFER_MCM_RADIANCE), "state")
     assert shard.sample_count() == plain.sample_count()
     g.destroy(); plain.destroy(); shard.destroy(); sc.gvol.destroy()

@@ -105,7 +105,7 @@ def lib():
         "vpt_renderer_reset": [P, UP], "vpt_renderer_generate": [P, UP], "vpt_renderer_integrate": [P, UP],
         "vpt_renderer_render_frame": [P, UP], "vpt_renderer_render": [P, UP],
         "vpt_renderer_read": [P, I, P, SZ], "vpt_renderer_play": [P, UP, P, I, I],
-        "vpt_gather_play": [P, UP, P, I], "vpt_gather_set_root": [P, I],
+        "vpt_gather_play": [P, UP, P, I, I], "vpt_gather_set_root": [P, I],
         "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
         "vpt_renderer_set_render_target": [P, P, SZ],
         "vpt_renderer_set_option": [P, I, I],

@@ -1363,7 +1363,7 @@ static void profile_events(vpt_renderer *r, hipEvent_t *t0, hipEvent_t *t1) {
     *t0 = r->events[r->events_used].first; *t1 = r->events[r->events_used].second;
     r->event_launches[r->events_used] = 1; r->events_used++;
 }
-static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0, hipEvent_t t1);
+static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0, hipEvent_t t1, uint32_t fused_passes);
 extern "C" int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u) {
     if (!g || !u) return fail(VPT_ERR_INVALID, "null argument");
     vpt_renderer *r = g->r;
@@ -1373,13 +1373,14 @@ extern "C" int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u) {
     VPT_TRY(make_args(r, u, true, &a));
     hipEvent_t t0, t1;
     profile_events(r, &t0, &t1);
-    VPT_TRY(gather_enqueue_frame(g, a, t0, t1));
+    VPT_TRY(gather_enqueue_frame(g, a, t0, t1, 0));
     if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)u->steps;
     r->warmed = true;
     return VPT_OK;
 }
 // one frame of the gather pipeline on (compute stream cs, communication stream)
-static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+// fused_passes > 0: the frame is the result of that many MCM passes run by one k_mcm_multi launch (a carries the frame table)
+static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, uint32_t fused_passes = 0) {
     vpt_renderer *r = g->r;
     hipStream_t cs = r->ctx->stream;
     int b = (int)(g->frames & 1);
@@ -1389,7 +1390,17 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
     a.render = in_place ? (uint2 *)((char *)g->recv[b] + (size_t)g->rank * g->send_bytes) : (uint2 *)g->send[b];
     r->render_target = a.render;                                             // vpt_renderer_read(RENDER) returns the last frame's rows
     if (t0) HIP_TRY(hipEventRecord(t0, cs));
-    VPT_TRY(launch_fused(r, a));
+    if (fused_passes) {
+        switch ((r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0)) {
+            case 0: VPT_TRY(launch_multi(k_mcm_multi<0>, r, a, fused_passes)); break;
+            case 1: VPT_TRY(launch_multi(k_mcm_multi<1>, r, a, fused_passes)); break;
+            case 2: VPT_TRY(launch_multi(k_mcm_multi<2>, r, a, fused_passes)); break;
+            default: VPT_TRY(launch_multi(k_mcm_multi<3>, r, a, fused_passes)); break;
+        }
+        hipLaunchKernelGGL(k_advance_frames, dim3(1), dim3(1), 0, cs, r->frame_counter, fused_passes);
+    } else {
+        VPT_TRY(launch_fused(r, a));
+    }
     if (t1) HIP_TRY(hipEventRecord(t1, cs));
     HIP_TRY(hipEventRecord(g->rendered[b], cs));
     HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[b], 0));
@@ -1417,18 +1428,28 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
 // `count` frames by one call.  A captured hipGraph holding the RCCL all-gathers was measured 6x slower per frame than
 // this eager enqueue and unstable over many replays on ROCm 7.0 / RCCL 2.26, so the sequence is
 // always enqueued eagerly: two stream operations per frame on each of the two streams.
-extern "C" int vpt_gather_play(vpt_gather *g, const vpt_uniforms *base, const float *frame_vars, int count) {
+extern "C" int vpt_gather_play(vpt_gather *g, const vpt_uniforms *base, const float *frame_vars, int count, int mode) {
     if (!g || !base || !frame_vars) return fail(VPT_ERR_INVALID, "null argument");
+    if (mode != VPT_PLAY_EAGER && mode != VPT_PLAY_FUSED) return fail(VPT_ERR_UNSUPPORTED, "the gather pipeline plays eagerly or with fused passes (no graph replay)");
     vpt_renderer *r = g->r;
     HIP_TRY(hipSetDevice(r->ctx->device));
     PassArgs a;
     VPT_TRY(play_args(r, base, count, &a));
     const FrameVar *v = (const FrameVar *)frame_vars;
-    for (int i = 0; i < count; i++) {
+    if (mode == VPT_PLAY_FUSED) {
+        // `count` passes in one launch, then ONE gather of the resulting frame
+        if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "fused passes are implemented for the MCM renderer only");
+        VPT_TRY(play_upload_table(r, frame_vars, count, &a));
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        profile_events(r, &t0, &t1);
+        if (t0) r->event_launches[r->events_used - 1] = (uint32_t)count;
+        VPT_TRY(gather_enqueue_frame(g, a, t0, t1, (uint32_t)count));
+    }
+    for (int i = 0; i < count && mode == VPT_PLAY_EAGER; i++) {
         PassArgs f = frame_args(a, v[i]);
         hipEvent_t t0 = nullptr, t1 = nullptr;
         profile_events(r, &t0, &t1);
-        VPT_TRY(gather_enqueue_frame(g, f, t0, t1));
+        VPT_TRY(gather_enqueue_frame(g, f, t0, t1, 0));
     }
     HIP_TRY(hipGetLastError());
     r->warmed = true;

@@ -119,13 +119,13 @@ class RcclFrameGather:
         u = r._prepare_frame_uniforms()
         self._N.check(self._N.lib().vpt_gather_render(self._h, self._C.byref(u)))
 
-    def play(self, count):
-        """`count` frames (kernel + all_gather each) by one native call"""
+    def play(self, count, fused=False):
+        """`count` frames (kernel + gather each) by one native call; fused (MCM): count passes in one launch, one gather"""
         r = self.renderer
         r._bind_volume()
         u, vars_ = r._collect_frames(count)
         self._N.check(self._N.lib().vpt_gather_play(self._h, self._C.byref(u), vars_.ctypes.data_as(self._C.c_void_p),
-                                                    count))
+                                                    count, self._N.PLAY_FUSED if fused else self._N.PLAY_EAGER))
 
     def synchronize(self):
         self._N.check(self._N.lib().vpt_gather_synchronize(self._h))
