@@ -6,7 +6,8 @@ The 8-GPU run itself belongs to the driver; this measures and checks what one ra
   * rank `--rank` of 8 renders its interleaved row blocks: kernel time per frame,
   * a band of its rows is compared bit for bit with the CPU oracle run on the same 2048^3 volume,
   * the full 3840x2160 frame on one GPU, for the strong-scaling denominator.
-Writes one JSON object (stdout, and --out).  Uses oracle/ as the checker only (test infrastructure).
+Writes one JSON object (stdout, and --out).  A test script (run by hand: python tests/c5_probe.py), kept out of the
+pytest collection because it needs ~10 GiB of host memory and a minute of volume generation; uses oracle/ as the checker.
 """
 import argparse
 import json
@@ -17,7 +18,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repository root
 sys.path.insert(0, ROOT)
 
 
