@@ -218,7 +218,8 @@ VPT_API int vpt_tonemapper_rows(vpt_tonemapper *t, int *rows);
 VPT_API int vpt_tonemapper_output_device(vpt_tonemapper *t, void **ptr, size_t *nbytes);
 /* Range and the eight curve mappers can run through a 65 536-entry byte table (every output byte depends on one
  * half-precision input): bit-identical output, byte gathers instead of log/exp/divisions.  AUTO (default) uses it for
- * images of >= 262 144 pixels or when the table of the current parameters already exists; Artistic never does. */
+ * images of >= 262 144 pixels or when the table of the current parameters already exists; Artistic does at
+ * saturation 1 only (otherwise its channels are coupled). */
 #define VPT_TONEMAPPER_OPTION_TABLE  0
 #define VPT_TONEMAPPER_TABLE_NEVER   0
 #define VPT_TONEMAPPER_TABLE_ALWAYS  1

@@ -57,7 +57,9 @@ def hdr_image(w, h, seed=3):
 
 
 PARAMS = {
-    'artistic': [{}, {'low': 0.1, 'mid': 0.3, 'high': 2.5, 'saturation': 0.4, 'gamma': 1.8}, {'low': 1.0, 'high': 1.0}],
+    'artistic': [{}, {'low': 0.1, 'mid': 0.3, 'high': 2.5, 'saturation': 0.4, 'gamma': 1.8}, {'low': 1.0, 'high': 1.0},
+                 {'saturation': 1, 'low': 0.1, 'mid': 0.7, 'high': 3.0}, {'saturation': 1, 'low': 0.2, 'high': 0.2},
+                 {'saturation': 1, 'low': 0.0, 'high': 1e-30, 'mid': 5e-31}],
     'range': [{}, {'min': -0.5, 'max': 3.0, 'gamma': 1.0}, {'gamma': 0.0}],
 }
 

@@ -1070,10 +1070,10 @@ template <int KIND>
 static void launch_tonemap(vpt_tonemapper *t, const uint2 *src, size_t n, const TonemapParams &p) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;                 // grid-stride beyond 32 workgroups per CU
-    // table form (vpt_tonemap.h): not for Artistic (its channels are coupled through the saturation mix); in AUTO mode only
+    // table form (vpt_tonemap.h): for Artistic only at saturation 1 (otherwise its channels are coupled through the mix); in AUTO mode only
     // when the image is large enough to pay for evaluating 65 536 entries, or the table of these parameters already exists
     bool current = t->table && t->table_valid && memcmp(&t->table_params, &p, sizeof(p)) == 0;
-    bool use_table = KIND != VPT_TM_ARTISTIC &&
+    bool use_table = (KIND != VPT_TM_ARTISTIC || p.saturation == 1.0f) &&
                      (t->table_mode == VPT_TONEMAPPER_TABLE_ALWAYS || (t->table_mode == VPT_TONEMAPPER_TABLE_AUTO && (current || n >= 4 * 65536)));
     if (use_table && !t->table && hipMalloc(&t->table, VPT_TM_TABLE_ENTRIES + 63) != hipSuccess) { t->table = nullptr; use_table = false; (void)hipGetLastError(); }
     if (!use_table) {
@@ -1081,10 +1081,12 @@ static void launch_tonemap(vpt_tonemapper *t, const uint2 *src, size_t n, const 
         return;
     }
     if (!current) {
-        hipLaunchKernelGGL(k_tonemap_table<KIND>, dim3(256), dim3(256), 0, t->ctx->stream, t->table, p);
+        if (KIND == VPT_TM_ARTISTIC) hipLaunchKernelGGL(k_tonemap_table_artistic, dim3(256), dim3(256), 0, t->ctx->stream, t->table, p);
+        else hipLaunchKernelGGL(k_tonemap_table<KIND>, dim3(256), dim3(256), 0, t->ctx->stream, t->table, p);
         t->table_params = p; t->table_valid = true;
     }
-    if (KIND == VPT_TM_RANGE) hipLaunchKernelGGL(k_tonemap_apply_table<true>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, t->table);
+    if (KIND == VPT_TM_ARTISTIC) hipLaunchKernelGGL(k_tonemap_apply_table_artistic, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, t->table, p);
+    else if (KIND == VPT_TM_RANGE) hipLaunchKernelGGL(k_tonemap_apply_table<true>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, t->table);
     else hipLaunchKernelGGL(k_tonemap_apply_table<false>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, t->table);
 }
 extern "C" int vpt_tonemapper_set_option(vpt_tonemapper *t, int option, int value) {

@@ -128,6 +128,30 @@ __global__ void __launch_bounds__(256) k_tonemap_table(uint8_t *table, TonemapPa
     table[h] = (uint8_t)(packed & 0xffu);
     if (h == 0) table[65536] = (uint8_t)(packed >> 24);       // Range never reads it: its alpha goes through table[h]
 }
+// Artistic with uSaturation == 1 (the default): mix(dot * gray, rgb, 1) = fma(rgb, 1, g * 0) = rgb whenever g is finite
+// (g * 0 is a signed zero; adding it changes at most the sign of a zero, which pow treats alike), so the channel byte
+// is again a function of one half: table[h] = unorm8(pow((h - low) / range, e)).  A non-finite g (a channel is inf /
+// NaN or the dot product overflows) makes every channel NaN -> 0, which the per-pixel test below reproduces.
+__global__ void __launch_bounds__(256) k_tonemap_table_artistic(uint8_t *table, TonemapParams p) {
+    uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    float c = __half2float(__ushort_as_half((unsigned short)h));
+    float range = p.high - p.low;
+    float e = (-vpt_logf((p.mid - p.low) / range) / vpt_logf(2.0f)) / p.gamma;
+    table[h] = (uint8_t)to_unorm8(vpt_powf((c - p.low) / range, e));
+    if (h == 0) table[65536] = 255;
+}
+__global__ void __launch_bounds__(256) k_tonemap_apply_table_artistic(const uint2 *src, uint32_t *dst, size_t n, const uint8_t *table, TonemapParams p) {
+    float range = p.high - p.low;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint2 t = src[i];
+        float4 c = half4_to_float4(t);
+        f3 v = { (c.x - p.low) / range, (c.y - p.low) / range, (c.z - p.low) / range };
+        const float gray = 0.57735026918962576f;
+        float z = (dot3(v, f3{ gray, gray, gray }) * gray) * (1.0f - p.saturation);     // g * 0: a signed zero, or NaN
+        uint32_t rgb = (uint32_t)table[t.x & 0xffffu] | ((uint32_t)table[t.x >> 16] << 8) | ((uint32_t)table[t.y & 0xffffu] << 16);
+        dst[i] = ((z == 0.0f) ? rgb : 0u) | 0xff000000u;
+    }
+}
 template <bool ALPHA_FROM_TABLE>
 __global__ void __launch_bounds__(256) k_tonemap_apply_table(const uint2 *src, uint32_t *dst, size_t n, const uint8_t *table) {
     uint32_t alpha = (uint32_t)table[65536] << 24;
