@@ -1246,6 +1246,9 @@ static int rccl_load() {
 #define RCCL_TRY(expr) do { int e_ = (expr); if (e_ != 0) \
     return fail(VPT_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(e_)); } while (0)
 
+#ifndef VPT_GATHER_RING
+#define VPT_GATHER_RING 16            // even; 1080p: 16 x (2 MB + 16.6 MB), 2160p: 16 x (8.3 MB + 66 MB) of 288 GB
+#endif
 struct vpt_gather {
     vpt_renderer *r;
     int rank, world;
@@ -1253,9 +1256,13 @@ struct vpt_gather {
     ncclComm_t_ comm;
     hipStream_t comm_stream;
     size_t send_bytes;                 // W * local_h * 8
-    void *send[2], *recv[2];
+    // A ring of VPT_GATHER_RING send / receive buffers: frame k uses buffer k % ring.  Per frame the streams exchange ONE
+    // event (kernel done -> the communication stream may send); the reverse edge (buffer free again -> the compute stream
+    // may overwrite it) is needed only once per half ring: the gather that ends a half records gathered[half parity], and
+    // the compute stream waits for it when it re-enters that half a whole ring later.  (With two buffers the reverse edge
+    // was paid every frame: ~11 us of event traffic per frame at a 24 us kernel.)
+    void *send[VPT_GATHER_RING], *recv[VPT_GATHER_RING];
     hipEvent_t rendered[2], gathered[2];
-    bool used[2];
     uint64_t frames;
     void *assembled;                   // [H][W] RGBA16F scratch for read_frame
 };
@@ -1310,9 +1317,11 @@ extern "C" int vpt_gather_destroy(vpt_gather *g) {
     if (g->comm_stream) hipStreamSynchronize(g->comm_stream);
     vpt_renderer_set_render_target(g->r, nullptr, 0);
     if (g->comm) g_rccl.CommDestroy(g->comm);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < VPT_GATHER_RING; b++) {
         if (g->send[b]) hipFree(g->send[b]);
         if (g->recv[b]) hipFree(g->recv[b]);
+    }
+    for (int b = 0; b < 2; b++) {
         if (g->rendered[b]) hipEventDestroy(g->rendered[b]);
         if (g->gathered[b]) hipEventDestroy(g->gathered[b]);
     }
@@ -1334,11 +1343,13 @@ extern "C" int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, i
     int rc = VPT_OK;
     hipError_t e = hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking);
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipEventCreateWithFlags(&g->rendered[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->gathered[b], hipEventDisableTiming);
+    }
+    for (int b = 0; b < VPT_GATHER_RING && e == hipSuccess; b++) {
         e = hipMalloc(&g->send[b], g->send_bytes);
         if (e == hipSuccess) e = hipMalloc(&g->recv[b], g->send_bytes * world);
         if (e == hipSuccess) e = hipMemset(g->send[b], 0, g->send_bytes);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->rendered[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->gathered[b], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipMalloc(&g->assembled, (size_t)r->W * r->H * 8);
     if (e != hipSuccess) rc = fail(VPT_ERR_HIP, "gather buffers: %s", hipGetErrorString(e));
@@ -1385,8 +1396,12 @@ extern "C" int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u) {
 static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, uint32_t fused_passes = 0) {
     vpt_renderer *r = g->r;
     hipStream_t cs = r->ctx->stream;
-    int b = (int)(g->frames & 1);
-    if (g->used[b]) HIP_TRY(hipStreamWaitEvent(cs, g->gathered[b], 0));     // the gather that last read send[b] is done
+    static_assert(VPT_GATHER_RING >= 2 && VPT_GATHER_RING % 2 == 0, "the ring is split into two halves");
+    const uint64_t half = VPT_GATHER_RING / 2;
+    int b = (int)(g->frames % VPT_GATHER_RING);
+    int parity = (int)((g->frames / half) & 1);
+    // entering a half of the ring again: the gathers that used these buffers a ring ago must have drained
+    if (g->frames % half == 0 && g->frames >= VPT_GATHER_RING) HIP_TRY(hipStreamWaitEvent(cs, g->gathered[parity], 0));
     // the receiving rank of a rooted gather renders straight into its own slot of the receive buffer
     bool in_place = g->root == g->rank;
     a.render = in_place ? (uint2 *)((char *)g->recv[b] + (size_t)g->rank * g->send_bytes) : (uint2 *)g->send[b];
@@ -1404,8 +1419,8 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
         VPT_TRY(launch_fused(r, a));
     }
     if (t1) HIP_TRY(hipEventRecord(t1, cs));
-    HIP_TRY(hipEventRecord(g->rendered[b], cs));
-    HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[b], 0));
+    HIP_TRY(hipEventRecord(g->rendered[b & 1], cs));
+    HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[b & 1], 0));
     if (g->root < 0) {
         RCCL_TRY(g_rccl.AllGather(g->send[b], g->recv[b], g->send_bytes, /*ncclUint8*/ 1, g->comm, g->comm_stream));
     } else if (g->world > 1) {
@@ -1422,8 +1437,7 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
         if (ne != 0) return fail(VPT_ERR_HIP, "ncclSend/ncclRecv failed: %s", g_rccl.GetErrorString(ne));
         if (ge != 0) return fail(VPT_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(ge));
     }
-    HIP_TRY(hipEventRecord(g->gathered[b], g->comm_stream));
-    g->used[b] = true;
+    if ((g->frames + 1) % half == 0) HIP_TRY(hipEventRecord(g->gathered[parity], g->comm_stream));   // this half's last gather
     g->frames++;
     return VPT_OK;
 }
@@ -1480,8 +1494,7 @@ extern "C" int vpt_gather_read_frame(vpt_gather *g, void *dst, size_t nbytes) {
     size_t need = (size_t)r->W * r->H * 8;
     if (nbytes < need) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, need);
     HIP_TRY(hipSetDevice(r->ctx->device));
-    int b = (int)((g->frames - 1) & 1);
-    HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->gathered[b], 0));
+    int b = (int)((g->frames - 1) % VPT_GATHER_RING);       // ordered behind that frame's gather by the communication stream itself
     hipLaunchKernelGGL(k_assemble_rows, dim3((unsigned)((r->W + 255) / 256), (unsigned)r->H), dim3(256), 0, g->comm_stream,
                        (const uint2 *)g->recv[b], (uint2 *)g->assembled, r->W, r->H, r->local_h, r->G, r->R);
     HIP_TRY(hipGetLastError());
