@@ -44,13 +44,22 @@ VPT_DEV int global_row(const PixMap &m, int l) {
 // tile of XCD x is the one with (tx + ty) % 8 == x; groups past tiles_x fail the p.i < W test.
 VPT_DEV Pix map_pixel(const PixMap &m) {
     int xcd = (int)blockIdx.x & 7, ty = (int)blockIdx.y;
-    int tx = ((int)blockIdx.x & ~7) + ((xcd - ty) & 7);
+    int tx, w, lane = (int)threadIdx.x & 63;
+    if (blockDim.x == 64) {
+        // one-wave workgroups (the ray marchers when their LDS image is small): blockIdx.x = (group * 4 + wave) * 8 + xcd.
+        // Same tile -> XCD map and the same buffer order; the unit the dispatcher balances over the CUs is a quarter
+        // of a tile, so the few cube-crossing tiles of a frame spread evenly (wave-uniform branch on blockDim)
+        w = ((int)blockIdx.x >> 3) & 3;
+        tx = ((int)blockIdx.x >> 5) * 8 + ((xcd - ty) & 7);
+    } else {
+        w = (int)threadIdx.x >> 6;
+        tx = ((int)blockIdx.x & ~7) + ((xcd - ty) & 7);
+    }
     int t = ty * m.tiles_x + tx;
-    int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     Pix p;
     p.i = tx * VPT_TILE + (w & 1) * 8 + (lane & 7);
     p.l = ty * VPT_TILE + (w >> 1) * 8 + (lane >> 3);
-    p.k = t * VPT_BLOCK + (int)threadIdx.x;
+    p.k = t * VPT_BLOCK + w * 64 + lane;
     p.j = global_row(m, p.l);
     p.valid = (p.i < m.W) && (p.l < m.local_h) && (p.j < m.H);
     p.tile = tx < m.tiles_x;
@@ -96,7 +105,8 @@ __global__ void k_advance_frame(uint32_t *counter) { *counter = *counter + 1u; }
 // dynamic LDS: [tf pairs: tf_w * 2 float4][TX nx][TY ny][TZ nz] (table entries 4 B, or 8 B when WIDE)
 template <bool WIDE>
 VPT_DEV LdsTables stage_lds(float4 *lds, const PassArgs &a) {
-    for (int t = (int)threadIdx.x; t < a.tf_w; t += VPT_BLOCK) {
+    const int nthreads = (int)blockDim.x;
+    for (int t = (int)threadIdx.x; t < a.tf_w; t += nthreads) {
         float4 v = a.tf[t], n = a.tf[min(t + 1, a.tf_w - 1)];
         lds[2 * t] = v;
         lds[2 * t + 1] = make_float4(n.x - v.x, n.y - v.y, n.z - v.z, n.w - v.w);
@@ -105,9 +115,9 @@ VPT_DEV LdsTables stage_lds(float4 *lds, const PassArgs &a) {
     uint32_t *tab = (uint32_t *)(lds + 2 * a.tf_w);
     if (WIDE) {
         uint64_t *t64 = (uint64_t *)tab;
-        for (int t = (int)threadIdx.x; t < ntab; t += VPT_BLOCK) t64[t] = a.vol.tab64[t];
+        for (int t = (int)threadIdx.x; t < ntab; t += nthreads) t64[t] = a.vol.tab64[t];
     } else {
-        for (int t = (int)threadIdx.x; t < ntab; t += VPT_BLOCK) tab[t] = a.vol.tab32[t];
+        for (int t = (int)threadIdx.x; t < ntab; t += nthreads) tab[t] = a.vol.tab32[t];
     }
     __syncthreads();
     LdsTables r;
