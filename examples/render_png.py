@@ -7,27 +7,14 @@
 Without --volume a synthetic 128^3 sphere with lattice noise is used.  PNG encoding is plain zlib (no imaging library)."""
 import argparse
 import os
-import struct
 import sys
-import zlib
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vpt_amd                                                     # noqa: E402
 from vpt_amd.synthetic import sphere_volume, colour_tf, GoldenRatioRng   # noqa: E402
-
-
-def write_png(path, rgba):
-    """rgba: [h][w][4] uint8, row 0 = bottom (GL convention) -> PNG rows top to bottom"""
-    h, w, _ = rgba.shape
-    raw = b"".join(b"\x00" + rgba[h - 1 - j].tobytes() for j in range(h))
-
-    def chunk(tag, data):
-        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
-    with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
-                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+from vpt_amd.png import write_png                                         # noqa: E402
 
 
 def main():

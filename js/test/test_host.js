@@ -24,6 +24,26 @@ for (const c of fixture.cases) {
         assert.deepStrictEqual(Array.from(new Uint32Array(l.buffer)), c[key + '_bits'], c.name + ' ' + key);
     }
 }
+// CircleAnimator against the reference's own (tests/golden/circle_animator_r01.json)
+const anim = JSON.parse(fs.readFileSync(path.join(__dirname, '..', '..', 'tests', 'golden', 'circle_animator_r01.json')));
+for (const c of anim.cases) {
+    const node = new vpt.Node();
+    const a = new vpt.CircleAnimator(node, c.options);
+    for (const f of c.frames) {
+        a.update(f.t);
+        assert.deepStrictEqual(Array.from(new Uint32Array(node.transform.localTranslation.buffer)), f.translation_bits);
+        assert.deepStrictEqual(Array.from(new Uint32Array(node.transform.localRotation.buffer)), f.rotation_bits);
+    }
+}
+// PNG encoder: signature, IHDR, CRCs
+{
+    const png = vpt.encodePNG({ data: new Uint8Array([255, 0, 0, 255, 0, 255, 0, 255]), width: 1, height: 2 }, true);
+    assert.strictEqual(png.slice(1, 4).toString('latin1'), 'PNG');
+    assert.strictEqual(png.readUInt32BE(16), 1); assert.strictEqual(png.readUInt32BE(20), 2);
+    assert.strictEqual(vpt.crc32(Buffer.from('IEND', 'latin1')), 0xae426082);
+    const raw = require('zlib').inflateSync(png.slice(41, png.length - 16));        // the IDAT body
+    assert.deepStrictEqual(Array.from(raw), [0, 0, 255, 0, 255, 0, 255, 0, 0, 255]);   // flipped: GL bottom row last
+}
 const bag = new vpt.PropertyBag();
 bag.registerProperties([{ name: 'steps', value: 64 }]);
 assert.strictEqual(bag.steps, 64);

@@ -31,6 +31,7 @@ constructor(options) {
     this.volumeTransform = new Transform(new Node());                                 // :57
     this.renderer = null;
     this.toneMapper = null;
+    this.cameraAnimator = null;       // the reference installs an OrbitCameraAnimator (UI); assign a CircleAnimator to record
     const size = this._size();
     this.resize(size[0], size[1]);
 }
@@ -101,6 +102,35 @@ render() {                                                                      
 
 // what the reference puts on the canvas: the tone mapper's RGBA8 image, read back
 getFrame() { return this.toneMapper.getTexture(); }
+
+// :259-305, headless and deterministic: for every frame time t = startTime + i / fps the camera animator is stepped, the
+// renderer reset and `passes` render() calls made (the reference renders for `frameTime` seconds of wall clock), and the
+// tone-mapped frame is written as directory/frameNNNN.png.  options: { directory, startTime, endTime, fps, passes }
+recordAnimationToImageSequence(options) {
+    const fs = require('fs'), path = require('path');
+    const { encodePNG } = require('./png.js');
+    options = options || {};
+    if (!this.cameraAnimator || !this.renderer || !this.toneMapper) {
+        throw new Error('recordAnimationToImageSequence needs a cameraAnimator, a renderer and a tone mapper');
+    }
+    const startTime = options.startTime || 0, endTime = options.endTime !== undefined ? options.endTime : 1;
+    const fps = options.fps || 30, passes = options.passes || 16;
+    const frames = Math.max(Math.ceil((endTime - startTime) * fps), 1);               // :261
+    const timeStep = 1 / fps;
+    fs.mkdirSync(options.directory, { recursive: true });
+    const files = [];
+    for (let i = 0; i < frames; i++) {
+        const t = startTime + i * timeStep;                                           // :283
+        this.cameraAnimator.update(t);
+        this.renderer.reset();                                                        // :286
+        for (let k = 0; k < passes; k++) { this.render(); }
+        const file = path.join(options.directory, 'frame' + String(i).padStart(4, '0') + '.png');   // :291
+        fs.writeFileSync(file, encodePNG(this.getFrame(), true));
+        files.push(file);
+        this.dispatchEvent(new CustomEvent('animationprogress', { detail: (i + 1) / frames }));     // :298-300
+    }
+    return files;
+}
 
 get resolution() { return this._resolution; }                                         // :212-214
 

@@ -17,6 +17,12 @@ const vec3 = {
         out[2] = (m[2] * x + m[6] * y + m[10] * z + m[14]) / w;
         return out;
     },
+    cross(out, a, b) {
+        const ax = a[0], ay = a[1], az = a[2], bx = b[0], by = b[1], bz = b[2];
+        out[0] = ay * bz - az * by; out[1] = az * bx - ax * bz; out[2] = ax * by - ay * bx;
+        return out;
+    },
+    dot(a, b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; },
     normalize(out, a) {
         const x = a[0], y = a[1], z = a[2];
         let len = x * x + y * y + z * z;
@@ -55,6 +61,22 @@ const mat4 = {
     fromTranslation(out, v) {
         out.fill(0); out[0] = 1; out[5] = 1; out[10] = 1; out[15] = 1;
         out[12] = v[0]; out[13] = v[1]; out[14] = v[2];
+        return out;
+    },
+    fromScaling(out, v) {
+        out.fill(0); out[0] = v[0]; out[5] = v[1]; out[10] = v[2]; out[15] = 1;
+        return out;
+    },
+    fromRotation(out, rad, axis) {
+        let x = axis[0], y = axis[1], z = axis[2];
+        let len = Math.hypot(x, y, z);
+        if (len < 0.000001) { return null; }
+        len = 1 / len; x *= len; y *= len; z *= len;
+        const s = Math.sin(rad), c = Math.cos(rad), t = 1 - c;
+        out[0] = x * x * t + c; out[1] = y * x * t + z * s; out[2] = z * x * t - y * s; out[3] = 0;
+        out[4] = x * y * t - z * s; out[5] = y * y * t + c; out[6] = z * y * t + x * s; out[7] = 0;
+        out[8] = x * z * t + y * s; out[9] = y * z * t - x * s; out[10] = z * z * t + c; out[11] = 0;
+        out[12] = 0; out[13] = 0; out[14] = 0; out[15] = 1;
         return out;
     },
     multiply(out, a, b) {

@@ -2,6 +2,6 @@
 // (their package.json has no "type": "module", so plain node would parse the .js files as CommonJS).
 // Used only by tests/golden/make_reader_fixture.py in the build container; nothing is copied.
 export async function getFormat(url, context, defaultGetFormat) {
-    if (url.startsWith('file:///root/reference/src/js/')) { return { format: 'module' }; }
+    if (url.startsWith('file:///root/reference/src/')) { return { format: 'module' }; }
     return defaultGetFormat(url, context, defaultGetFormat);
 }

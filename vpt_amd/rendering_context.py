@@ -30,6 +30,7 @@ class RenderingContext(EventTarget):
         self.volumeTransform = Transform(Node())                                      # :57
         self.renderer = None
         self.toneMapper = None
+        self.cameraAnimator = None          # the reference installs an OrbitCameraAnimator (UI); assign a CircleAnimator to record
         self.resize(*self._size())
 
     def _size(self):
@@ -99,6 +100,36 @@ class RenderingContext(EventTarget):
     def getFrame(self):
         """what the reference puts on the canvas: the tone mapper's RGBA8 image, read back"""
         return self.toneMapper.getTexture()
+
+    def recordAnimationToImageSequence(self, options=None):
+        """RenderingContext.js:259-305, headless and deterministic: for every frame time t = startTime + i / fps the camera
+        animator is stepped, the renderer reset and `passes` render() calls made (the reference renders for `frameTime`
+        seconds of wall clock instead), and the tone-mapped frame is written as directory/frame%04d.png.
+        options: {'directory', 'startTime', 'endTime', 'fps', 'passes'}; dispatches 'animationprogress'."""
+        import math
+        import os
+        from .png import write_png
+        options = options or {}
+        if self.cameraAnimator is None or not self.renderer or not self.toneMapper:
+            raise RuntimeError('recordAnimationToImageSequence needs a cameraAnimator, a renderer and a tone mapper')
+        directory = options['directory']
+        startTime, endTime, fps = options.get('startTime', 0), options.get('endTime', 1), options.get('fps', 30)
+        passes = int(options.get('passes', 16))
+        frames = max(math.ceil((endTime - startTime) * fps), 1)                       # :261
+        timeStep = 1 / fps
+        os.makedirs(directory, exist_ok=True)
+        files = []
+        for i in range(frames):
+            t = startTime + i * timeStep                                              # :283
+            self.cameraAnimator.update(t)
+            self.renderer.reset()                                                     # :286
+            for _ in range(passes):
+                self.render()
+            path = os.path.join(directory, 'frame%s.png' % str(i).zfill(4))           # :291
+            write_png(path, self.getFrame())
+            files.append(path)
+            self.dispatchEvent(CustomEvent('animationprogress', {'detail': (i + 1) / frames}))   # :298-300
+        return files
 
     @property
     def resolution(self):                                                             # :212-214

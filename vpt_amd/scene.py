@@ -49,6 +49,17 @@ class vec3:
         return out
 
     @staticmethod
+    def cross(out, a, b):
+        ax, ay, az = float(a[0]), float(a[1]), float(a[2])
+        bx, by, bz = float(b[0]), float(b[1]), float(b[2])
+        out[0], out[1], out[2] = ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx
+        return out
+
+    @staticmethod
+    def dot(a, b):
+        return float(a[0]) * float(b[0]) + float(a[1]) * float(b[1]) + float(a[2]) * float(b[2])
+
+    @staticmethod
     def normalize(out, a):
         """gl-matrix 3.4.1 vec3.normalize"""
         x, y, z = float(a[0]), float(a[1]), float(a[2])
@@ -106,6 +117,29 @@ class mat4:
         out[:] = 0
         out[0] = out[5] = out[10] = out[15] = 1
         out[12], out[13], out[14] = v[0], v[1], v[2]
+        return out
+
+    @staticmethod
+    def fromScaling(out, v):
+        out[:] = 0
+        out[0], out[5], out[10], out[15] = v[0], v[1], v[2], 1
+        return out
+
+    @staticmethod
+    def fromRotation(out, rad, axis):
+        """gl-matrix 3.4.1 mat4.fromRotation (axis normalised with hypot; None for a degenerate axis)"""
+        x, y, z = float(axis[0]), float(axis[1]), float(axis[2])
+        length = math.hypot(x, y, z)
+        if length < 0.000001:
+            return None
+        length = 1 / length
+        x *= length; y *= length; z *= length
+        s, c = math.sin(rad), math.cos(rad)
+        t = 1 - c
+        out[0] = x * x * t + c; out[1] = y * x * t + z * s; out[2] = z * x * t - y * s; out[3] = 0
+        out[4] = x * y * t - z * s; out[5] = y * y * t + c; out[6] = z * y * t + x * s; out[7] = 0
+        out[8] = x * z * t + y * s; out[9] = y * z * t - x * s; out[10] = z * z * t + c; out[11] = 0
+        out[12] = out[13] = out[14] = 0; out[15] = 1
         return out
 
     @staticmethod
