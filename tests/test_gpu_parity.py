@@ -482,7 +482,7 @@ def test_gpu_matches_committed_contract_digests(gpu_ctx):
         r.destroy(); vol.destroy()
 
 
-@pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "mcm"])
+@pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "mcm", "depth", "iso"])
 def test_play_frame_sequences_equal_render_calls(gpu_ctx, oracle, kind):
     """vpt_renderer_play: per-frame uniforms from a device table, eager and as a replayed hipGraph == N x render()"""
     sc = Scene(gpu_ctx, oracle, 32, 100, 70, tf=colour_tf(64, 1), camera=orbit_camera(100 / 70))
@@ -518,9 +518,15 @@ def test_play_frame_sequences_equal_render_calls(gpu_ctx, oracle, kind):
         fusedr.play(2, use_graph=True); ref.render(); ref.render()          # the graph path's device frame counter stayed in step
         assert_same_bits(fusedr.read(buf), ref.read(buf), "graph replay after fused passes")
         fusedr.destroy()
-    else:
-        with pytest.raises(vpt_amd.VptError, match="MCM renderer only"):
+    elif kind == "iso":
+        with pytest.raises(vpt_amd.VptError, match="not implemented for the ISO renderer"):
             eager.play(2, fused=True)
+    else:
+        fusedr = make()
+        fusedr.play(4, fused=True); fusedr.play(1, fused=True); fusedr.render(); fusedr.play(4, fused=True)
+        assert_same_bits(fusedr.getTexture(), want_img, "%s fused passes" % kind); assert_same_bits(fusedr.read(buf), want_buf, "%s fused passes buffer" % kind)
+        assert fusedr.sample_count() == want_ns
+        fusedr.destroy()
     for r in (ref, eager, graph):
         r.destroy()
     sc.gvol.destroy()

@@ -830,8 +830,19 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
             HIP_TRY(hipGraphLaunch(g->exec, c->stream));
         }
         g->ran = true;
+    } else if (use_graph == VPT_PLAY_FUSED && r->kind != VPT_RENDERER_MCM) {
+        // the accumulating renderers: the pass loop lives in their fused kernels (PassArgs.multi_passes)
+        if (r->kind == VPT_RENDERER_ISO) return fail(VPT_ERR_UNSUPPORTED, "fused passes are not implemented for the ISO renderer");
+        VPT_TRY(play_upload_table(r, frame_vars, count, &a));
+        a.multi_passes = (uint32_t)count;
+        {
+            Timed t(r, true, (uint32_t)count);
+            VPT_TRY(launch_fused(r, a));
+        }
+        hipLaunchKernelGGL(k_advance_frames, dim3(1), dim3(1), 0, c->stream, r->frame_counter, (uint32_t)count);
+        HIP_TRY(hipGetLastError());
+        r->warmed = true;
     } else if (use_graph == VPT_PLAY_FUSED) {
-        if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "fused passes are implemented for the MCM renderer only");
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
         {
             Timed t(r, true, (uint32_t)count);

@@ -81,6 +81,7 @@ struct PassArgs {
     float mix, blur, inv_w, inv_h;
     float isovalue, gradient_step, threshold;   // ISO / Depth (vpt_kernels_iso_depth.h)
     uint32_t stagger_ticks, stagger_blocks, stagger_pattern;   // MCM phase staggering (k_mcm_integrate), 0 = off
+    uint32_t multi_passes;       // > 1: the fused (MODE 1) kernels run that many passes per pixel in one launch (VPT_PLAY_FUSED)
     void *frame;                 // tile order
     void *acc;                   // tile order (ping-pong collapsed: each pixel reads and writes only itself)
     float4 *st0, *st1, *st2, *st3;   // MCM photon state, tile order
@@ -101,6 +102,16 @@ VPT_DEV void apply_frame_table(PassArgs &a) {
     }
 }
 __global__ void k_advance_frame(uint32_t *counter) { *counter = *counter + 1u; }
+// VPT_PLAY_FUSED for the accumulating renderers: pass f of a fused launch takes its per-frame uniforms from the f-th
+// entry of the frame table after the device frame counter, exactly as launch f of the unfused sequence would
+VPT_DEV uint32_t multi_pass_count(const PassArgs &a) { return a.multi_passes > 1u ? a.multi_passes : 1u; }
+VPT_DEV void multi_pass_select(PassArgs &a, uint32_t base, uint32_t f) {
+    if (a.multi_passes > 1u) {
+        FrameVar v = a.frame_table[(base + f) & a.frame_mask];
+        a.seed = v.seed; a.offset = v.offset; a.mix = v.mix;
+        a.light = f3{ v.lx, v.ly, v.lz };
+    }
+}
 
 // dynamic LDS: [tf pairs: tf_w * 2 float4][TX nx][TY ny][TZ nz] (table entries 4 B, or 8 B when WIDE)
 template <bool WIDE>
@@ -207,12 +218,15 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mip(PassArgs a) {
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        uint32_t q = mip_pixel<V>(a, t, p, ns);
         uint8_t *frame = (uint8_t *)a.frame, *acc = (uint8_t *)a.acc;
         if (MODE == 0) {
-            frame[p.k] = (uint8_t)q;
+            frame[p.k] = (uint8_t)mip_pixel<V>(a, t, p, ns);
         } else {
-            uint32_t m = max((uint32_t)acc[p.k], q);
+            uint32_t m = acc[p.k], base = a.multi_passes > 1u ? *a.frame_counter : 0u;
+            for (uint32_t f = 0, np = multi_pass_count(a); f < np; f++) {
+                multi_pass_select(a, base, f);
+                m = max(m, mip_pixel<V>(a, t, p, ns));
+            }
             acc[p.k] = (uint8_t)m;
             float v = from_unorm8(m);
             a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(v, v, v, 1.0f);
@@ -307,12 +321,15 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_eam(PassArgs a) {
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        uint32_t q = eam_pixel<V>(a, t, p, ns);
         uint32_t *frame = (uint32_t *)a.frame, *acc = (uint32_t *)a.acc;
         if (MODE == 0) {
-            frame[p.k] = q;
+            frame[p.k] = eam_pixel<V>(a, t, p, ns);
         } else {
-            uint32_t m = eam_mix(acc[p.k], q, a.mix);
+            uint32_t m = acc[p.k], base = a.multi_passes > 1u ? *a.frame_counter : 0u;
+            for (uint32_t f = 0, np = multi_pass_count(a); f < np; f++) {
+                multi_pass_select(a, base, f);
+                m = eam_mix(m, eam_pixel<V>(a, t, p, ns), a.mix);
+            }
             acc[p.k] = m;
             a.render[(size_t)p.l * a.pm.W + p.i] = eam_to_half4(m);
         }
@@ -409,12 +426,16 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        float4 c = mcs_pixel<V>(a, t, p, ns);
         float4 *frame = (float4 *)a.frame, *acc = (float4 *)a.acc;
         if (MODE == 0) {
-            frame[p.k] = c;
+            frame[p.k] = mcs_pixel<V>(a, t, p, ns);
         } else {
-            float4 m = mcs_mix(acc[p.k], c, a.mix);
+            float4 m = acc[p.k];
+            uint32_t base = a.multi_passes > 1u ? *a.frame_counter : 0u;
+            for (uint32_t f = 0, np = multi_pass_count(a); f < np; f++) {
+                multi_pass_select(a, base, f);
+                m = mcs_mix(m, mcs_pixel<V>(a, t, p, ns), a.mix);
+            }
             acc[p.k] = m;
             a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(m.x, m.y, m.z, m.w);
         }

@@ -145,12 +145,16 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_depth(PassArgs a) {
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        float d = depth_pixel<V>(a, t, p, ns);
         float *frame = (float *)a.frame, *acc = (float *)a.acc;
         if (MODE == 0) {
-            frame[p.k] = d;
+            frame[p.k] = depth_pixel<V>(a, t, p, ns);
         } else {
-            float m = mixf(acc[p.k], d, a.mix);              // DepthRenderer.glsl:114-118
+            float m = acc[p.k];
+            uint32_t base = a.multi_passes > 1u ? *a.frame_counter : 0u;
+            for (uint32_t f = 0, np = multi_pass_count(a); f < np; f++) {
+                multi_pass_select(a, base, f);
+                m = mixf(m, depth_pixel<V>(a, t, p, ns), a.mix);     // DepthRenderer.glsl:114-118
+            }
             acc[p.k] = m;
             a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(m, m, m, 1.0f);    // :150-153
         }
