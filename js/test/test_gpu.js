@@ -146,6 +146,17 @@ async function main() {
         rc.destroy();
     }
 
+    // ---- frame sequences: play(count, FUSED) == count x render(), bit for bit (MCM state, MCS accumulator)
+    for (const kind of ['mcm', 'mcs']) {
+        const mk = () => { const R = vpt.RendererFactory(kind); const r = new R(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() }); r.extinction = 6; r.reset(); return r; };
+        const a = mk(), b = mk();
+        for (let k = 0; k < 6; k++) { a.render(); }
+        b.play(4, N.VPT_PLAY_FUSED); b.play(2, N.VPT_PLAY_EAGER);
+        assert.deepStrictEqual(b.getTexture().data, a.getTexture().data, kind + ' play');
+        assert.strictEqual(b.sampleCount(), a.sampleCount());
+        a.destroy(); b.destroy();
+    }
+
     // ---- ISO and Depth through the Node host (uniform block offsets 112..124): hits, misses and shading present
     {
         const iso = new vpt.ISORenderer(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });

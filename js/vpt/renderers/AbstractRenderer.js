@@ -105,6 +105,20 @@ getTexture() {
     return { data: out, width: size[0], height: rows, format: 'RGBA16F' };
 }
 
+// extension: `count` render() passes by one native call.  mode: native().VPT_PLAY_EAGER | _GRAPH | _FUSED (one launch,
+// state / accumulator in registers between passes; not ISO).  The per-frame draws are taken exactly as render() would.
+play(count, mode) {
+    this._bindVolume();
+    const vars = new Float32Array(8 * count);
+    let u = null;
+    for (let k = 0; k < count; k++) {
+        u = this._prepareFused();
+        vars[8 * k] = u.getFloat32(U.SEED, true); vars[8 * k + 1] = u.getFloat32(U.OFFSET, true); vars[8 * k + 2] = u.getFloat32(U.MIX, true);
+        for (let i = 0; i < 3; i++) { vars[8 * k + 4 + i] = u.getFloat32(U.LIGHT + 4 * i, true); }
+    }
+    native().rendererPlay(this._h, u, vars, mode === undefined ? native().VPT_PLAY_EAGER : mode);
+}
+
 read(buffer, out) { native().rendererRead(this._h, buffer, out); return out; }
 sampleCount() { return native().rendererSampleCount(this._h); }
 
