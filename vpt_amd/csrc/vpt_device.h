@@ -299,7 +299,7 @@ VPT_DEV uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
 struct DevVolume {
     const uint8_t *bricks;
     const uint32_t *tab32;   // TX | TY | TZ (nx + ny + nz entries), 32-bit offsets
-    const uint64_t *tab64;   // same, 64-bit (bricked size > 4 GiB)
+    const uint32_t *tabc;    // Morton brick codes only (bricked size > 4 GiB: the byte offset no longer fits 32 bits)
     int nx, ny, nz;
     float fnx, fny, fnz;     // (float)n
     float hx, hy, hz;        // (float)(n - 1)
@@ -330,8 +330,12 @@ VPT_DEV uint32_t nearest_cell(float s, float fn, float hi) {
 template <bool WIDE>
 VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_t x, uint32_t y, uint32_t z) {
     if (WIDE) {
-        const uint64_t *tx = (const uint64_t *)t.tx, *ty = (const uint64_t *)t.ty, *tz = (const uint64_t *)t.tz;
-        return v.bricks + (tx[x] + ty[y] + tz[z]);
+        // > 4 GiB of bricks (2048^3: 16 GiB): the tables hold the 27-bit Morton code of the brick only (still 32-bit
+        // entries: 24 KB of LDS for 2048^3 where 64-bit byte offsets took 48 KB and halved the occupancy); the in-brick
+        // offset costs five VALU instructions instead of riding along in the table
+        uint32_t code = t.tx[x] + t.ty[y] + t.tz[z];
+        uint32_t intra = (x & 3u) + (y & 3u) * 5u + (z & 3u) * 25u;
+        return v.bricks + (((uint64_t)code << 7) + intra);
     }
     return v.bricks + (uint32_t)(t.tx[x] + t.ty[y] + t.tz[z]);
 }

@@ -49,7 +49,7 @@ struct vpt_volume {
     uint8_t *bricks;       // apron bricks, Morton order
     size_t brick_bytes;
     uint32_t *tab32;       // separable brick-offset tables TX | TY | TZ (vpt_device.h), 32-bit form
-    uint64_t *tab64;       // 64-bit form (always built; used when brick_bytes > 4 GiB)
+    uint32_t *tabc;        // brick Morton codes (always built; used when brick_bytes > 4 GiB, vpt_device.h cell_addr<WIDE>)
     bool wide;
     bool dirty;            // blocks uploaded since the last brickify
     bool any_upload;
@@ -195,11 +195,14 @@ extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format
         for (int i = 0; i < h; i++) t64[(size_t)w + i] = ((uint64_t)host_spread3(i >> 2) << 8) + (uint64_t)(i & 3) * 5;
         for (int i = 0; i < d; i++) t64[(size_t)w + h + i] = ((uint64_t)host_spread3(i >> 2) << 9) + (uint64_t)(i & 3) * 25;
         for (size_t i = 0; i < t64.size(); i++) t32[i] = (uint32_t)t64[i];
+        for (size_t i = 0; i < t64.size(); i++) t64[i] >>= 7;              // the brick's Morton code alone (WIDE variant)
+        std::vector<uint32_t> tc(t64.size());
+        for (size_t i = 0; i < t64.size(); i++) tc[i] = (uint32_t)t64[i];
         v->wide = v->brick_bytes > 0xffffffffull;
         HIP_TRY(hipMalloc(&v->tab32, t32.size() * 4));
-        HIP_TRY(hipMalloc(&v->tab64, t64.size() * 8));
+        HIP_TRY(hipMalloc(&v->tabc, tc.size() * 4));
         HIP_TRY(hipMemcpy(v->tab32, t32.data(), t32.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(v->tab64, t64.data(), t64.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(v->tabc, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
     }
     v->dirty = true;
     *out = v;
@@ -278,7 +281,7 @@ extern "C" int vpt_volume_destroy(vpt_volume *v) {
     if (v->bricks) hipFree(v->bricks);
     if (v->staging) hipFree(v->staging);
     if (v->tab32) hipFree(v->tab32);
-    if (v->tab64) hipFree(v->tab64);
+    if (v->tabc) hipFree(v->tabc);
     delete v;
     return VPT_OK;
 }
@@ -474,7 +477,7 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         a->vol.bricks = v->bricks; a->vol.nx = v->nx; a->vol.ny = v->ny; a->vol.nz = v->nz;
         a->vol.fnx = (float)v->nx; a->vol.fny = (float)v->ny; a->vol.fnz = (float)v->nz;
         a->vol.hx = (float)(v->nx - 1); a->vol.hy = (float)(v->ny - 1); a->vol.hz = (float)(v->nz - 1);
-        a->vol.tab32 = v->tab32; a->vol.tab64 = v->tab64;
+        a->vol.tab32 = v->tab32; a->vol.tabc = v->tabc;
         a->vol.filter = v->filter;
     }
     a->env.texels = r->env; a->env.w = r->env_w; a->env.h = r->env_h; a->env.constant = r->env_const;
@@ -502,7 +505,7 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
 // dynamic LDS of the sampling kernels: transfer-function pairs + the three brick-offset tables
 static size_t lds_bytes(const vpt_renderer *r) {
     const vpt_volume *v = r->vol;
-    return (size_t)r->tf_w * 2 * sizeof(float4) + (size_t)(v->nx + v->ny + v->nz) * (v->wide ? 8 : 4);
+    return (size_t)r->tf_w * 2 * sizeof(float4) + (size_t)(v->nx + v->ny + v->nz) * 4;
 }
 static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)(r->tiles_x + 7) / 8u * 8u, (unsigned)r->tiles_y); }
 // Ray-marching kernels (MIP, EAM, ISO, Depth, MCS) run as one-wave workgroups when 28 of their LDS images fit a CU: with

@@ -113,7 +113,7 @@ VPT_DEV void multi_pass_select(PassArgs &a, uint32_t base, uint32_t f) {
     }
 }
 
-// dynamic LDS: [tf pairs: tf_w * 2 float4][TX nx][TY ny][TZ nz] (table entries 4 B, or 8 B when WIDE)
+// dynamic LDS: [tf pairs: tf_w * 2 float4][TX nx][TY ny][TZ nz], 4-byte entries (byte offsets, or brick codes when WIDE)
 template <bool WIDE>
 VPT_DEV LdsTables stage_lds(float4 *lds, const PassArgs &a) {
     const int nthreads = (int)blockDim.x;
@@ -124,17 +124,12 @@ VPT_DEV LdsTables stage_lds(float4 *lds, const PassArgs &a) {
     }
     int ntab = a.vol.nx + a.vol.ny + a.vol.nz;
     uint32_t *tab = (uint32_t *)(lds + 2 * a.tf_w);
-    if (WIDE) {
-        uint64_t *t64 = (uint64_t *)tab;
-        for (int t = (int)threadIdx.x; t < ntab; t += nthreads) t64[t] = a.vol.tab64[t];
-    } else {
-        for (int t = (int)threadIdx.x; t < ntab; t += nthreads) tab[t] = a.vol.tab32[t];
-    }
+    const uint32_t *src = WIDE ? a.vol.tabc : a.vol.tab32;
+    for (int t = (int)threadIdx.x; t < ntab; t += nthreads) tab[t] = src[t];
     __syncthreads();
     LdsTables r;
     r.tf = lds;
-    int s = WIDE ? 2 : 1;
-    r.tx = tab; r.ty = tab + s * a.vol.nx; r.tz = tab + s * (a.vol.nx + a.vol.ny);
+    r.tx = tab; r.ty = tab + a.vol.nx; r.tz = tab + (a.vol.nx + a.vol.ny);
     return r;
 }
 // sampleVolumeColor: MIPRenderer.glsl:45-49 (= EAM :46-50, MCS :64-68, MCM :85-89)
