@@ -107,7 +107,8 @@ VPT_API int vpt_volume_upload_block_device(vpt_volume *vol, int x, int y, int z,
 VPT_API int vpt_volume_finalize(vpt_volume *vol);
 VPT_API int vpt_volume_set_filter(vpt_volume *vol, int filter);
 VPT_API int vpt_volume_destroy(vpt_volume *vol);
-/* force the 64-bit brick-offset tables (automatic when the bricked layout exceeds 4 GiB); lets the wide kernel variants
+/* force the > 4 GiB addressing variant (brick-code tables + computed in-brick offset; automatic when the bricked layout
+ * exceeds 4 GiB); lets the wide kernel variants
  * be checked against the oracle on small volumes */
 VPT_API int vpt_volume_set_wide_tables(vpt_volume *vol, int wide);
 /* bytes of the bricked layout in HBM (for reporting) */

@@ -101,7 +101,7 @@ class Volume(EventTarget):
         return vol
 
     def set_wide_tables(self, wide):
-        """force the 64-bit brick-offset tables (automatic above 4 GiB of bricked data)"""
+        """force the > 4 GiB addressing variant of the kernels (automatic above 4 GiB of bricked data)"""
         N.check(N.lib().vpt_volume_set_wide_tables(self.texture, 1 if wide else 0))
 
     def bricked_bytes(self):
