@@ -560,6 +560,9 @@ def test_native_rccl_gather_play(gpu_ctx, oracle, root):
     assert_same_bits(g.frame(), plain.getTexture(), "fused passes then one gather")
     assert_same_bits(shard.read(N.BUFFER_MCM_RADIANCE), plain.read(N.BUFFER_MCM_RADIANCE), "state")
     assert shard.sample_count() == plain.sample_count()
+    shard.setResolution((64, 40))                           # the gather's buffers were sized for 100x70: refuse, do not overrun
+    with pytest.raises(vpt_amd.VptError, match="re-create the gather"):
+        g.render()
     g.destroy(); plain.destroy(); shard.destroy(); sc.gvol.destroy()
 
 

@@ -1422,6 +1422,8 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
     vpt_renderer *r = g->r;
     hipStream_t cs = r->ctx->stream;
     static_assert(VPT_GATHER_RING >= 2 && VPT_GATHER_RING % 2 == 0, "the ring is split into two halves");
+    if ((size_t)r->W * r->local_h * 8 != g->send_bytes || r->G != g->world || r->g != g->rank)
+        return fail(VPT_ERR_INVALID, "the renderer was resized or re-sharded after the gather was created: destroy and re-create the gather");
     const uint64_t half = VPT_GATHER_RING / 2;
     int b = (int)(g->frames % VPT_GATHER_RING);
     int parity = (int)((g->frames / half) & 1);
