@@ -254,3 +254,17 @@ def test_record_animation_to_image_sequence(gpu_ctx, oracle, tmp_path):
         same(got, want[::-1], "animation frame %d" % i)
         assert (want[..., :3] > 0).any()
     rc.destroy()
+
+
+def test_tonemapper_survives_its_renderer(gpu_ctx, oracle):
+    """destroying the bound renderer unbinds it: the tone mapper falls back to the white placeholder instead of reading freed memory"""
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, sphere_volume(16, noise=20.0), 'linear')
+    r = vpt_amd.MIPRenderer(gpu_ctx, gvol, default_camera(1.0), None, {'resolution': 48, 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+    r.reset(); r.render()
+    tm = vpt_amd.RangeToneMapper(gpu_ctx, r, {'resolution': 48})
+    tm.render()
+    assert (tm.getTexture()[..., 0] < 255).any()
+    r.destroy()
+    tm.render()
+    assert (tm.getTexture() == 255).all()
+    tm.destroy(); gvol.destroy()

@@ -35,10 +35,12 @@ extern "C" const char *vpt_version(void) { return "vpt-mi355x 0.1 (gfx950)"; }
 // ---------------------------------------------------------------------------------------------
 // objects
 // ---------------------------------------------------------------------------------------------
+struct vpt_tonemapper;
 struct vpt_context {
     int device;
     hipStream_t stream;
     bool owns_stream;
+    std::vector<vpt_tonemapper *> tonemappers;   // live tone mappers: a destroyed renderer is unbound from them
 };
 
 struct vpt_volume {
@@ -413,10 +415,12 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     *out = r;
     return VPT_OK;
 }
+static void tonemappers_unbind(vpt_context *c, vpt_renderer *r);
 extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (!r) return VPT_OK;
     hipSetDevice(r->ctx->device);
     hipStreamSynchronize(r->ctx->stream);
+    tonemappers_unbind(r->ctx, r);            // a tone mapper still bound to this renderer falls back to the white placeholder
     renderer_free_buffers(r);                 // renderer-owned buffers only; volume is NOT owned (Volume.js:17-22)
     if (r->tf) hipFree(r->tf);
     if (r->env) hipFree(r->env);
@@ -1043,6 +1047,9 @@ struct vpt_tonemapper {
     int table_mode;                // VPT_TONEMAPPER_TABLE_*
     uint8_t *table; bool table_valid; TonemapParams table_params;   // byte table of the current parameters (vpt_tonemap.h)
 };
+static void tonemappers_unbind(vpt_context *c, vpt_renderer *r) {
+    for (vpt_tonemapper *t : c->tonemappers) if (t->source == r) t->source = nullptr;
+}
 extern "C" int vpt_tonemapper_create(vpt_context *c, int kind, int width, int height, vpt_tonemapper **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
     if (kind < VPT_TONEMAPPER_ARTISTIC || kind > VPT_TONEMAPPER_UCHIMURA) return fail(VPT_ERR_INVALID, "No suitable class");   // ToneMapperFactory.js:26
@@ -1050,6 +1057,7 @@ extern "C" int vpt_tonemapper_create(vpt_context *c, int kind, int width, int he
     vpt_tonemapper *t = new vpt_tonemapper();
     memset(t, 0, sizeof(*t));
     t->ctx = c; t->kind = kind; t->W = width; t->H = height; t->table_mode = VPT_TONEMAPPER_TABLE_AUTO;
+    c->tonemappers.push_back(t);
     *out = t;
     return VPT_OK;
 }
@@ -1060,6 +1068,8 @@ extern "C" int vpt_tonemapper_destroy(vpt_tonemapper *t) {
     if (t->image) hipFree(t->image);
     if (t->out) hipFree(t->out);
     if (t->table) hipFree(t->table);
+    for (size_t i = 0; i < t->ctx->tonemappers.size(); i++)
+        if (t->ctx->tonemappers[i] == t) { t->ctx->tonemappers.erase(t->ctx->tonemappers.begin() + (long)i); break; }
     delete t;
     return VPT_OK;
 }
