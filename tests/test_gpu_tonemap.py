@@ -268,3 +268,17 @@ def test_tonemapper_survives_its_renderer(gpu_ctx, oracle):
     tm.render()
     assert (tm.getTexture() == 255).all()
     tm.destroy(); gvol.destroy()
+
+
+def test_renderer_survives_its_volume(gpu_ctx, oracle):
+    """destroying a bound volume through the C ABI unbinds it: the next pass reports 'no ready volume' (Volume.js:107-113)"""
+    import ctypes as C
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, sphere_volume(16, noise=20.0), 'linear')
+    r = vpt_amd.MIPRenderer(gpu_ctx, gvol, default_camera(1.0), None, {'resolution': 32, 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+    r.reset(); r.render()
+    u = r._prepare_frame_uniforms()
+    N.check(N.lib().vpt_volume_destroy(gvol.texture))          # behind the host mirror's back
+    gvol.texture = None; gvol.ready = False
+    assert N.lib().vpt_renderer_render(r._h, C.byref(u)) == -3  # VPT_ERR_NO_VOLUME
+    assert b"no ready volume" in N.lib().vpt_last_error()
+    r.destroy()

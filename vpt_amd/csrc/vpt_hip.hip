@@ -41,6 +41,7 @@ struct vpt_context {
     hipStream_t stream;
     bool owns_stream;
     std::vector<vpt_tonemapper *> tonemappers;   // live tone mappers: a destroyed renderer is unbound from them
+    std::vector<struct vpt_renderer *> renderers; // live renderers: a destroyed volume is unbound from them
 };
 
 struct vpt_volume {
@@ -275,10 +276,12 @@ extern "C" int vpt_volume_bricked_bytes(vpt_volume *v, uint64_t *n) {
     *n = v->brick_bytes;
     return VPT_OK;
 }
+static void renderers_unbind(vpt_context *c, vpt_volume *v);
 extern "C" int vpt_volume_destroy(vpt_volume *v) {
     if (!v) return VPT_OK;
     hipSetDevice(v->ctx->device);
     hipStreamSynchronize(v->ctx->stream);
+    renderers_unbind(v->ctx, v);              // a renderer still bound to it reports "no ready volume" instead of reading freed memory
     if (v->linear) hipFree(v->linear);
     if (v->bricks) hipFree(v->bricks);
     if (v->staging) hipFree(v->staging);
@@ -391,6 +394,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     HIP_TRY(hipSetDevice(c->device));
     vpt_renderer *r = new vpt_renderer();
     r->ctx = c; r->kind = kind; r->W = width; r->H = height;
+    c->renderers.push_back(r);
     r->G = 1; r->g = 0; r->R = 8;
     r->vol = nullptr; r->tf = nullptr; r->env = nullptr;
     r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
@@ -421,6 +425,8 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     hipSetDevice(r->ctx->device);
     hipStreamSynchronize(r->ctx->stream);
     tonemappers_unbind(r->ctx, r);            // a tone mapper still bound to this renderer falls back to the white placeholder
+    for (size_t i = 0; i < r->ctx->renderers.size(); i++)
+        if (r->ctx->renderers[i] == r) { r->ctx->renderers.erase(r->ctx->renderers.begin() + (long)i); break; }
     renderer_free_buffers(r);                 // renderer-owned buffers only; volume is NOT owned (Volume.js:17-22)
     if (r->tf) hipFree(r->tf);
     if (r->env) hipFree(r->env);
@@ -1047,6 +1053,9 @@ struct vpt_tonemapper {
     int table_mode;                // VPT_TONEMAPPER_TABLE_*
     uint8_t *table; bool table_valid; TonemapParams table_params;   // byte table of the current parameters (vpt_tonemap.h)
 };
+static void renderers_unbind(vpt_context *c, vpt_volume *v) {
+    for (vpt_renderer *r : c->renderers) if (r->vol == v) r->vol = nullptr;
+}
 static void tonemappers_unbind(vpt_context *c, vpt_renderer *r) {
     for (vpt_tonemapper *t : c->tonemappers) if (t->source == r) t->source = nullptr;
 }
