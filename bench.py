@@ -115,6 +115,16 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    lib_path = os.path.join(ROOT, "vpt_amd", "libvpt_hip.so")
+    if not os.path.exists(lib_path):                       # git-ignored artefact: a bare checkout builds it (one rank, the others wait)
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            for _ in range(600):
+                if os.path.exists(lib_path):
+                    break
+                time.sleep(1.0)
     import numpy as np
     import torch                       # first: its libamdhip64 is the one libvpt_hip.so binds to
     import torch.distributed as dist
