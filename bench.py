@@ -118,8 +118,8 @@ def main():
     lib_path = os.path.join(ROOT, "vpt_amd", "libvpt_hip.so")
     if not os.path.exists(lib_path):                       # git-ignored artefact: a bare checkout builds it (one rank, the others wait)
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-            import __graft_entry__
-            __graft_entry__.build()
+            import subprocess                              # in a child: build() loads the library, and here torch must load HIP first
+            subprocess.check_call([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, stdout=sys.stderr)
         else:
             for _ in range(600):
                 if os.path.exists(lib_path):
