@@ -282,3 +282,25 @@ def test_renderer_survives_its_volume(gpu_ctx, oracle):
     assert N.lib().vpt_renderer_render(r._h, C.byref(u)) == -3  # VPT_ERR_NO_VOLUME
     assert b"no ready volume" in N.lib().vpt_last_error()
     r.destroy()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_tonemapper_random_parameters(gpu_ctx, oracle, seed):
+    """all ten mappers under random (also degenerate) parameters, direct and table form, on an image with specials"""
+    rng = np.random.default_rng(500 + seed)
+    w, h = int(rng.integers(1, 90)), int(rng.integers(1, 60))
+    img = hdr_image(w, h, seed=100 + seed)
+
+    def pick(lo, hi):
+        return float(rng.choice([rng.uniform(lo, hi), 0.0, 1.0, -rng.uniform(0, 1), 1e-6, 1e6]))
+    for kind in KINDS:
+        tm = vpt_amd.ToneMapperFactory(kind)(gpu_ctx, img, {'resolution': (w, h)})
+        for p in tm.properties:
+            setattr(tm, p['name'], pick(0.05, 4.0))
+        full = {p['name']: getattr(tm, p['name']) for p in tm.properties}
+        want = oracle.tonemap(kind, img, **full)
+        for mode in (N.TONEMAPPER_TABLE_NEVER, N.TONEMAPPER_TABLE_ALWAYS):
+            tm.set_option(N.TONEMAPPER_OPTION_TABLE, mode)
+            tm.render()
+            same(tm.getTexture(), want, "%s %r mode %d" % (kind, full, mode))
+        tm.destroy()
