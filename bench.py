@@ -75,9 +75,17 @@ def cpu_baseline(vol, args, matrix, tf):
         fr.seed = float(np.float32((k + 1) * 0.61803398875 % 1.0))
         n += o.integrate(fr)
     dt = time.perf_counter() - t0
+    # the same oracle on ONE thread, on the middle half of the rows of one more pass (per-core figure)
+    f1 = O.make_frame(w, h, matrix, seed=0.75, extinction=1.0, anisotropy=0.0, max_bounces=8, mcm_steps=8, nthreads=1,
+                      y0=h // 4, y1=h // 4 + h // 2)
+    t1 = time.perf_counter()
+    n1 = o.integrate(f1)
+    dt1 = time.perf_counter() - t1
     return {"value": n / dt, "unit": "volume samples/s", "cores": threads, "kind": "port",
             "sample": "%d MCM integrate passes (steps=8) of the full %dx%d frame on the same %d^3 volume, "
-                      "oracle/vpt_oracle.c with OpenMP over rows, %.2f s wall" % (passes, w, h, args.volume, dt)}
+                      "oracle/vpt_oracle.c with OpenMP over rows, %.2f s wall" % (passes, w, h, args.volume, dt),
+            "single_thread": {"value": n1 / dt1, "cores": 1,
+                              "sample": "one pass over rows %d..%d on one thread, %.2f s" % (h // 4, h // 4 + h // 2, dt1)}}
 
 
 def cpu_baseline_js(vol, args, matrix):
