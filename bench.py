@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--fused-passes", type=int, default=0,
                     help="MCM, single GPU, with --frames-per-launch F: one launch runs F passes with the photon state in registers")
     ap.add_argument("--graph", type=int, default=1, help="replay frame sequences as a captured hipGraph (with --frames-per-launch > 1)")
-    ap.add_argument("--gather-root", type=int, default=0,
-                    help="native gather: rank that receives every frame (grouped ncclSend/ncclRecv); -1 = every rank (all_gather)")
+    ap.add_argument("--gather-root", default="auto",
+                    help="native gather: rank that receives every frame (grouped ncclSend/ncclRecv); -1 = every rank (all_gather); "
+                         "auto = time both during the warm-up (rank 0 receives the frame either way) and keep the faster")
     ap.add_argument("--gather", default="native", choices=["native", "torch"],
                     help="frame gather for N > 1: 'native' = RCCL pipeline below the C ABI (vpt_gather_*), 'torch' = torch.distributed all_gather")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
@@ -187,7 +188,7 @@ def main():
             try:
                 ids = [RcclFrameGather.unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
-                native = RcclFrameGather(r, ids[0], rank, world, root=args.gather_root)
+                native = RcclFrameGather(r, ids[0], rank, world, root=0 if args.gather_root == "auto" else int(args.gather_root))
             except Exception as e:                       # noqa: BLE001 - reported below
                 err = repr(e)
             flag = torch.tensor([0 if native is not None else 1], dtype=torch.int32, device=device)
@@ -246,6 +247,21 @@ def main():
 
         r.set_profiling(args.profile_kernel)          # before the warm-up so that a captured graph carries its timing events
         warm = args.warmup
+        gather_choice = None
+        if native is not None and args.gather_root == "auto":
+            # which exchange is faster on this node is a property of RCCL's p2p and collective paths: measure both
+            trial = {}
+            for root in (0, -1):
+                native.set_root(root)
+                run_steps(8); drain(); dist.barrier(); torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                run_steps(40); drain(); torch.cuda.synchronize()
+                tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=device)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                trial[root] = float(tt_[0]) / 40
+            best = min(trial, key=trial.get)
+            native.set_root(best)
+            gather_choice = {"chosen_root": best, "ms_per_frame_root0": trial[0] * 1e3, "ms_per_frame_all_gather": trial[-1] * 1e3}
         run_steps(warm)                               # the first frame sequence runs eagerly (lazy allocations) ...
         if fpl > 1:
             run_steps(2 * fpl)                        # ... the next ones capture and replay the graph, outside the timed region
@@ -337,7 +353,8 @@ def main():
                                    "default camera, default 2x1 transfer function, extinction %g, anisotropy 0, bounces 8, "
                                    "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
                        "parallelism": ("image rows sharded over %d GPU(s), per-frame RCCL %s (%s pipeline)" % (
-                           world, ("gather to rank %d" % args.gather_root) if (native is not None and args.gather_root >= 0) else "all_gather", args.gather)) if use_dist else "single GPU",
+                           world, ("gather to rank %d" % native.root) if (native is not None and native.root >= 0) else "all_gather", args.gather)) if use_dist else "single GPU",
+                       "gather_calibration": gather_choice,
                        "frames_per_launch": fpl, "hipgraph": bool(args.graph) and fpl > 1 and native is None and not args.fused_passes,
                        "fused_passes": bool(args.fused_passes) and fpl > 1,
                        "samples_per_step": samples / args.steps},
