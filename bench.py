@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--fused-passes", type=int, default=0,
                     help="MCM, single GPU, with --frames-per-launch F: one launch runs F passes with the photon state in registers")
     ap.add_argument("--graph", type=int, default=1, help="replay frame sequences as a captured hipGraph (with --frames-per-launch > 1)")
+    ap.add_argument("--watchdog", type=int, default=1500, help="abort if the whole run takes longer than this many seconds")
     ap.add_argument("--gather-root", default="auto",
                     help="native gather: rank that receives every frame (grouped ncclSend/ncclRecv); -1 = every rank (all_gather); "
                          "auto = time both during the warm-up (rank 0 receives the frame either way) and keep the faster")
@@ -124,6 +125,16 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # a collective that never completes must not hang the caller for ever: give up loudly
+    import threading
+
+    def _give_up():
+        sys.stderr.write("bench.py: no result after %d s (a hung collective or kernel?) - aborting\n" % args.watchdog)
+        sys.stderr.flush()
+        os._exit(3)
+    watchdog = threading.Timer(args.watchdog, _give_up)
+    watchdog.daemon = True
+    watchdog.start()
     lib_path = os.path.join(ROOT, "vpt_amd", "libvpt_hip.so")
     if not os.path.exists(lib_path):                       # git-ignored artefact: a bare checkout builds it (one rank, the others wait)
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -386,6 +397,7 @@ def main():
     r.destroy(); gvol.destroy(); ctx.destroy()
     if use_dist:
         dist.destroy_process_group()
+    watchdog.cancel()
     if not ok:
         raise SystemExit("gathered frame does not match the rank-local rows")
 
