@@ -46,6 +46,8 @@ extern "C" {
 
 /* Volume formats (RAWReader.js:36-38: format RED, internalFormat R8, type UNSIGNED_BYTE) */
 #define VPT_FORMAT_R8 0
+#define VPT_FORMAT_RG8 1         /* format RG, internalFormat RG8, type UNSIGNED_BYTE: two interleaved channels, texture(uVolume, p).rg
+                                  * has both and the transfer function is looked up in 2-D (MIPRenderer.glsl:45-49) */
 
 /* Buffers readable through vpt_renderer_read (SingleBuffer.js / DoubleBuffer.js attachments) */
 #define VPT_BUFFER_RENDER 0      /* RGBA16F, 8 B/pixel  (AbstractRenderer.js:142-155, getTexture() :114-116) */

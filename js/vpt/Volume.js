@@ -3,7 +3,7 @@
 const { EventTarget, CustomEvent } = require('./EventTarget.js');
 const { native } = require('./native.js');
 
-const { RAWReader, GL_RED, GL_UNSIGNED_BYTE } = require('./readers/readers.js');
+const { RAWReader, GL_RED, GL_RG, GL_UNSIGNED_BYTE } = require('./readers/readers.js');
 
 class Volume extends EventTarget {
 
@@ -34,11 +34,11 @@ async readModality(modalityName) {
     if (!modality) { throw new Error(`Modality '${modalityName}' does not exist`); }          // Volume.js:40
     this.modality = modality;
     if (this.texture) { N.volumeDestroy(this.texture); this.texture = null; }
-    if (modality.type !== GL_UNSIGNED_BYTE || modality.format !== GL_RED) {
+    if (modality.type !== GL_UNSIGNED_BYTE || (modality.format !== GL_RED && modality.format !== GL_RG)) {
         throw new Error('Unknown volume datatype: ' + modality.type);                           // Volume.js:103
     }
     const { width, height, depth } = modality.dimensions;
-    this.texture = N.volumeCreate(this._gl._h, width, height, depth, N.VPT_FORMAT_R8);
+    this.texture = N.volumeCreate(this._gl._h, width, height, depth, modality.format === GL_RG ? N.VPT_FORMAT_RG8 : N.VPT_FORMAT_R8);
     for (const { index, position } of modality.placements) {
         const data = await this._reader.readBlock(index);
         const d = this.metadata.blocks[index].dimensions;

@@ -4,6 +4,7 @@
 const { AbstractLoader, BlobLoader } = require('../loaders/loaders.js');
 
 const GL_RED = 6403, GL_R8 = 33321, GL_UNSIGNED_BYTE = 5121;
+const GL_RG = 33319, GL_RG8 = 33323;                  // two-channel volumes of BVP manifests
 
 class AbstractReader {                                          // AbstractReader.js:1-15
     constructor(loader) { this._loader = loader; }
@@ -123,4 +124,4 @@ function ReaderFactory(which) {                                 // ReaderFactory
     }
 }
 
-module.exports = { AbstractReader, RAWReader, ZIPReader, BVPReader, ReaderFactory, GL_RED, GL_R8, GL_UNSIGNED_BYTE };
+module.exports = { AbstractReader, RAWReader, ZIPReader, BVPReader, ReaderFactory, GL_RED, GL_R8, GL_RG, GL_RG8, GL_UNSIGNED_BYTE };

@@ -50,6 +50,7 @@ typedef struct {
     int32_t tf_w, tf_h;
     const uint8_t *env_rgba;    /* RGBA8 environment map, LINEAR/CLAMP (RenderingContext.js:90-101) */
     int32_t env_w, env_h;
+    int32_t channels;           /* 1 = R8 (RAWReader.js:36-38), 2 = RG8 interleaved: texture(uVolume, p).rg has both (0 means 1) */
 } vpo_scene;
 
 typedef struct {
@@ -357,9 +358,10 @@ static inline float lerpf(float a, float b, float f) { return fmaf(f, b - a, a);
 
 /* texture(uVolume, p).r — R8 normalised, CLAMP_TO_EDGE (Volume.js:49-60).  Interpolates the integer
  * texel values (x, then y, then z) and normalises once by * fl32(1/255). */
-static float sample_volume(const vpo_scene *sc, v3 p) {
-    const uint8_t *v = sc->volume;
-    size_t sx = 1, sy = (size_t)sc->nx, sz = (size_t)sc->nx * (size_t)sc->ny;
+static float sample_volume_channel(const vpo_scene *sc, v3 p, int channel) {
+    size_t nch = sc->channels == 2 ? 2 : 1;
+    const uint8_t *v = sc->volume + channel;
+    size_t sx = nch, sy = nch * (size_t)sc->nx, sz = nch * (size_t)sc->nx * (size_t)sc->ny;
     if (sc->filter == 0) {
         int32_t x = nearest_coord(p.x, sc->nx), y = nearest_coord(p.y, sc->ny), z = nearest_coord(p.z, sc->nz);
         return (float)v[x * sx + y * sy + z * sz] * VPO_INV255;
@@ -377,6 +379,7 @@ static float sample_volume(const vpo_scene *sc, v3 p) {
     float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
     return lerpf(c0, c1, fz) * VPO_INV255;
 }
+static inline float sample_volume(const vpo_scene *sc, v3 p) { return sample_volume_channel(sc, p, 0); }
 
 /* decoded float4 tables, built once per call */
 typedef struct {
@@ -419,11 +422,12 @@ static v4 sample_2d(const v4 *tex, int32_t w, int32_t h, float s, float t) {
 }
 
 /* sampleVolumeColor: MIPRenderer.glsl:45-49 (= EAM :46-50, MCS :64-68, MCM :85-89).
- * R8 volume => .rg = (r, 0). */
+ * R8 volume => .rg = (r, 0); RG8 volume => both channels filtered, the transfer function is looked up in 2-D. */
 static inline v4 sample_volume_color(const scene_tables *t, v3 p, uint64_t *ns) {
     float r = sample_volume(t->sc, p);
+    float g = t->sc->channels == 2 ? sample_volume_channel(t->sc, p, 1) : 0.0f;
     (*ns)++;
-    return sample_2d(t->tf, t->sc->tf_w, t->sc->tf_h, r, 0.0f);
+    return sample_2d(t->tf, t->sc->tf_w, t->sc->tf_h, r, g);
 }
 
 /* sampleEnvironmentMap: MCSRenderer.glsl:59-62, MCMRenderer.glsl:80-83 (INVPI 0.31830988618).

@@ -65,8 +65,11 @@ def random_case(seed):
         vol = np.clip(255 * (1.0 - np.sqrt(x * x + y * y + z * z) / 1.1) + rng.normal(0, 12, size=dims), 0, 255).astype(np.uint8)
     else:
         vol = np.full(dims, int(rng.integers(0, 256)), dtype=np.uint8)
+    if seed % 3 == 1:                                  # a two-channel (RG8) volume: the transfer function is looked up in 2-D
+        second = rng.integers(0, 256, size=dims, dtype=np.uint8) if rng.uniform() < 0.7 else (255 - vol)
+        vol = np.ascontiguousarray(np.stack([vol, second], axis=-1))
     w, h = int(rng.integers(1, 200)), int(rng.integers(1, 140))
-    tf_w, tf_h = int(rng.choice([1, 2, 3, 7, 64, 256])), int(rng.choice([1, 1, 3]))
+    tf_w, tf_h = int(rng.choice([1, 2, 3, 7, 64, 256])), int(rng.choice([1, 1, 3, 16]))
     tf = rng.integers(0, 256, size=(tf_h, tf_w, 4), dtype=np.uint8)
     if rng.uniform() < 0.3:
         tf = None

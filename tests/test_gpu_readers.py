@@ -85,3 +85,58 @@ def test_raw_reader_from_file(gpu_ctx, tmp_path):
     a, b = render_mip(gpu_ctx, v), render_mip(gpu_ctx, whole)
     assert (a[0] == b[0]).all()
     v.destroy(); whole.destroy()
+
+
+def test_rg8_volume_through_bvp(gpu_ctx, oracle, tmp_path):
+    """a two-channel BVP modality (format RG, internalFormat RG8): blocks of interleaved bytes land where texSubImage3D puts
+    them, texture(uVolume, p).rg feeds a 2-D transfer function; every renderer equals the oracle on the same data"""
+    rng = np.random.default_rng(21)
+    vol = np.stack([sphere_volume(0, noise=35.0, dims=(22, 30, 26)), rng.integers(0, 256, size=(22, 30, 26), dtype=np.uint8)], axis=-1)
+    d, h, w = vol.shape[:3]
+    # two blocks along x with partial extents, each [bd][bh][bw][2] bytes
+    blocks = [(0, 11), (11, w)]
+    bio = io.BytesIO()
+    with zipfile.ZipFile(bio, "w", compression=zipfile.ZIP_STORED) as z:
+        for i, (x0, x1) in enumerate(blocks):
+            z.writestr("b%d.raw" % i, np.ascontiguousarray(vol[:, :, x0:x1]).tobytes())
+        manifest = {"meta": {"version": 1},
+                    "modalities": [{"name": "default", "dimensions": {"width": w, "height": h, "depth": d},
+                                    "transform": {"matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]},
+                                    "format": 33319, "internalFormat": 33323, "type": 5121,
+                                    "placements": [{"index": i, "position": {"x": x0, "y": 0, "z": 0}} for i, (x0, x1) in enumerate(blocks)]}],
+                    "blocks": [{"url": "b%d.raw" % i, "format": "raw", "dimensions": {"width": x1 - x0, "height": h, "depth": d}} for i, (x0, x1) in enumerate(blocks)]}
+        z.writestr("manifest.json", json.dumps(manifest))
+    v = vpt_amd.Volume(gpu_ctx, BVPReader(BlobLoader(bio.getvalue())))
+    v.load(); v.setFilter('linear')
+    whole = vpt_amd.Volume.from_array(gpu_ctx, vol, 'linear')
+    tf = rng.integers(0, 256, size=(9, 32, 4), dtype=np.uint8)          # 32 x 9: both axes matter
+    from conftest import default_matrix
+    W, H = 96, 72
+    m = default_matrix(W / H)
+    osc = oracle.OracleScene(vol, 'linear', tf=tf)
+    for kind in ('mip', 'eam', 'mcm'):
+        outs = []
+        for gv in (v, whole):
+            r = vpt_amd.RendererFactory(kind)(gpu_ctx, gv, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+            r.setTransferFunction(tf)
+            if kind == 'mcm':
+                r.extinction = 9
+            r.reset()
+            for _ in range(2):
+                r.render()
+            outs.append(r.getTexture()); u = r._u
+            r.destroy()
+        assert (outs[0].view(np.uint16) == outs[1].view(np.uint16)).all(), kind
+        o = oracle.OracleRenderer(kind, osc, W, H)
+        rg = GoldenRatioRng()
+        if kind == 'mcm':
+            o.reset(oracle.make_frame(W, H, m, seed=np.float32(rg())))
+            for _ in range(2):
+                o.render(oracle.make_frame(W, H, m, seed=np.float32(rg()), extinction=9))
+        else:
+            o.reset(oracle.make_frame(W, H, m))
+            for k in range(2):
+                off = np.float32(rg())
+                o.render(oracle.make_frame(W, H, m, offset=off, steps=64, extinction=100, mix=np.float32(1.0 / (k + 1))))
+        assert (outs[0].view(np.uint16).reshape(-1) == o.out).all(), "%s vs oracle" % kind
+    v.destroy(); whole.destroy()

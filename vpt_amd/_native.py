@@ -13,7 +13,7 @@ OPTION_MCM_STAGGER = 2
 PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED = 0, 1, 2
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH = 0, 1, 2, 3, 4, 5
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
-FORMAT_R8 = 0
+FORMAT_R8, FORMAT_RG8 = 0, 1
 BUFFER_RENDER, BUFFER_FRAME, BUFFER_ACCUM = 0, 1, 2
 BUFFER_MCM_POSITION, BUFFER_MCM_DIRECTION, BUFFER_MCM_TRANSMITTANCE, BUFFER_MCM_RADIANCE = 3, 4, 5, 6
 (PROBE_LOG, PROBE_SIN, PROBE_COS, PROBE_ASIN, PROBE_ATAN2, PROBE_PCG, PROBE_UNIFORM, PROBE_F16,

@@ -304,6 +304,8 @@ struct DevVolume {
     float fnx, fny, fnz;     // (float)n
     float hx, hy, hz;        // (float)(n - 1)
     int filter;              // VPT_FILTER_*
+    int channels;            // 1 = R8, 2 = RG8: the G brick follows the R brick in a 256-byte slot (R at +0, G at +128)
+    uint32_t slot_shift;     // log2 of the slot size: 7 (R8) or 8 (RG8)
 };
 // LDS image of the per-workgroup tables: [tf pairs][TX][TY][TZ]
 struct LdsTables {
@@ -335,7 +337,7 @@ VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_
         // offset costs five VALU instructions instead of riding along in the table
         uint32_t code = t.tx[x] + t.ty[y] + t.tz[z];
         uint32_t intra = (x & 3u) + (y & 3u) * 5u + (z & 3u) * 25u;
-        return v.bricks + (((uint64_t)code << 7) + intra);
+        return v.bricks + (((uint64_t)code << v.slot_shift) + intra);
     }
     return v.bricks + (uint32_t)(t.tx[x] + t.ty[y] + t.tz[z]);
 }
@@ -344,23 +346,15 @@ VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_
 #define VPT_V_WIDE    1
 #define VPT_V_NEAREST 2
 #define VPT_V_ALIGNED 4   // fetch the two tap windows as dword-aligned 12-byte loads + v_alignbyte (texture-path bound kernels)
+#define VPT_V_RG      8   // two-channel (RG8) volume: texture(uVolume, p).rg has both channels, the transfer function is looked up in 2-D
+// the eight taps around a cell of one channel's brick and their trilinear blend: taps +0,+1 (y,z) ; +5,+6 (y+1,z) ;
+// +25,+26 (y,z+1) ; +30,+31 (y+1,z+1) = two 8-byte windows of one line.
+// tools/gather_rates.hip (MI355X, L1-resident gathers): a dword-aligned 8/12/16-byte wave load costs ~27-33 cycles
+// of the CU's texture path, a byte-aligned 8-byte one 2x that.  Kernels bound by that path (MIP, EAM: ~60 VALU
+// instructions per sample) fetch 12 aligned bytes per window and realign in registers (v_alignbyte_b32); the
+// VALU-bound MCM / MCS keep the two unaligned 8-byte loads (fewer instructions).
 template <int V>
-VPT_DEV float sample_volume(const DevVolume &v, const LdsTables &t, f3 p) {
-    constexpr bool WIDE = (V & VPT_V_WIDE) != 0;
-    if (V & VPT_V_NEAREST) {
-        uint32_t x = nearest_cell(p.x, v.fnx, v.hx), y = nearest_cell(p.y, v.fny, v.hy), z = nearest_cell(p.z, v.fnz, v.hz);
-        return (float)(*cell_addr<WIDE>(v, t, x, y, z)) * VPT_INV255;
-    }
-    uint32_t x, y, z; float fx, fy, fz;
-    linear_cell(p.x, v.fnx, v.hx, x, fx);
-    linear_cell(p.y, v.fny, v.hy, y, fy);
-    linear_cell(p.z, v.fnz, v.hz, z, fz);
-    const uint8_t *a = cell_addr<WIDE>(v, t, x, y, z);
-    // taps: +0,+1 (y,z) ; +5,+6 (y+1,z) ; +25,+26 (y,z+1) ; +30,+31 (y+1,z+1): two 8-byte windows of one line.
-    // tools/gather_rates.hip (MI355X, L1-resident gathers): a dword-aligned 8/12/16-byte wave load costs ~27-33 cycles
-    // of the CU's texture path, a byte-aligned 8-byte one 2x that.  Kernels bound by that path (MIP, EAM: ~60 VALU
-    // instructions per sample) fetch 12 aligned bytes per window and realign in registers (v_alignbyte_b32); the
-    // VALU-bound MCM / MCS keep the two unaligned 8-byte loads (fewer instructions).
+VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
     uint32_t l0, h0, l1, h1;
     if (V & VPT_V_ALIGNED) {
         struct W3 { uint32_t a, b, c; };
@@ -384,6 +378,26 @@ VPT_DEV float sample_volume(const DevVolume &v, const LdsTables &t, f3 p) {
     float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
     return lerpf(c0, c1, fz) * VPT_INV255;
 }
+// texture(uVolume, p).rg: r always, g only for RG8 volumes (V & VPT_V_RG; an R8 volume has g = 0).  The cell and its
+// brick address are computed once for both channels.
+template <int V>
+VPT_DEV f2 sample_volume_rg(const DevVolume &v, const LdsTables &t, f3 p) {
+    constexpr bool WIDE = (V & VPT_V_WIDE) != 0;
+    constexpr bool RG = (V & VPT_V_RG) != 0;
+    if (V & VPT_V_NEAREST) {
+        uint32_t x = nearest_cell(p.x, v.fnx, v.hx), y = nearest_cell(p.y, v.fny, v.hy), z = nearest_cell(p.z, v.fnz, v.hz);
+        const uint8_t *a = cell_addr<WIDE>(v, t, x, y, z);
+        return f2{ (float)a[0] * VPT_INV255, RG ? (float)a[128] * VPT_INV255 : 0.0f };
+    }
+    uint32_t x, y, z; float fx, fy, fz;
+    linear_cell(p.x, v.fnx, v.hx, x, fx);
+    linear_cell(p.y, v.fny, v.hy, y, fy);
+    linear_cell(p.z, v.fnz, v.hz, z, fz);
+    const uint8_t *a = cell_addr<WIDE>(v, t, x, y, z);
+    return f2{ trilinear_taps<V>(a, fx, fy, fz), RG ? trilinear_taps<V>(a + 128, fx, fy, fz) : 0.0f };
+}
+template <int V>
+VPT_DEV float sample_volume(const DevVolume &v, const LdsTables &t, f3 p) { return sample_volume_rg<V & ~VPT_V_RG>(v, t, p).x; }
 
 // transfer function: row 0 of the decoded SRGB8_ALPHA8 table, LINEAR / CLAMP_TO_EDGE, staged in LDS as
 // (value, forward difference) pairs.  R8 volume => lookup at (r, 0): both bilinear rows clamp to row 0, so row 0
@@ -412,6 +426,16 @@ VPT_DEV void linear_taps(float s, int n, int &i0, int &i1, float &f) {
     int i = (int)fl;
     i0 = min(max(i, 0), n - 1);
     i1 = min(max(i + 1, 0), n - 1);
+}
+// the whole transfer function (w x h decoded float4 in HBM, L2-resident), LINEAR / CLAMP_TO_EDGE in both axes: the
+// lookup of RG8 volumes, texture(uTransferFunction, volumeSample.rg) (x lerps first, then y, as the oracle's sample_2d)
+VPT_DEV float4 sample_tf2d(const float4 *tf, int w, int h, float r, float g) {
+    int x0, x1, y0, y1; float fx, fy;
+    linear_taps(r, w, x0, x1, fx);
+    linear_taps(g, h, y0, y1, fy);
+    float4 r0 = lerp4(tf[(size_t)y0 * w + x0], tf[(size_t)y0 * w + x1], fx);
+    float4 r1 = lerp4(tf[(size_t)y1 * w + x0], tf[(size_t)y1 * w + x1], fx);
+    return lerp4(r0, r1, fy);
 }
 VPT_DEV float4 sample_environment(const DevEnv &e, f3 d) {
     if (e.w == 1 && e.h == 1) return e.constant;

@@ -47,8 +47,9 @@ struct vpt_context {
 struct vpt_volume {
     vpt_context *ctx;
     int nx, ny, nz;
+    int channels;          // 1 = R8, 2 = RG8 (interleaved)
     int filter;
-    uint8_t *linear;       // nx*ny*nz, the "texture storage" blocks are uploaded into
+    uint8_t *linear;       // nx*ny*nz*channels, the "texture storage" blocks are uploaded into
     uint8_t *bricks;       // apron bricks, Morton order
     size_t brick_bytes;
     uint32_t *tab32;       // separable brick-offset tables TX | TY | TZ (vpt_device.h), 32-bit form
@@ -172,33 +173,35 @@ static uint32_t host_spread3(uint32_t x) {
 }
 extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format, vpt_volume **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
-    if (format != VPT_FORMAT_R8) return fail(VPT_ERR_UNSUPPORTED, "Unknown volume datatype: %d", format);  // Volume.js:103
+    if (format != VPT_FORMAT_R8 && format != VPT_FORMAT_RG8) return fail(VPT_ERR_UNSUPPORTED, "Unknown volume datatype: %d", format);  // Volume.js:103
     if (w < 1 || h < 1 || d < 1 || w > 4096 || h > 4096 || d > 4096)
         return fail(VPT_ERR_INVALID, "volume dimensions %dx%dx%d out of range [1,4096]", w, h, d);
     HIP_TRY(hipSetDevice(c->device));
     vpt_volume *v = new vpt_volume();
     memset(v, 0, sizeof(*v));
     v->ctx = c; v->nx = w; v->ny = h; v->nz = d;
+    v->channels = format == VPT_FORMAT_RG8 ? 2 : 1;
+    const int slot_shift = v->channels == 2 ? 8 : 7;     // RG8: 256-byte slots, the R brick at +0 and the G brick at +128
     v->filter = VPT_FILTER_LINEAR;                       // Volume.js:53-54
     int nbx = (w + 3) / 4, nby = (h + 3) / 4, nbz = (d + 3) / 4;
     size_t max_slot = (size_t)(host_spread3(nbx - 1) | (host_spread3(nby - 1) << 1) | (host_spread3(nbz - 1) << 2));
-    v->brick_bytes = (max_slot + 1) * VPT_BRICK_BYTES;
-    hipError_t e = hipMalloc(&v->linear, (size_t)w * h * d);
+    v->brick_bytes = (max_slot + 1) << slot_shift;
+    hipError_t e = hipMalloc(&v->linear, (size_t)w * h * d * v->channels);
     if (e == hipSuccess) e = hipMalloc(&v->bricks, v->brick_bytes + 64);   // +64: the 8-byte tap windows end <= byte 125+7
     if (e != hipSuccess) {
         if (v->linear) hipFree(v->linear);
         delete v;
         return fail(VPT_ERR_HIP, "hipMalloc volume %dx%dx%d: %s", w, h, d, hipGetErrorString(e));
     }
-    HIP_TRY(hipMemsetAsync(v->linear, 0, (size_t)w * h * d, c->stream));   // texStorage3D zero-initialises
+    HIP_TRY(hipMemsetAsync(v->linear, 0, (size_t)w * h * d * v->channels, c->stream));   // texStorage3D zero-initialises
     {   // offset tables: off(x,y,z) = TX[x] + TY[y] + TZ[z]
         std::vector<uint64_t> t64((size_t)w + h + d);
         std::vector<uint32_t> t32(t64.size());
-        for (int i = 0; i < w; i++) t64[i] = ((uint64_t)host_spread3(i >> 2) << 7) + (uint64_t)(i & 3);
-        for (int i = 0; i < h; i++) t64[(size_t)w + i] = ((uint64_t)host_spread3(i >> 2) << 8) + (uint64_t)(i & 3) * 5;
-        for (int i = 0; i < d; i++) t64[(size_t)w + h + i] = ((uint64_t)host_spread3(i >> 2) << 9) + (uint64_t)(i & 3) * 25;
+        for (int i = 0; i < w; i++) t64[i] = ((uint64_t)host_spread3(i >> 2) << slot_shift) + (uint64_t)(i & 3);
+        for (int i = 0; i < h; i++) t64[(size_t)w + i] = ((uint64_t)host_spread3(i >> 2) << (slot_shift + 1)) + (uint64_t)(i & 3) * 5;
+        for (int i = 0; i < d; i++) t64[(size_t)w + h + i] = ((uint64_t)host_spread3(i >> 2) << (slot_shift + 2)) + (uint64_t)(i & 3) * 25;
         for (size_t i = 0; i < t64.size(); i++) t32[i] = (uint32_t)t64[i];
-        for (size_t i = 0; i < t64.size(); i++) t64[i] >>= 7;              // the brick's Morton code alone (WIDE variant)
+        for (size_t i = 0; i < t64.size(); i++) t64[i] >>= slot_shift;     // the brick's Morton code alone (WIDE variant)
         std::vector<uint32_t> tc(t64.size());
         for (size_t i = 0; i < t64.size(); i++) tc[i] = (uint32_t)t64[i];
         v->wide = v->brick_bytes > 0xffffffffull;
@@ -215,13 +218,13 @@ static int volume_upload(vpt_volume *v, int x, int y, int z, int w, int h, int d
     if (!v || !data) return fail(VPT_ERR_INVALID, "null argument");
     if (w < 1 || h < 1 || d < 1 || x < 0 || y < 0 || z < 0 || x + w > v->nx || y + h > v->ny || z + d > v->nz)
         return fail(VPT_ERR_INVALID, "block (%d,%d,%d)+(%d,%d,%d) outside volume %dx%dx%d", x, y, z, w, h, d, v->nx, v->ny, v->nz);
-    size_t need = (size_t)w * h * d;
+    size_t need = (size_t)w * h * d * v->channels;
     if (nbytes < need) return fail(VPT_ERR_INVALID, "block data too short: %zu < %zu", nbytes, need);
     vpt_context *c = v->ctx;
     HIP_TRY(hipSetDevice(c->device));
     bool full_xy = (x == 0 && y == 0 && w == v->nx && h == v->ny);
     if (full_xy) {   // contiguous run of z-slices (RAWReader.js:47-63 produces exactly these)
-        uint8_t *dst = v->linear + (size_t)z * v->nx * v->ny;
+        uint8_t *dst = v->linear + (size_t)z * v->nx * v->ny * v->channels;
         HIP_TRY(hipMemcpyAsync(dst, data, need, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     } else {
         const uint8_t *src = (const uint8_t *)data;
@@ -234,8 +237,8 @@ static int volume_upload(vpt_volume *v, int x, int y, int z, int w, int h, int d
             HIP_TRY(hipMemcpyAsync(v->staging, data, need, hipMemcpyHostToDevice, c->stream));
             src = v->staging;
         }
-        int grid = (int)((need + 255) / 256); if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(k_blit_block, dim3(grid), dim3(256), 0, c->stream, v->linear, v->nx, v->ny, src, x, y, z, w, h, d);
+        int grid = (int)((need / v->channels + 255) / 256); if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(k_blit_block, dim3(grid), dim3(256), 0, c->stream, v->linear, v->nx, v->ny, src, x, y, z, w, h, d, v->channels);
         HIP_TRY(hipGetLastError());
     }
     if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));   // host buffer may be released by the caller
@@ -255,7 +258,7 @@ extern "C" int vpt_volume_finalize(vpt_volume *v) {
     HIP_TRY(hipSetDevice(c->device));
     int nbx = (v->nx + 3) / 4, nby = (v->ny + 3) / 4, nbz = (v->nz + 3) / 4;
     if (nby > 65535 || nbz > 65535) return fail(VPT_ERR_UNSUPPORTED, "too many bricks");
-    hipLaunchKernelGGL(k_brickify, dim3((unsigned)nbx, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz);
+    hipLaunchKernelGGL(k_brickify, dim3((unsigned)nbx, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->channels);
     HIP_TRY(hipGetLastError());
     v->dirty = false;
     return VPT_OK;
@@ -489,9 +492,10 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         a->vol.hx = (float)(v->nx - 1); a->vol.hy = (float)(v->ny - 1); a->vol.hz = (float)(v->nz - 1);
         a->vol.tab32 = v->tab32; a->vol.tabc = v->tabc;
         a->vol.filter = v->filter;
+        a->vol.channels = v->channels; a->vol.slot_shift = v->channels == 2 ? 8u : 7u;
     }
     a->env.texels = r->env; a->env.w = r->env_w; a->env.h = r->env_h; a->env.constant = r->env_const;
-    a->tf = r->tf; a->tf_w = r->tf_w; a->tf_fw = (float)r->tf_w; a->tf_hi = (float)(r->tf_w - 1);
+    a->tf = r->tf; a->tf_w = r->tf_w; a->tf_h = r->tf_h; a->tf_fw = (float)r->tf_w; a->tf_hi = (float)(r->tf_w - 1);
     if (u) {
         memcpy(a->mvp_inv.m, u->mvp_inverse, sizeof(float) * 16);
         a->seed = u->rand_seed; a->offset = u->offset; a->step = u->step_size;
@@ -537,15 +541,21 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     }
     return VPT_OK;
 }
-// picks the instantiation for (offset-table width, filter): V = VPT_V_WIDE | VPT_V_NEAREST bits
+// the instantiation for (addressing, filter, channels): V = VPT_V_WIDE | VPT_V_NEAREST | VPT_V_RG bits
+static int variant_of(const vpt_renderer *r) {
+    return (r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0) | (r->vol->channels == 2 ? VPT_V_RG : 0);
+}
 #define LAUNCH_S(KT, r, a) do { \
-    int v_ = ((r)->vol->wide ? VPT_V_WIDE : 0) | ((r)->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0); \
     unsigned g_ = (unsigned)(r)->ntiles; \
-    switch (v_) { \
+    switch (variant_of(r)) { \
         case 0: VPT_TRY(launch_sampling(KT(0), (r), (a), g_)); break; \
         case 1: VPT_TRY(launch_sampling(KT(1), (r), (a), g_)); break; \
         case 2: VPT_TRY(launch_sampling(KT(2), (r), (a), g_)); break; \
-        default: VPT_TRY(launch_sampling(KT(3), (r), (a), g_)); break; \
+        case 3: VPT_TRY(launch_sampling(KT(3), (r), (a), g_)); break; \
+        case 8: VPT_TRY(launch_sampling(KT(8), (r), (a), g_)); break; \
+        case 9: VPT_TRY(launch_sampling(KT(9), (r), (a), g_)); break; \
+        case 10: VPT_TRY(launch_sampling(KT(10), (r), (a), g_)); break; \
+        default: VPT_TRY(launch_sampling(KT(11), (r), (a), g_)); break; \
     } } while (0)
 #define K_MIP0(V) (k_mip<0, V | VPT_V_ALIGNED>)
 #define K_MIP1(V) (k_mip<1, V | VPT_V_ALIGNED>)
@@ -673,7 +683,7 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
             case VPT_RENDERER_EAM: LAUNCH_S(K_EAM0, r, a); break;
             case VPT_RENDERER_ISO: LAUNCH_S(K_ISO0, r, a); break;
             case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH0, r, a); break;
-            case VPT_RENDERER_MCS: if (r->mcs_persistent) LAUNCH_MCS_PERSIST(0, r, a); else LAUNCH_S(K_MCS0, r, a); break;
+            case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1) LAUNCH_MCS_PERSIST(0, r, a); else LAUNCH_S(K_MCS0, r, a); break;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -692,7 +702,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_DEPTH: LAUNCH(k_depth_integrate, r, a, 0); break;
         case VPT_RENDERER_MCM: {
             Timed t(r, true);
-            if (r->mcm_persistent) LAUNCH_MCM_PERSIST(false, r, a); else LAUNCH_S(K_MCM0, r, a);
+            if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(false, r, a); else LAUNCH_S(K_MCM0, r, a);
             r->samples_host += r->valid_pixels * (uint64_t)u->steps;   // exactly W*H*steps per pass (MCMRenderer.glsl:129-133)
         } break;
     }
@@ -723,9 +733,9 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
         case VPT_RENDERER_EAM: LAUNCH_S(K_EAM1, r, a); break;
         case VPT_RENDERER_ISO: LAUNCH_S(K_ISO1, r, a); break;
         case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH1, r, a); break;
-        case VPT_RENDERER_MCS: if (r->mcs_persistent) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
+        case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
         case VPT_RENDERER_MCM:
-            if (r->mcm_persistent) LAUNCH_MCM_PERSIST(true, r, a); else LAUNCH_S(K_MCM1, r, a);
+            if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(true, r, a); else LAUNCH_S(K_MCM1, r, a);
             break;
     }
     return VPT_OK;
@@ -811,6 +821,18 @@ static int launch_multi(K kernel, vpt_renderer *r, const PassArgs &a, uint32_t n
     hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a, npasses);
     return VPT_OK;
 }
+static int launch_mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses) {
+    switch (variant_of(r)) {
+        case 0: return launch_multi(k_mcm_multi<0>, r, a, npasses);
+        case 1: return launch_multi(k_mcm_multi<1>, r, a, npasses);
+        case 2: return launch_multi(k_mcm_multi<2>, r, a, npasses);
+        case 3: return launch_multi(k_mcm_multi<3>, r, a, npasses);
+        case 8: return launch_multi(k_mcm_multi<8>, r, a, npasses);
+        case 9: return launch_multi(k_mcm_multi<9>, r, a, npasses);
+        case 10: return launch_multi(k_mcm_multi<10>, r, a, npasses);
+        default: return launch_multi(k_mcm_multi<11>, r, a, npasses);
+    }
+}
 static bool play_key_equal(const PassArgs &x, const PassArgs &y) { return memcmp(&x, &y, sizeof(PassArgs)) == 0; }
 
 extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int use_graph) {
@@ -859,12 +881,7 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
         {
             Timed t(r, true, (uint32_t)count);
-            switch ((r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0)) {
-                case 0: VPT_TRY(launch_multi(k_mcm_multi<0>, r, a, (uint32_t)count)); break;
-                case 1: VPT_TRY(launch_multi(k_mcm_multi<1>, r, a, (uint32_t)count)); break;
-                case 2: VPT_TRY(launch_multi(k_mcm_multi<2>, r, a, (uint32_t)count)); break;
-                default: VPT_TRY(launch_multi(k_mcm_multi<3>, r, a, (uint32_t)count)); break;
-            }
+            VPT_TRY(launch_mcm_multi(r, a, (uint32_t)count));
         }
         hipLaunchKernelGGL(k_advance_frames, dim3(1), dim3(1), 0, c->stream, r->frame_counter, (uint32_t)count);   // keeps the graph path's counter in step
         HIP_TRY(hipGetLastError());
@@ -1023,13 +1040,16 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
     if (e != hipSuccess) { hipFree(din); return fail(VPT_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpyAsync(din, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        int v = (r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0);
         dim3 grid((unsigned)((n + 255) / 256));
-        switch (v) {
+        switch (variant_of(r)) {
             case 0: hipLaunchKernelGGL(k_probe_sample<0>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
             case 1: hipLaunchKernelGGL(k_probe_sample<1>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
             case 2: hipLaunchKernelGGL(k_probe_sample<2>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            default: hipLaunchKernelGGL(k_probe_sample<3>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 3: hipLaunchKernelGGL(k_probe_sample<3>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 8: hipLaunchKernelGGL(k_probe_sample<8>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 9: hipLaunchKernelGGL(k_probe_sample<9>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 10: hipLaunchKernelGGL(k_probe_sample<10>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            default: hipLaunchKernelGGL(k_probe_sample<11>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
         }
         e = hipGetLastError();
     }
@@ -1454,12 +1474,7 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
     r->render_target = a.render;                                             // vpt_renderer_read(RENDER) returns the last frame's rows
     if (t0) HIP_TRY(hipEventRecord(t0, cs));
     if (fused_passes) {
-        switch ((r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0)) {
-            case 0: VPT_TRY(launch_multi(k_mcm_multi<0>, r, a, fused_passes)); break;
-            case 1: VPT_TRY(launch_multi(k_mcm_multi<1>, r, a, fused_passes)); break;
-            case 2: VPT_TRY(launch_multi(k_mcm_multi<2>, r, a, fused_passes)); break;
-            default: VPT_TRY(launch_multi(k_mcm_multi<3>, r, a, fused_passes)); break;
-        }
+        VPT_TRY(launch_mcm_multi(r, a, fused_passes));
         hipLaunchKernelGGL(k_advance_frames, dim3(1), dim3(1), 0, cs, r->frame_counter, fused_passes);
     } else {
         VPT_TRY(launch_fused(r, a));

@@ -73,7 +73,7 @@ struct PassArgs {
     PixMap pm;
     DevVolume vol;
     DevEnv env;
-    const float4 *tf; int tf_w; float tf_fw, tf_hi;   // decoded row 0 of the transfer function; (float)w, (float)(w-1)
+    const float4 *tf; int tf_w, tf_h; float tf_fw, tf_hi;   // decoded row 0 of the transfer function; (float)w, (float)(w-1)
     Mat4 mvp_inv;
     float seed, offset, step, extinction, inv_extinction, anisotropy;
     uint32_t max_bounces, steps;
@@ -135,6 +135,10 @@ VPT_DEV LdsTables stage_lds(float4 *lds, const PassArgs &a) {
 // sampleVolumeColor: MIPRenderer.glsl:45-49 (= EAM :46-50, MCS :64-68, MCM :85-89)
 template <int V>
 VPT_DEV float4 sample_volume_color(const PassArgs &a, const LdsTables &t, f3 p) {
+    if (V & VPT_V_RG) {
+        f2 rg = sample_volume_rg<V>(a.vol, t, p);
+        return sample_tf2d(a.tf, a.tf_w, a.tf_h, rg.x, rg.y);
+    }
     float r = sample_volume<V>(a.vol, t, p);
     return sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
 }
@@ -873,26 +877,31 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_detile(PixMap pm, const uint8_t *
     for (int b = 0; b < elem; b++) d[b] = s[b];
 }
 
-// texSubImage3D: contiguous block (bw x bh x bd) -> linear volume at (x0,y0,z0)
-__global__ void k_blit_block(uint8_t *vol, int nx, int ny, const uint8_t *blk, int x0, int y0, int z0, int bw, int bh, int bd) {
+// texSubImage3D: contiguous block (bw x bh x bd, `ch` interleaved bytes per voxel) -> linear volume at (x0,y0,z0)
+__global__ void k_blit_block(uint8_t *vol, int nx, int ny, const uint8_t *blk, int x0, int y0, int z0, int bw, int bh, int bd, int ch) {
     size_t n = (size_t)bw * bh * bd;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
         int x = (int)(t % bw); size_t r = t / bw; int y = (int)(r % bh); int z = (int)(r / bh);
-        vol[((size_t)(z0 + z) * ny + (y0 + y)) * nx + (x0 + x)] = blk[t];
+        size_t dst = (((size_t)(z0 + z) * ny + (y0 + y)) * nx + (x0 + x)) * ch;
+        for (int c = 0; c < ch; c++) vol[dst + c] = blk[t * ch + c];
     }
 }
 // linear volume -> apron bricks in Morton order; one 128-thread workgroup per brick
 // (3-D grid: a 1-D grid of 2048^3's 2^27 bricks x 128 threads exceeds HIP's 2^32 work-items per dimension)
-__global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz) {
+// `ch` = 1 (R8: 128-byte slots) or 2 (RG8: 256-byte slots, the R brick at +0 and the G brick at +128)
+__global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, int ch) {
     int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
     int t = (int)threadIdx.x;
-    uint8_t v = 0;
-    if (t < 125) {
-        int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
-        int x = min(bx * VPT_BRICK + lx, nx - 1), y = min(by * VPT_BRICK + ly, ny - 1), z = min(bz * VPT_BRICK + lz, nz - 1);
-        v = lin[((size_t)z * ny + y) * nx + x];
+    size_t slot = (size_t)morton3((uint32_t)bx, (uint32_t)by, (uint32_t)bz) << (ch == 2 ? 8 : 7);
+    for (int c = 0; c < ch; c++) {
+        uint8_t v = 0;
+        if (t < 125) {
+            int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
+            int x = min(bx * VPT_BRICK + lx, nx - 1), y = min(by * VPT_BRICK + ly, ny - 1), z = min(bz * VPT_BRICK + lz, nz - 1);
+            v = lin[(((size_t)z * ny + y) * nx + x) * ch + c];
+        }
+        bricks[slot + (size_t)c * 128 + t] = v;
     }
-    bricks[((size_t)morton3((uint32_t)bx, (uint32_t)by, (uint32_t)bz) << 7) + t] = v;
 }
 
 // streaming read: every lane pulls 16 B per iteration, grid-stride; the xor keeps the loads alive

@@ -13,6 +13,7 @@ from .loaders import AbstractLoader, BlobLoader
 
 # WebGL2 enums carried by reader metadata (RAWReader.js:36-38)
 GL_RED, GL_R8, GL_UNSIGNED_BYTE = 6403, 33321, 5121
+GL_RG, GL_RG8 = 33319, 33323              # two-channel volumes (value + e.g. gradient magnitude) of BVP manifests
 
 
 class AbstractReader:

@@ -7,7 +7,7 @@ import numpy as np
 from . import _native as N
 from .property_bag import EventTarget, CustomEvent
 
-from .readers import RAWReader, GL_RED, GL_R8, GL_UNSIGNED_BYTE      # noqa: F401  (re-exported: the in-memory RAW form lives in readers.py)
+from .readers import RAWReader, GL_RED, GL_R8, GL_RG, GL_RG8, GL_UNSIGNED_BYTE      # noqa: F401  (re-exported: the in-memory RAW form lives in readers.py)
 
 
 class Volume(EventTarget):
@@ -47,10 +47,11 @@ class Volume(EventTarget):
             L.vpt_volume_destroy(self.texture)
             self.texture = None
         dims = modality['dimensions']
-        if modality['type'] != GL_UNSIGNED_BYTE or modality['format'] != GL_RED:
+        if modality['type'] != GL_UNSIGNED_BYTE or modality['format'] not in (GL_RED, GL_RG):
             raise RuntimeError('Unknown volume datatype: %s' % modality['type'])    # Volume.js:103
+        fmt, channels = (N.FORMAT_RG8, 2) if modality['format'] == GL_RG else (N.FORMAT_R8, 1)
         h = C.c_void_p()
-        N.check(L.vpt_volume_create(self._gl._h, dims['width'], dims['height'], dims['depth'], N.FORMAT_R8, C.byref(h)))
+        N.check(L.vpt_volume_create(self._gl._h, dims['width'], dims['height'], dims['depth'], fmt, C.byref(h)))
         self.texture = h
         placements = modality['placements']
         for placement in placements:
@@ -79,16 +80,19 @@ class Volume(EventTarget):
     # ---- extension: whole-array upload (one block) for synthetic volumes ----
     @classmethod
     def from_array(cls, gl, array, filter='linear'):
-        """Upload a [depth][height][width] uint8 array as a single block (host -> HBM once)."""
+        """Upload a [depth][height][width] (R8) or [depth][height][width][2] (RG8) uint8 array (host -> HBM once)."""
         array = np.ascontiguousarray(array, dtype=np.uint8)
-        d, h, w = array.shape
-        vol = cls(gl, RAWReader(array, {'width': w, 'height': h, 'depth': d}))
+        if array.ndim == 4 and array.shape[3] != 2:
+            raise ValueError('a two-channel volume is [depth][height][width][2]')
+        d, h, w = array.shape[:3]
+        channels = 2 if array.ndim == 4 else 1
+        vol = cls(gl, RAWReader(array, {'width': w * channels, 'height': h, 'depth': d}))      # slices of w * channels bytes
         L = N.lib()
         hnd = C.c_void_p()
-        N.check(L.vpt_volume_create(gl._h, w, h, d, N.FORMAT_R8, C.byref(hnd)))
+        N.check(L.vpt_volume_create(gl._h, w, h, d, N.FORMAT_RG8 if channels == 2 else N.FORMAT_R8, C.byref(hnd)))
         vol.texture = hnd
         # chunk along z so one call stays < 2 GiB
-        zs = max(1, (1 << 30) // (w * h))
+        zs = max(1, (1 << 30) // (w * h * channels))
         for z0 in range(0, d, zs):
             z1 = min(d, z0 + zs)
             chunk = array[z0:z1]
@@ -96,6 +100,11 @@ class Volume(EventTarget):
         N.check(L.vpt_volume_finalize(hnd))
         vol.metadata = vol._reader.readMetadata()
         vol.modality = vol.metadata['modalities'][0]
+        if channels == 2:                                   # the slices were handed over as w * 2 bytes wide: restore the description
+            vol.modality['dimensions']['width'] = w
+            vol.modality['format'], vol.modality['internalFormat'] = GL_RG, GL_RG8
+            for b in vol.metadata['blocks']:
+                b['dimensions']['width'] = w
         vol.ready = True
         vol.setFilter(filter)
         return vol
