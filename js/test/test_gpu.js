@@ -146,6 +146,31 @@ async function main() {
         rc.destroy();
     }
 
+    // ---- a two-channel (RG8) volume through the Node host: with G = 0 it must render exactly like the R8 volume
+    {
+        const rg = new Uint8Array(2 * n * n * n);
+        for (let i = 0; i < n * n * n; i++) { rg[2 * i] = vol[i]; }
+        const reader = {
+            async readMetadata() {
+                const md = await new vpt.RAWReader(vol, { width: n, height: n, depth: n }).readMetadata();
+                md.modalities[0].format = vpt.GL_RG; md.modalities[0].internalFormat = vpt.GL_RG8;
+                return md;
+            },
+            async readBlock(i) { return rg.subarray(2 * i * n * n, 2 * (i + 1) * n * n); },
+        };
+        const v2 = new vpt.Volume(ctx, reader);
+        await v2.load(); v2.setFilter('linear');
+        const imgs = [volume, v2].map(v => {
+            const r = new vpt.EAMRenderer(ctx, v, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });
+            r.reset(); r.render(); r.render();
+            const out = r.getTexture().data;
+            r.destroy();
+            return out;
+        });
+        assert.deepStrictEqual(imgs[1], imgs[0], 'RG8 with G = 0 equals R8');
+        v2.destroy();
+    }
+
     // ---- frame sequences: play(count, FUSED) == count x render(), bit for bit (MCM state, MCS accumulator)
     for (const kind of ['mcm', 'mcs']) {
         const mk = () => { const R = vpt.RendererFactory(kind); const r = new R(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() }); r.extinction = 6; r.reset(); return r; };
