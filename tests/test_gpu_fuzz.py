@@ -153,3 +153,35 @@ def test_random_scene(gpu_ctx, oracle, kind, seed):
     if 'shard' not in opts:
         assert r.sample_count() == o.samples, what
     r.destroy(); gvol.destroy()
+
+
+@pytest.mark.parametrize("w,h", [(5000, 2), (2, 5000), (4099, 33), (1, 1), (17, 4097)])
+@pytest.mark.parametrize("kind", ["mip", "mcm"])
+def test_extreme_image_shapes(gpu_ctx, oracle, kind, w, h):
+    """very wide / very tall / single-pixel images: the tile -> workgroup map at its edges (tiles_x not a multiple of 8,
+    hundreds of tile rows, one-wave and four-wave workgroups)"""
+    rng = np.random.default_rng(w * 31 + h)
+    vol = rng.integers(0, 256, size=(9, 11, 13), dtype=np.uint8)
+    camera = random_camera(np.random.default_rng(5), w / h)
+    model = Transform(Node())
+    m = mvp_inverse_matrix(camera, model)
+    osc = oracle.OracleScene(vol, "linear")
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, "linear")
+    r = vpt_amd.RendererFactory(kind)(gpu_ctx, gvol, camera, None, {'resolution': (w, h), 'transform': model, 'rng': GoldenRatioRng()})
+    o = oracle.OracleRenderer(kind, osc, w, h)
+    r.reset()
+    if kind == "mcm":
+        r.extinction = 5
+        o.reset(oracle.make_frame(w, h, m, seed=np.float32(GoldenRatioRng()())))
+    else:
+        o.reset(oracle.make_frame(w, h, m))
+    rg = GoldenRatioRng(2 if kind == "mcm" else 1)
+    for k in range(2):
+        r.render()
+        if kind == "mcm":
+            o.render(oracle.make_frame(w, h, m, seed=np.float32(rg()), extinction=5, nthreads=4))
+        else:
+            o.render(oracle.make_frame(w, h, m, offset=np.float32(rg()), steps=64, nthreads=4))
+    same_bits(r.getTexture().view(np.uint16), o.out, "%s %dx%d" % (kind, w, h))
+    assert r.sample_count() == o.samples
+    r.destroy(); gvol.destroy()
