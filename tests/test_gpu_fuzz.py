@@ -185,3 +185,26 @@ def test_extreme_image_shapes(gpu_ctx, oracle, kind, w, h):
     same_bits(r.getTexture().view(np.uint16), o.out, "%s %dx%d" % (kind, w, h))
     assert r.sample_count() == o.samples
     r.destroy(); gvol.destroy()
+
+
+@pytest.mark.parametrize("dims", [(2, 3, 4096), (4096, 2, 3), (3, 4096, 1), (1, 1, 4096)])
+def test_extreme_volume_shapes(gpu_ctx, oracle, dims):
+    """a 4096-voxel axis (the largest the C ABI accepts) next to 1..3-voxel axes: offset tables, brick padding, LDS size"""
+    rng = np.random.default_rng(sum(dims))
+    vol = rng.integers(0, 256, size=dims, dtype=np.uint8)                       # (nz, ny, nx)
+    w, h = 90, 70
+    camera = random_camera(np.random.default_rng(11), w / h)
+    model = Transform(Node())
+    m = mvp_inverse_matrix(camera, model)
+    for filt in ("linear", "nearest"):
+        osc = oracle.OracleScene(vol, filt)
+        gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, filt)
+        r = vpt_amd.EAMRenderer(gpu_ctx, gvol, camera, None, {'resolution': (w, h), 'transform': model, 'rng': GoldenRatioRng()})
+        r.slices = 200
+        o = oracle.OracleRenderer('eam', osc, w, h)
+        r.reset(); o.reset(oracle.make_frame(w, h, m))
+        r.render()
+        o.render(oracle.make_frame(w, h, m, offset=np.float32(GoldenRatioRng()()), steps=200, extinction=100, mix=1.0))
+        same_bits(r.getTexture().view(np.uint16), o.out, "eam volume %s %s" % (dims, filt))
+        assert r.sample_count() == o.samples
+        r.destroy(); gvol.destroy()

@@ -184,7 +184,16 @@ extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format
     const int slot_shift = v->channels == 2 ? 8 : 7;     // RG8: 256-byte slots, the R brick at +0 and the G brick at +128
     v->filter = VPT_FILTER_LINEAR;                       // Volume.js:53-54
     int nbx = (w + 3) / 4, nby = (h + 3) / 4, nbz = (d + 3) / 4;
-    size_t max_slot = (size_t)(host_spread3(nbx - 1) | (host_spread3(nby - 1) << 1) | (host_spread3(nbz - 1) << 2));
+    // Z-order over the bricks with exactly as many bits per axis as the axis needs: the low bits of x, y, z interleave
+    // (x lowest, as the classic Morton code), and once an axis runs out of bits the longer axes continue alone — a cube
+    // gets the classic code, a 4096 x 2 x 3 volume 2^10 slots instead of 2^30.  code(bx,by,bz) = CX[bx] | CY[by] | CZ[bz].
+    int nbits[3] = { 0, 0, 0 };
+    { int nb[3] = { nbx, nby, nbz }; for (int ax = 0; ax < 3; ax++) while ((1 << nbits[ax]) < nb[ax]) nbits[ax]++; }
+    int bitpos[3][16]; int total_bits = 0;
+    for (int level = 0; level < 16; level++)
+        for (int ax = 0; ax < 3; ax++) if (level < nbits[ax]) bitpos[ax][level] = total_bits++;
+    auto axis_code = [&](int ax, uint32_t b) { uint64_t c = 0; for (int k = 0; k < nbits[ax]; k++) c |= (uint64_t)((b >> k) & 1u) << bitpos[ax][k]; return c; };
+    size_t max_slot = (size_t)(axis_code(0, (uint32_t)nbx - 1) | axis_code(1, (uint32_t)nby - 1) | axis_code(2, (uint32_t)nbz - 1));
     v->brick_bytes = (max_slot + 1) << slot_shift;
     hipError_t e = hipMalloc(&v->linear, (size_t)w * h * d * v->channels);
     if (e == hipSuccess) e = hipMalloc(&v->bricks, v->brick_bytes + 64);   // +64: the 8-byte tap windows end <= byte 125+7
@@ -197,9 +206,9 @@ extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format
     {   // offset tables: off(x,y,z) = TX[x] + TY[y] + TZ[z]
         std::vector<uint64_t> t64((size_t)w + h + d);
         std::vector<uint32_t> t32(t64.size());
-        for (int i = 0; i < w; i++) t64[i] = ((uint64_t)host_spread3(i >> 2) << slot_shift) + (uint64_t)(i & 3);
-        for (int i = 0; i < h; i++) t64[(size_t)w + i] = ((uint64_t)host_spread3(i >> 2) << (slot_shift + 1)) + (uint64_t)(i & 3) * 5;
-        for (int i = 0; i < d; i++) t64[(size_t)w + h + i] = ((uint64_t)host_spread3(i >> 2) << (slot_shift + 2)) + (uint64_t)(i & 3) * 25;
+        for (int i = 0; i < w; i++) t64[i] = (axis_code(0, (uint32_t)i >> 2) << slot_shift) + (uint64_t)(i & 3);
+        for (int i = 0; i < h; i++) t64[(size_t)w + i] = (axis_code(1, (uint32_t)i >> 2) << slot_shift) + (uint64_t)(i & 3) * 5;
+        for (int i = 0; i < d; i++) t64[(size_t)w + h + i] = (axis_code(2, (uint32_t)i >> 2) << slot_shift) + (uint64_t)(i & 3) * 25;
         for (size_t i = 0; i < t64.size(); i++) t32[i] = (uint32_t)t64[i];
         for (size_t i = 0; i < t64.size(); i++) t64[i] >>= slot_shift;     // the brick's Morton code alone (WIDE variant)
         std::vector<uint32_t> tc(t64.size());
@@ -258,7 +267,7 @@ extern "C" int vpt_volume_finalize(vpt_volume *v) {
     HIP_TRY(hipSetDevice(c->device));
     int nbx = (v->nx + 3) / 4, nby = (v->ny + 3) / 4, nbz = (v->nz + 3) / 4;
     if (nby > 65535 || nbz > 65535) return fail(VPT_ERR_UNSUPPORTED, "too many bricks");
-    hipLaunchKernelGGL(k_brickify, dim3((unsigned)nbx, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->channels);
+    hipLaunchKernelGGL(k_brickify, dim3((unsigned)nbx, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->channels, v->tabc);
     HIP_TRY(hipGetLastError());
     v->dirty = false;
     return VPT_OK;

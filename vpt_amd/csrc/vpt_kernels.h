@@ -889,10 +889,11 @@ __global__ void k_blit_block(uint8_t *vol, int nx, int ny, const uint8_t *blk, i
 // linear volume -> apron bricks in Morton order; one 128-thread workgroup per brick
 // (3-D grid: a 1-D grid of 2048^3's 2^27 bricks x 128 threads exceeds HIP's 2^32 work-items per dimension)
 // `ch` = 1 (R8: 128-byte slots) or 2 (RG8: 256-byte slots, the R brick at +0 and the G brick at +128)
-__global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, int ch) {
+// codes = the brick-code tables CX | CY | CZ (indexed by voxel coordinate): slot(bx,by,bz) = CX[4bx] + CY[4by] + CZ[4bz]
+__global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, int ch, const uint32_t *codes) {
     int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
     int t = (int)threadIdx.x;
-    size_t slot = (size_t)morton3((uint32_t)bx, (uint32_t)by, (uint32_t)bz) << (ch == 2 ? 8 : 7);
+    size_t slot = (size_t)(codes[4 * bx] + codes[nx + 4 * by] + codes[nx + ny + 4 * bz]) << (ch == 2 ? 8 : 7);
     for (int c = 0; c < ch; c++) {
         uint8_t v = 0;
         if (t < 125) {
