@@ -271,30 +271,22 @@ VPT_DEV float intersect_cube_near(f3 o, f3 d) {
 
 // ---- bricked Z-order volume -------------------------------------------------------------------
 // Layout in HBM: 4^3-voxel bricks stored with a +1 apron = 5^3 = 125 bytes in a 128-byte slot
-// (one L2 line holds every tap of a trilinear sample); brick (bx,by,bz) sits at slot morton3(bx,by,bz).
+// (one L2 line holds every tap of a trilinear sample; RG8 volumes: 256-byte slots, R brick at +0, G brick at +128).
+// Brick (bx,by,bz) sits at slot CX[bx] | CY[by] | CZ[bz]: a Z-order code with as many bits per axis as the axis needs
+// (the classic Morton code for a cube; built by the host, vpt_volume_create).
 // Inside a slot the byte of local voxel (lx,ly,lz) in [0,5)^3 is lz*25 + ly*5 + lx.
 //
 // Addressing: the byte offset of voxel cell (x,y,z) is SEPARABLE:
-//     off(x,y,z) = TX[x] + TY[y] + TZ[z],   TX[i] = (spread3(i>>2) << 7) + (i&3),
-//                                             TY[i] = (spread3(i>>2) << 8) + (i&3)*5,
-//                                             TZ[i] = (spread3(i>>2) << 9) + (i&3)*25
+//     off(x,y,z) = TX[x] + TY[y] + TZ[z],   TX[i] = (CX[i>>2] << s) + (i&3),
+//                                             TY[i] = (CY[i>>2] << s) + (i&3)*5,
+//                                             TZ[i] = (CZ[i>>2] << s) + (i&3)*25        (s = 7, or 8 for RG8)
 // The three tables (nx+ny+nz dwords) are staged in LDS once per workgroup, so a sample's address costs three
 // ds_read_b32 and one v_add3_u32 instead of ~30 VALU instructions of bit interleaving, and the 32-bit sum feeds
-// global_load's SGPR-base + VGPR-offset form directly (bricked size <= 4 GiB; WIDE tables are 64-bit otherwise).
+// global_load's SGPR-base + VGPR-offset form directly (bricked size <= 4 GiB; above that the tables hold the brick
+// codes alone and the in-brick offset is computed, cell_addr<WIDE>).
 #define VPT_BRICK        4
 #define VPT_BRICK_SHIFT  2
 #define VPT_BRICK_BYTES  128
-
-VPT_DEV uint32_t spread3(uint32_t x) {   // 10 bits -> every third bit
-    x = (x | (x << 16)) & 0x030000FFu;
-    x = (x | (x << 8))  & 0x0300F00Fu;
-    x = (x | (x << 4))  & 0x030C30C3u;
-    x = (x | (x << 2))  & 0x09249249u;
-    return x;
-}
-VPT_DEV uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
-    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
-}
 
 struct DevVolume {
     const uint8_t *bricks;

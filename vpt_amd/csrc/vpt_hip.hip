@@ -164,13 +164,6 @@ extern "C" int vpt_context_synchronize(vpt_context *c) {
 // ---------------------------------------------------------------------------------------------
 // volume — Volume.js:31-78
 // ---------------------------------------------------------------------------------------------
-static uint32_t host_spread3(uint32_t x) {
-    x = (x | (x << 16)) & 0x030000FFu;
-    x = (x | (x << 8)) & 0x0300F00Fu;
-    x = (x | (x << 4)) & 0x030C30C3u;
-    x = (x | (x << 2)) & 0x09249249u;
-    return x;
-}
 extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format, vpt_volume **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
     if (format != VPT_FORMAT_R8 && format != VPT_FORMAT_RG8) return fail(VPT_ERR_UNSUPPORTED, "Unknown volume datatype: %d", format);  // Volume.js:103
