@@ -208,3 +208,34 @@ def test_extreme_volume_shapes(gpu_ctx, oracle, dims):
         same_bits(r.getTexture().view(np.uint16), o.out, "eam volume %s %s" % (dims, filt))
         assert r.sample_count() == o.samples
         r.destroy(); gvol.destroy()
+
+
+@pytest.mark.parametrize("tf_w", [1024, 2048])
+@pytest.mark.parametrize("kind", ["eam", "mcm"])
+def test_widest_transfer_functions(gpu_ctx, oracle, kind, tf_w):
+    """transfer functions of 1024 and 2048 entries (the C ABI's limit): 32 / 64 KiB of (value, difference) pairs in LDS next to
+    the offset tables — beyond the default 64 KiB dynamic-LDS limit for the widest one"""
+    rng = np.random.default_rng(tf_w)
+    vol = rng.integers(0, 256, size=(20, 24, 28), dtype=np.uint8)
+    tf = rng.integers(0, 256, size=(1, tf_w, 4), dtype=np.uint8)
+    w, h = 64, 48
+    camera = random_camera(np.random.default_rng(3), w / h)
+    model = Transform(Node())
+    m = mvp_inverse_matrix(camera, model)
+    osc = oracle.OracleScene(vol, "linear", tf=tf)
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, "linear")
+    r = vpt_amd.RendererFactory(kind)(gpu_ctx, gvol, camera, None, {'resolution': (w, h), 'transform': model, 'rng': GoldenRatioRng()})
+    r.setTransferFunction(tf)
+    o = oracle.OracleRenderer(kind, osc, w, h)
+    r.reset()
+    if kind == "mcm":
+        r.extinction = 6
+        o.reset(oracle.make_frame(w, h, m, seed=np.float32(GoldenRatioRng()())))
+        r.render()
+        o.render(oracle.make_frame(w, h, m, seed=np.float32(GoldenRatioRng(2)()), extinction=6))
+    else:
+        o.reset(oracle.make_frame(w, h, m))
+        r.render()
+        o.render(oracle.make_frame(w, h, m, offset=np.float32(GoldenRatioRng()()), steps=64, extinction=100, mix=1.0))
+    same_bits(r.getTexture().view(np.uint16), o.out, "%s tf %d" % (kind, tf_w))
+    r.destroy(); gvol.destroy()
