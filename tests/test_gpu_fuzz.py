@@ -239,3 +239,62 @@ def test_widest_transfer_functions(gpu_ctx, oracle, kind, tf_w):
         o.render(oracle.make_frame(w, h, m, offset=np.float32(GoldenRatioRng()()), steps=64, extinction=100, mix=1.0))
     same_bits(r.getTexture().view(np.uint16), o.out, "%s tf %d" % (kind, tf_w))
     r.destroy(); gvol.destroy()
+
+
+@pytest.mark.parametrize("kind", ["mcm", "mcs", "mip"])
+def test_rg8_volume_with_frame_sequences_and_shards(gpu_ctx, oracle, kind):
+    """the RG8 kernel variants through the other launch paths: fused passes, graph replay, a row shard"""
+    rng = np.random.default_rng(77)
+    vol = rng.integers(0, 256, size=(18, 20, 22, 2), dtype=np.uint8)
+    tf = rng.integers(0, 256, size=(6, 16, 4), dtype=np.uint8)
+    w, h = 88, 60
+    camera = random_camera(np.random.default_rng(9), w / h)
+    model = Transform(Node())
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, "linear")
+
+    def make(**opts):
+        o = {'resolution': (w, h), 'transform': model, 'rng': GoldenRatioRng()}
+        o.update(opts)
+        r = vpt_amd.RendererFactory(kind)(gpu_ctx, gvol, camera, None, o)
+        r.setTransferFunction(tf)
+        if kind in ("mcm", "mcs"):
+            r.extinction = 7
+        r.reset()
+        return r
+
+    ref = make()
+    for _ in range(6):
+        ref.render()
+    want = ref.getTexture()
+    a = make(); a.play(6, fused=True)
+    same_bits(a.getTexture().view(np.uint16), want.view(np.uint16), "%s RG8 fused passes" % kind)
+    b = make(); b.render(); b.render(); b.play(4, use_graph=True)
+    same_bits(b.getTexture().view(np.uint16), want.view(np.uint16), "%s RG8 graph replay" % kind)
+    c = make(shard=(1, 3, 8))
+    for _ in range(6):
+        c.render()
+    rows = c.global_rows(); valid = rows >= 0
+    same_bits(c.getTexture()[valid].view(np.uint16), want[rows[valid]].view(np.uint16), "%s RG8 shard" % kind)
+    # and against the oracle
+    osc = oracle.OracleScene(vol, "linear", tf=tf)
+    m = mvp_inverse_matrix(camera, model)
+    o = oracle.OracleRenderer(kind, osc, w, h)
+    rg = GoldenRatioRng()
+    if kind == "mcm":
+        o.reset(oracle.make_frame(w, h, m, seed=np.float32(rg())))
+    else:
+        o.reset(oracle.make_frame(w, h, m))
+    r2 = make()
+    for k in range(6):
+        r2.render()
+        u = r2._u
+        fr = oracle.make_frame(w, h, np.array(list(u.mvp_inverse), np.float32))
+        fr.seed = u.rand_seed; fr.offset = u.offset; fr.step = u.step_size; fr.extinction = u.extinction; fr.anisotropy = u.anisotropy
+        fr.max_bounces = u.max_bounces; fr.steps = u.steps; fr.mix = u.mix; fr.blur = u.blur
+        for i in range(3):
+            fr.light_dir[i] = u.light_direction[i]
+        o.render(fr)
+    same_bits(want.view(np.uint16), o.out, "%s RG8 vs oracle" % kind)
+    for r in (ref, a, b, c, r2):
+        r.destroy()
+    gvol.destroy()
