@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--renderer", default="mcm", choices=["mcm", "mcs", "eam", "mip", "iso", "depth"])
+    ap.add_argument("--renderer", default="mcm", choices=["mcm", "mcs", "eam", "mip", "iso", "depth", "lao"])
     ap.add_argument("--extinction", type=float, default=None)
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0)

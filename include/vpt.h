@@ -39,6 +39,7 @@ extern "C" {
 #define VPT_RENDERER_MCM 3
 #define VPT_RENDERER_ISO   4   /* src/js/renderers/ISORenderer.js, src/glsl/renderers/ISORenderer.glsl */
 #define VPT_RENDERER_DEPTH 5   /* src/js/renderers/DepthRenderer.js, src/glsl/renderers/DepthRenderer.glsl */
+#define VPT_RENDERER_LAO   6   /* src/js/renderers/LAORenderer.js, src/glsl/renderers/LAORenderer.glsl */
 
 /* Volume.js:115-125 setFilter('linear' | 'nearest') */
 #define VPT_FILTER_NEAREST 0
@@ -174,6 +175,21 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * (DESIGN.md section 5).  0 = off. */
 #define VPT_OPTION_MCM_STAGGER 2
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
+/* the LAO renderer's own uniforms (gl.uniform* calls of LAORenderer.js:159-169; uStepSize and uExtinction travel in
+ * vpt_uniforms); defaults are the reference's property defaults (LAORenderer.js:17-108) */
+struct vpt_lao_params {
+    int   local_ambient_occlusion;  /* uLocalAmbientOcclusion (true) */
+    float lao_weight;               /* uLAOWeight (0.69) */
+    int   num_lao_samples;          /* uNumLAOSamples (1) */
+    float lao_step_size;            /* uLAOStepSize (0.05) */
+    int   soft_shadows;             /* uSoftShadows (true) */
+    float shadows_weight;           /* uShadowsWeight (0.54) */
+    int   num_shadow_samples;       /* uNumShadowSamples (10) */
+    float light_radius;             /* uLightRadious (0.19) */
+    float light_coefficient;        /* uLightCoeficient (1.0) */
+    float light_position[3];        /* uLightPosition (2, 12, 3) */
+};
+VPT_API int vpt_renderer_set_lao_params(vpt_renderer *r, const struct vpt_lao_params *p);
 /* volume samples executed since creation / last clear (SURVEY §8d metric) */
 VPT_API int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count);
 VPT_API int vpt_renderer_clear_sample_count(vpt_renderer *r);

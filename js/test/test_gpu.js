@@ -208,6 +208,26 @@ async function main() {
         for (let i = 0; i < W * H; i++) { if (d[i] > 0) { pos++; } else if (d[i] < 0) { neg++; } }
         assert.ok(pos > 50 && neg > 0, 'depth pos ' + pos + ' neg ' + neg);
         dep.destroy();
+        // LAO: the parameter block reaches the kernels (occlusion and shadows only ever darken), alpha is 1, frames replace
+        const lao = new vpt.LAORenderer(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });
+        assert.strictEqual(lao.properties.length, 13);
+        lao.slices = 24;
+        const shot = () => { lao.reset(); lao.render(); const a = new Uint8Array(W * H * 4); lao.read(N.VPT_BUFFER_ACCUM, a); return a; };
+        const lit = shot();
+        lao.localAmbientOcclusion = false; lao.softShadows = false;
+        const plain = shot();
+        let darker = 0, brighter = 0, lum = 0;
+        for (let i = 0; i < W * H; i++) {
+            assert.strictEqual(lit[4 * i + 3], 255);
+            for (let c = 0; c < 3; c++) { lum += plain[4 * i + c]; if (lit[4 * i + c] < plain[4 * i + c]) { darker++; } else if (lit[4 * i + c] > plain[4 * i + c]) { brighter++; } }
+        }
+        assert.ok(lum > 0 && darker > 100 && darker > 20 * brighter, 'lao darker ' + darker + ' brighter ' + brighter);
+        lao.render();
+        const again = new Uint8Array(W * H * 4); lao.read(N.VPT_BUFFER_ACCUM, again);
+        assert.deepStrictEqual(again, plain);                  // no accumulation across frames (LAORenderer.glsl:225-227)
+        lao.LAOStepSize = 0;
+        assert.throws(() => lao.render(), /step size/);
+        lao.destroy();
     }
 
     // ---- errors are thrown Errors carrying the native message

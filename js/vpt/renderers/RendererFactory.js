@@ -1,11 +1,12 @@
 'use strict';
-// src/js/renderers/RendererFactory.js:10-23 ('lao' and 'dos' are not built)
+// src/js/renderers/RendererFactory.js:10-23 ('dos' is not built)
 const { MIPRenderer } = require('./MIPRenderer.js');
 const { EAMRenderer } = require('./EAMRenderer.js');
 const { MCSRenderer } = require('./MCSRenderer.js');
 const { MCMRenderer } = require('./MCMRenderer.js');
 const { ISORenderer } = require('./ISORenderer.js');
 const { DepthRenderer } = require('./DepthRenderer.js');
+const { LAORenderer } = require('./LAORenderer.js');
 
 function RendererFactory(which) {
     switch (which) {
@@ -15,6 +16,7 @@ function RendererFactory(which) {
         case 'mcm': return MCMRenderer;
         case 'iso': return ISORenderer;
         case 'depth': return DepthRenderer;
+        case 'lao': return LAORenderer;
         default: throw new Error('No suitable class');
     }
 }

@@ -44,6 +44,30 @@ class Frame(C.Structure):
     ]
 
 
+class LaoParams(C.Structure):
+    """struct vpo_lao_params (oracle/vpt_oracle.c); defaults = LAORenderer.js:17-108"""
+    _fields_ = [("local_ambient_occlusion", C.c_int32), ("lao_weight", C.c_float), ("num_lao_samples", C.c_int32),
+                ("lao_step_size", C.c_float), ("soft_shadows", C.c_int32), ("shadows_weight", C.c_float),
+                ("num_shadow_samples", C.c_int32), ("light_radius", C.c_float), ("light_coefficient", C.c_float),
+                ("light_position", C.c_float * 3)]
+
+
+def lao_params(**kw):
+    p = LaoParams(local_ambient_occlusion=1, lao_weight=float(np.float32(0.69)), num_lao_samples=1, lao_step_size=float(np.float32(0.05)),
+                  soft_shadows=1, shadows_weight=float(np.float32(0.54)), num_shadow_samples=10, light_radius=float(np.float32(0.19)),
+                  light_coefficient=1.0)
+    p.light_position[0], p.light_position[1], p.light_position[2] = 2.0, 12.0, 3.0
+    for k, v in kw.items():
+        if k == "light_position":
+            for i in range(3):
+                p.light_position[i] = float(np.float32(v[i]))
+        elif isinstance(getattr(p, k), int):
+            setattr(p, k, int(v))
+        else:
+            setattr(p, k, float(np.float32(v)))
+    return p
+
+
 class TonemapParams(C.Structure):
     """parameters of the ten tone mappers (oracle/vpt_tonemap_oracle.c); defaults = the reference's property defaults"""
     _fields_ = [("low", C.c_float), ("mid", C.c_float), ("high", C.c_float), ("saturation", C.c_float),
@@ -111,6 +135,10 @@ def lib():
         L.vpo_depth_integrate.restype = None; L.vpo_depth_integrate.argtypes = [FP, P, P]
         L.vpo_depth_render.restype = None; L.vpo_depth_render.argtypes = [FP, P, P]
         L.vpo_depth_reset.restype = None; L.vpo_depth_reset.argtypes = [FP, P]
+        L.vpo_lao_generate.restype = C.c_uint64; L.vpo_lao_generate.argtypes = [SP, FP, C.POINTER(LaoParams), P]
+        L.vpo_lao_integrate.restype = None; L.vpo_lao_integrate.argtypes = [FP, P, P]
+        L.vpo_lao_render.restype = None; L.vpo_lao_render.argtypes = [FP, P, P]
+        L.vpo_lao_reset.restype = None; L.vpo_lao_reset.argtypes = [FP, P]
         L.vpo_mcm_reset.restype = None; L.vpo_mcm_reset.argtypes = [FP, P, P, P, P]
         L.vpo_mcm_integrate.restype = C.c_uint64; L.vpo_mcm_integrate.argtypes = [SP, FP, P, P, P, P]
         L.vpo_mcm_render.restype = None; L.vpo_mcm_render.argtypes = [FP, P, P]
@@ -188,8 +216,9 @@ class OracleRenderer:
         n = width * height
         if kind == "mip":
             self.frame = np.zeros(n, np.uint8); self.acc = np.zeros(n, np.uint8)
-        elif kind == "eam":
+        elif kind in ("eam", "lao"):
             self.frame = np.zeros(4 * n, np.uint8); self.acc = np.zeros(4 * n, np.uint8)
+            self.lao = lao_params()
         elif kind == "mcs":
             self.frame = np.zeros(4 * n, np.float32); self.acc = np.zeros(4 * n, np.float32)
         elif kind == "iso":
@@ -213,7 +242,10 @@ class OracleRenderer:
     def generate(self, fr):
         if self.kind == "mcm":
             return 0
-        n = getattr(lib(), "vpo_%s_generate" % self.kind)(C.byref(self.scene.c), C.byref(fr), _ptr(self.frame))
+        if self.kind == "lao":
+            n = lib().vpo_lao_generate(C.byref(self.scene.c), C.byref(fr), C.byref(self.lao), _ptr(self.frame))
+        else:
+            n = getattr(lib(), "vpo_%s_generate" % self.kind)(C.byref(self.scene.c), C.byref(fr), _ptr(self.frame))
         self.samples += n
         return n
 

@@ -754,6 +754,136 @@ VPO_API void vpo_depth_reset(const vpo_frame *fr, float *acc) {
 }
 
 /* ==========================================================================================
+ * LAO  (LAORenderer.glsl) — SURVEY section 8f row 3.  An experimental shader of the reference: its "random" numbers are
+ * rand(vPosition * seed) with a constant seed, i.e. one fixed value per pixel, and its frames do not accumulate
+ * (integrate copies the frame).  frame / accumulation: RGBA8 (LAORenderer.js:217-243).
+ * ======================================================================================== */
+float vpo_expf(float x);                                                    /* vpt_tonemap_oracle.c */
+float vpo_powf(float x, float y);
+typedef struct {
+    int32_t local_ambient_occlusion;    /* uLocalAmbientOcclusion */
+    float lao_weight;                   /* uLAOWeight */
+    int32_t num_lao_samples;            /* uNumLAOSamples */
+    float lao_step_size;                /* uLAOStepSize */
+    int32_t soft_shadows;               /* uSoftShadows */
+    float shadows_weight;               /* uShadowsWeight */
+    int32_t num_shadow_samples;         /* uNumShadowSamples */
+    float light_radius;                 /* uLightRadious */
+    float light_coefficient;            /* uLightCoeficient */
+    float light_position[3];            /* uLightPosition */
+} vpo_lao_params;
+/* mixins/rand.glsl:3-13 — mat2 is column-major; the two dot products are fma chains (first column first) */
+static v2 lao_rand(float px, float py) {
+    const float m00 = 23.14069263277926f, m01 = 2.665144142690225f, m10 = 12.98987893203892f, m11 = 78.23376739376591f;
+    float dx = fmaf(m10, py, m00 * px), dy = fmaf(m11, py, m01 * px);
+    float s, c, s2, c2;
+    vpo_sincosf(dx, &s, &c); vpo_sincosf(dy, &s2, &c2);
+    float ax = c * 1235.6789f, ay = s2 * 4378.5453f;
+    v2 r = { ax - floorf(ax), ay - floorf(ay) };
+    return r;
+}
+static inline float sample_volume_raw(const scene_tables *t, v3 p, uint64_t *ns) { (*ns)++; return sample_volume(t->sc, p); }
+/* generate/fragment main(): LAORenderer.glsl:97-191; the vertex stage's vLight (:25) = (M^-1 * (uLightPosition, 1)).xyz, no divide */
+VPO_API uint64_t vpo_lao_generate(const vpo_scene *sc, const vpo_frame *fr, const vpo_lao_params *lp, uint8_t *frame) {
+    scene_tables t; tables_init(&t, sc);
+    uint64_t ns = 0; int nth = clamp_threads(fr);
+    v4 lh = mat4_mul_point(fr->mvp_inv, lp->light_position[0], lp->light_position[1], lp->light_position[2]);
+    const v3 vl = { lh.x, lh.y, lh.z };
+    const float vs = 1.0f / 32.0f;                                         /* voxelSize, :59 */
+    const float rs = lao_rand(3.14f, 2.71f).x;                              /* rand(seed).x */
+    FOR_ROWS(fr) {
+        for (int32_t i = 0; i < fr->width; i++) {
+            float px = pixel_ndc(i, fr->width), py = pixel_ndc(j, fr->height);
+            v3 rf, rt;
+            unproject(px, py, fr->mvp_inv, &rf, &rt);
+            v3 dir = sub3(rt, rf);
+            v2 tb = intersect_cube(rf, dir);
+            tb.x = vmax(tb.x, 0.0f); tb.y = vmax(tb.y, 0.0f);
+            v4 o = { 0.0f, 0.0f, 0.0f, 1.0f };
+            if (!(tb.x >= tb.y)) {
+                v3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
+                const float R = lao_rand(px * 3.14f, py * 2.71f).x;         /* every rand(vPosition * seed) of the shader */
+                float tt = vclamp01((R * fr->step) * 1.5f);
+                v4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+                while (tt < 1.0f && acc.w < 0.99f) {
+                    if (acc.w > 0.98f) break;
+                    v3 pos = mix3(from, to, tt);
+                    tt += fr->step;
+                    v3 gx0 = { pos.x - vs, pos.y, pos.z }, gx1 = { pos.x + vs, pos.y, pos.z };
+                    v3 gy0 = { pos.x, pos.y - vs, pos.z }, gy1 = { pos.x, pos.y + vs, pos.z };
+                    v3 gz0 = { pos.x, pos.y, pos.z - vs }, gz1 = { pos.x, pos.y, pos.z + vs };
+                    v3 grad;
+                    grad.x = sample_volume_raw(&t, gx0, &ns) - sample_volume_raw(&t, gx1, &ns);
+                    grad.y = sample_volume_raw(&t, gy0, &ns) - sample_volume_raw(&t, gy1, &ns);
+                    grad.z = sample_volume_raw(&t, gz0, &ns) - sample_volume_raw(&t, gz1, &ns);
+                    float value = sample_volume_raw(&t, pos, &ns);
+                    float lao = 0.0f, soft = 0.0f;
+                    if (lp->local_ambient_occlusion) {
+                        float a = 0.0f;                                     /* accumuLAOContribution: not reset between samples */
+                        for (int32_t samp = 0; samp < lp->num_lao_samples; samp++) {
+                            for (float u = 0.001f; u < 1.0f; u += lp->lao_step_size) {
+                                float rc = -1.0f + 2.0f * R;
+                                v3 rd = { rc, rc, rc };
+                                rd = normalize3(rd); rd.x *= R; rd.y *= R; rd.z *= R;
+                                float m = mixf(0.0f, lp->light_radius, u);
+                                v3 hv = { (vl.x + rd.x * m) - pos.x, (vl.y + rd.y * m) - pos.y, (vl.z + rd.z * m) - pos.z };
+                                hv = normalize3(hv);
+                                v3 sp = { pos.x + hv.x * u, pos.y + hv.y * u, pos.z + hv.z * u };
+                                a += sample_volume_raw(&t, sp, &ns) * vpo_powf(1.0f - u, 2.0f);
+                                if (!(lp->lao_step_size > 0.0f)) break;     /* a zero step would never end; one sample then */
+                            }
+                            a /= lp->light_coefficient;
+                            a = vclamp01(a);
+                            lao += a;
+                        }
+                        lao /= (float)lp->num_lao_samples;
+                    }
+                    if (lp->soft_shadows) {
+                        float a = 0.0f;
+                        for (int32_t samp = 0; samp < lp->num_shadow_samples; samp++) {
+                            v3 rd = { -1.0f + vl.x * R, vl.y + R * vl.z, -1.0f + 2.0f * rs };
+                            rd = normalize3(rd); rd.x *= R; rd.y *= R; rd.z *= R;
+                            v3 sp = { pos.x + rd.x * lp->light_radius, pos.y + rd.y * lp->light_radius, pos.z + rd.z * lp->light_radius };
+                            float s1 = sample_volume_raw(&t, sp, &ns) * 0.2f;
+                            a += (sample_volume_raw(&t, sp, &ns) * s1) * vpo_powf(length3(rd), 1.0f);
+                        }
+                        a = vpo_powf(a, 1.0f);
+                        a /= (float)lp->num_shadow_samples;
+                        a *= 20.0f;
+                        a = vclamp01(a);
+                        soft = mixf(1.0f - soft, a, 1.2f);
+                    }
+                    soft /= 1.3f;
+                    soft = vclamp01(soft);
+                    v4 c = sample_2d(t.tf, sc->tf_w, sc->tf_h, value, length3(grad));     /* getColor(value, gradientMagnitude(grad)) */
+                    float w1 = lao * lp->lao_weight, w2 = soft * lp->shadows_weight;
+                    c.x = mixf(c.x, c.x * 0.15f, w1); c.y = mixf(c.y, c.y * 0.18f, w1); c.z = mixf(c.z, c.z * 0.32f, w1); c.w = mixf(c.w, c.w * 1.0f, w1);
+                    c.x = mixf(c.x, c.x * 0.15f, w2); c.y = mixf(c.y, c.y * 0.18f, w2); c.z = mixf(c.z, c.z * 0.22f, w2); c.w = mixf(c.w, c.w * 1.0f, w2);
+                    float k = 1.0f - acc.w;
+                    acc.x += (k * c.x) * value; acc.y += (k * c.y) * value; acc.z += (k * c.z) * value;
+                    acc.w += ((k * value) * fr->extinction) / 100.0f;
+                    if (acc.w > 0.9f) break;
+                }
+                if (acc.w > 1.0f) { acc.x /= acc.w; acc.y /= acc.w; acc.z /= acc.w; }
+                o.x = acc.x; o.y = acc.y; o.z = acc.z;
+            }
+            uint8_t *pxl = frame + 4 * ((size_t)j * fr->width + i);
+            pxl[0] = to_unorm8(o.x); pxl[1] = to_unorm8(o.y); pxl[2] = to_unorm8(o.z); pxl[3] = to_unorm8(o.w);
+        }
+    }
+    tables_free(&t);
+    return ns;
+}
+/* integrate: LAORenderer.glsl:225-227 — oColor = texture(uFrame): the frame replaces the accumulation */
+VPO_API void vpo_lao_integrate(const vpo_frame *fr, uint8_t *acc, const uint8_t *frame) {
+    for (int32_t j = fr->y0; j < fr->y1; j++)
+        memcpy(acc + 4 * (size_t)j * fr->width, frame + 4 * (size_t)j * fr->width, 4 * (size_t)fr->width);
+}
+/* render: LAORenderer.glsl:259-261; reset: :285-287 — as EAM's */
+VPO_API void vpo_lao_render(const vpo_frame *fr, const uint8_t *acc, uint16_t *out) { vpo_eam_render(fr, acc, out); }
+VPO_API void vpo_lao_reset(const vpo_frame *fr, uint8_t *acc) { vpo_eam_reset(fr, acc); }
+
+/* ==========================================================================================
  * MCS  (MCSRenderer.glsl)
  * ======================================================================================== */
 #define VPO_MAX_TRACK_ITERS 65536u   /* safety net shared with the GPU kernels */

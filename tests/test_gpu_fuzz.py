@@ -15,7 +15,7 @@ from vpt_amd.synthetic import GoldenRatioRng
 pytestmark = pytest.mark.gpu
 
 MCM_BUFFERS = [N.BUFFER_MCM_POSITION, N.BUFFER_MCM_DIRECTION, N.BUFFER_MCM_TRANSMITTANCE, N.BUFFER_MCM_RADIANCE]
-KINDS = ["mip", "eam", "mcs", "mcm", "iso", "depth"]
+KINDS = ["mip", "eam", "mcs", "mcm", "iso", "depth", "lao"]
 
 
 def same_bits(got, want, what):
@@ -86,7 +86,7 @@ def random_case(seed):
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("seed", range(40))
 def test_random_scene(gpu_ctx, oracle, kind, seed):
-    rng, vol, (w, h), tf, env, filt, model = random_case(seed * 6 + KINDS.index(kind))
+    rng, vol, (w, h), tf, env, filt, model = random_case(seed * 6 + KINDS.index(kind) if kind != "lao" else 5000 + seed)
     camera = random_camera(rng, w / h)
     m = mvp_inverse_matrix(camera, model)
     osc = oracle.OracleScene(vol, filt, tf=tf, env=env)
@@ -119,7 +119,19 @@ def test_random_scene(gpu_ctx, oracle, kind, seed):
         r.steps = int(rng.choice([1, 2, 7, 50])); r.isovalue = float(rng.choice([0.0, 0.2, 0.5, 1.0])); r.light = [float(v) for v in rng.uniform(-3, 3, size=3)]
     elif kind == "depth":
         r.slices = int(rng.choice([1, 9, 64])); r.extinction = float(rng.choice([0.0, 10.0, 100.0])); r.threshold = float(rng.choice([0.0, 0.1, 0.9])); r.random = bool(rng.integers(0, 2))
+    elif kind == "lao":
+        r.slices = int(rng.choice([1, 7, 24])); r.extinction = float(rng.choice([0.0, 30.0, 100.0, 400.0]))
+        r.localAmbientOcclusion = bool(rng.integers(0, 2)); r.softShadows = bool(rng.integers(0, 2))
+        r.LAOWeight = float(rng.uniform(0, 1)); r.shadowsWeight = float(rng.uniform(0, 1))
+        r.numLAOSamples = int(rng.integers(1, 4)); r.numShadowSamples = int(rng.integers(1, 12))
+        r.LAOStepSize = float(rng.choice([0.01, 0.05, 0.3, 1.5])); r.lightRadious = float(rng.choice([0.0, 0.19, 0.7]))
+        r.lightCoeficient = float(rng.choice([0.5, 1.0, 3.0])); r.lightPosition = [float(v) for v in rng.uniform(-12, 12, size=3)]
     o = oracle.OracleRenderer(kind, osc, w, h)
+    if kind == "lao":
+        o.lao = oracle.lao_params(local_ambient_occlusion=int(r.localAmbientOcclusion), lao_weight=r.LAOWeight, num_lao_samples=r.numLAOSamples,
+                                  lao_step_size=r.LAOStepSize, soft_shadows=int(r.softShadows), shadows_weight=r.shadowsWeight,
+                                  num_shadow_samples=r.numShadowSamples, light_radius=r.lightRadious, light_coefficient=r.lightCoeficient,
+                                  light_position=r.lightPosition)
     what = "%s seed %d (%dx%d image, volume %s, %s, fused=%s, shard=%s)" % (kind, seed, w, h, vol.shape, filt, fused, opts.get('shard'))
 
     def frame_of(u):

@@ -330,7 +330,7 @@ def test_native_rccl_gather_single_rank(gpu_ctx, oracle):
 
 def test_errors_are_loud(gpu_ctx):
     with pytest.raises(RuntimeError, match="No suitable class"):
-        vpt_amd.RendererFactory('lao')
+        vpt_amd.RendererFactory('dos')
     r = vpt_amd.MIPRenderer(gpu_ctx, None, default_camera(), None, {'resolution': 32})
     r.reset()
     with pytest.raises(vpt_amd.VptError, match="no ready volume"):

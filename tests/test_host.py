@@ -25,7 +25,7 @@ def test_renderer_factory_names():
     assert vpt_amd.RendererFactory('mcs') is vpt_amd.MCSRenderer
     assert vpt_amd.RendererFactory('mcm') is vpt_amd.MCMRenderer
     assert vpt_amd.RendererFactory('iso') is vpt_amd.ISORenderer and vpt_amd.RendererFactory('depth') is vpt_amd.DepthRenderer
-    for name in ('lao', 'dos', 'nope'):
+    for name in ('dos', 'nope'):
         with pytest.raises(RuntimeError, match='No suitable class'):      # RendererFactory.js:21
             vpt_amd.RendererFactory(name)
 

@@ -11,7 +11,7 @@ OPTION_MCS_PERSISTENT = 0
 OPTION_MCM_PERSISTENT = 1
 OPTION_MCM_STAGGER = 2
 PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED = 0, 1, 2
-RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH = 0, 1, 2, 3, 4, 5
+RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO = 0, 1, 2, 3, 4, 5, 6
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 FORMAT_R8, FORMAT_RG8 = 0, 1
 BUFFER_RENDER, BUFFER_FRAME, BUFFER_ACCUM = 0, 1, 2
@@ -34,7 +34,7 @@ SYMBOLS = [
     "vpt_renderer_reset", "vpt_renderer_generate", "vpt_renderer_integrate", "vpt_renderer_render_frame",
     "vpt_renderer_render", "vpt_renderer_play", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
     "vpt_renderer_set_render_target",
-    "vpt_renderer_set_option", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
+    "vpt_renderer_set_option", "vpt_renderer_set_lao_params", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile",
     "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play", "vpt_gather_set_root",
     "vpt_gather_synchronize",
@@ -57,6 +57,14 @@ class Uniforms(C.Structure):
         ("mix", C.c_float), ("blur", C.c_float),
         ("isovalue", C.c_float), ("gradient_step", C.c_float), ("threshold", C.c_float), ("reserved", C.c_float),
     ]
+
+
+class LaoParams(C.Structure):
+    """struct vpt_lao_params (include/vpt.h)"""
+    _fields_ = [("local_ambient_occlusion", C.c_int32), ("lao_weight", C.c_float), ("num_lao_samples", C.c_int32),
+                ("lao_step_size", C.c_float), ("soft_shadows", C.c_int32), ("shadows_weight", C.c_float),
+                ("num_shadow_samples", C.c_int32), ("light_radius", C.c_float), ("light_coefficient", C.c_float),
+                ("light_position", C.c_float * 3)]
 
 
 class TonemapParams(C.Structure):
@@ -109,6 +117,7 @@ def lib():
         "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
         "vpt_renderer_set_render_target": [P, P, SZ],
         "vpt_renderer_set_option": [P, I, I],
+        "vpt_renderer_set_lao_params": [P, C.POINTER(LaoParams)],
         "vpt_renderer_sample_count": [P, C.POINTER(C.c_uint64)], "vpt_renderer_clear_sample_count": [P],
         "vpt_renderer_set_profiling": [P, I],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],

@@ -83,6 +83,7 @@ struct vpt_renderer {
     struct PlayGraph *play_graph;  // cached hipGraph of a frame sequence
     uint32_t *work_counter;        // tile counter of the persistent MCS kernel
     bool mcs_persistent;           // use k_mcs_persist (active-ray compaction) for the MCS generate pass
+    LaoParams lao;                 // LAO renderer parameters (vpt_renderer_set_lao_params; defaults LAORenderer.js:17-108)
     int mcm_stagger;               // VPT_OPTION_MCM_STAGGER: phase-stagger quantum (10 ns ticks) | pattern << 24; 0 = off
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
@@ -107,6 +108,7 @@ static size_t frame_elem(int kind) {
         case VPT_RENDERER_MCS: return 16;
         case VPT_RENDERER_ISO: return 8;      // RGBA16F (ISORenderer.js:165-197)
         case VPT_RENDERER_DEPTH: return 4;    // R32F (DepthRenderer.js:165-189)
+        case VPT_RENDERER_LAO: return 4;      // RGBA8 (LAORenderer.js:217-243)
         default: return 0;
     }
 }
@@ -394,7 +396,7 @@ extern "C" int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba
 }
 extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int height, vpt_renderer **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
-    if (kind < VPT_RENDERER_MIP || kind > VPT_RENDERER_DEPTH) return fail(VPT_ERR_INVALID, "No suitable class");  // RendererFactory.js:21
+    if (kind < VPT_RENDERER_MIP || kind > VPT_RENDERER_LAO) return fail(VPT_ERR_INVALID, "No suitable class");  // RendererFactory.js:21
     if (width < 1 || height < 1 || width > 32768 || height > 32768) return fail(VPT_ERR_INVALID, "resolution %dx%d out of range", width, height);
     HIP_TRY(hipSetDevice(c->device));
     vpt_renderer *r = new vpt_renderer();
@@ -410,6 +412,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->warmed = false; r->play_graph = nullptr;
     r->mcm_stagger = 0; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
+    r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
         hipError_t e = hipMalloc(&r->samples, COUNTER_BYTES);
@@ -508,6 +511,7 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         a->mix = u->mix; a->blur = u->blur;
         a->isovalue = u->isovalue; a->gradient_step = u->gradient_step; a->threshold = u->threshold;
     }
+    a->lao = r->lao;
     a->stagger_ticks = (uint32_t)(r->mcm_stagger & 0xffffff); a->stagger_pattern = (uint32_t)(r->mcm_stagger >> 24) & 1u;
     a->stagger_blocks = 256u * 7u;                  // the workgroups resident at launch: 256 CUs x 7 (28 waves per CU)
     a->inv_w = (float)(1.0 / (double)r->W);     // gl.uniform2f(uInverseResolution, 1/res, 1/res): MCMRenderer.js:91,155
@@ -570,6 +574,8 @@ static int variant_of(const vpt_renderer *r) {
 #define K_ISOR(V) (k_iso_render<V>)
 #define K_DEPTH0(V) (k_depth<0, V>)
 #define K_DEPTH1(V) (k_depth<1, V>)
+#define K_LAO0(V) (k_lao<0, V>)
+#define K_LAO1(V) (k_lao<1, V>)
 #define K_MCM0(V) (k_mcm_integrate<false, V>)
 #define K_MCM1(V) (k_mcm_integrate<true, V>)
 
@@ -666,6 +672,7 @@ extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_MCM: LAUNCH(k_mcm_reset, r, a, 0); break;
         case VPT_RENDERER_ISO: LAUNCH(k_iso_reset, r, a, 0); break;
         case VPT_RENDERER_DEPTH: LAUNCH(k_depth_reset, r, a, 0); break;
+        case VPT_RENDERER_LAO: LAUNCH(k_eam_reset, r, a, 0); break;           // LAORenderer.glsl:285-287: (0, 0, 0, 1) into RGBA8
     }
     HIP_TRY(hipGetLastError());
     return VPT_OK;
@@ -685,6 +692,7 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
             case VPT_RENDERER_EAM: LAUNCH_S(K_EAM0, r, a); break;
             case VPT_RENDERER_ISO: LAUNCH_S(K_ISO0, r, a); break;
             case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH0, r, a); break;
+            case VPT_RENDERER_LAO: LAUNCH_S(K_LAO0, r, a); break;
             case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1) LAUNCH_MCS_PERSIST(0, r, a); else LAUNCH_S(K_MCS0, r, a); break;
         }
     }
@@ -702,6 +710,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_integrate, r, a, 0); break;
         case VPT_RENDERER_ISO: LAUNCH(k_iso_integrate, r, a, 0); break;
         case VPT_RENDERER_DEPTH: LAUNCH(k_depth_integrate, r, a, 0); break;
+        case VPT_RENDERER_LAO: LAUNCH(k_lao_integrate, r, a, 0); break;
         case VPT_RENDERER_MCM: {
             Timed t(r, true);
             if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(false, r, a); else LAUNCH_S(K_MCM0, r, a);
@@ -720,6 +729,7 @@ extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u)
     switch (r->kind) {
         case VPT_RENDERER_ISO: LAUNCH_S(K_ISOR, r, a); break;
         case VPT_RENDERER_DEPTH: LAUNCH(k_depth_render, r, a, 0); break;
+        case VPT_RENDERER_LAO: LAUNCH(k_eam_render, r, a, 0); break;           // LAORenderer.glsl:259-261
         case VPT_RENDERER_MIP: LAUNCH(k_mip_render, r, a, 0); break;
         case VPT_RENDERER_EAM: LAUNCH(k_eam_render, r, a, 0); break;
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_render, r, a, 0); break;
@@ -735,6 +745,7 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
         case VPT_RENDERER_EAM: LAUNCH_S(K_EAM1, r, a); break;
         case VPT_RENDERER_ISO: LAUNCH_S(K_ISO1, r, a); break;
         case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH1, r, a); break;
+        case VPT_RENDERER_LAO: LAUNCH_S(K_LAO1, r, a); break;
         case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
         case VPT_RENDERER_MCM:
             if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(true, r, a); else LAUNCH_S(K_MCM1, r, a);
@@ -745,7 +756,7 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
 extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(r->ctx->device));
-    if (r->kind == VPT_RENDERER_MIP || r->kind == VPT_RENDERER_EAM || r->kind == VPT_RENDERER_ISO || r->kind == VPT_RENDERER_DEPTH) VPT_TRY(check_step(u));
+    if (r->kind != VPT_RENDERER_MCS && r->kind != VPT_RENDERER_MCM) VPT_TRY(check_step(u));
     if (r->kind == VPT_RENDERER_ISO) VPT_TRY(check_iso(u));
     PassArgs a;
     VPT_TRY(make_args(r, u, true, &a));
@@ -870,6 +881,7 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
     } else if (use_graph == VPT_PLAY_FUSED && r->kind != VPT_RENDERER_MCM) {
         // the accumulating renderers: the pass loop lives in their fused kernels (PassArgs.multi_passes)
         if (r->kind == VPT_RENDERER_ISO) return fail(VPT_ERR_UNSUPPORTED, "fused passes are not implemented for the ISO renderer");
+        if (r->kind == VPT_RENDERER_LAO) return fail(VPT_ERR_UNSUPPORTED, "fused passes are pointless for the LAO renderer: its frames do not accumulate");
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
         a.multi_passes = (uint32_t)count;
         {
@@ -950,6 +962,16 @@ extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t
     size_t need = (size_t)r->W * r->local_h * 8;
     if (ptr && nbytes < need) return fail(VPT_ERR_INVALID, "render target too small: %zu < %zu", nbytes, need);
     r->render_target = (uint2 *)ptr;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_set_lao_params(vpt_renderer *r, const struct vpt_lao_params *p) {
+    if (!r || !p) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind != VPT_RENDERER_LAO) return fail(VPT_ERR_INVALID, "not an LAO renderer");
+    if (p->num_lao_samples < 1 || p->num_lao_samples > 64 || p->num_shadow_samples < 1 || p->num_shadow_samples > 1024)
+        return fail(VPT_ERR_INVALID, "sample counts out of range (LAO 1..64, shadows 1..1024)");
+    if (!(p->lao_step_size >= 1.0f / 4096.0f)) return fail(VPT_ERR_INVALID, "LAO step size below 1/4096 (the occlusion march would not end)");
+    static_assert(sizeof(LaoParams) == sizeof(vpt_lao_params), "parameter block layout");
+    memcpy(&r->lao, p, sizeof(r->lao));
     return VPT_OK;
 }
 extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {

@@ -69,6 +69,11 @@ VPT_DEV Pix map_pixel(const PixMap &m) {
 VPT_DEV float ndc_col(const PixMap &m, int i) { return m.ndc_x[i]; }
 VPT_DEV float ndc_row(const PixMap &m, int j) { return m.ndc_y[j]; }
 
+struct LaoParams {               // = struct vpt_lao_params (include/vpt.h)
+    int local_ambient_occlusion; float lao_weight; int num_lao_samples; float lao_step_size;
+    int soft_shadows; float shadows_weight; int num_shadow_samples; float light_radius; float light_coefficient;
+    float light_position[3];
+};
 struct PassArgs {
     PixMap pm;
     DevVolume vol;
@@ -81,6 +86,7 @@ struct PassArgs {
     float mix, blur, inv_w, inv_h;
     float isovalue, gradient_step, threshold;   // ISO / Depth (vpt_kernels_iso_depth.h)
     uint32_t stagger_ticks, stagger_blocks, stagger_pattern;   // MCM phase staggering (k_mcm_integrate), 0 = off
+    LaoParams lao;               // LAO renderer (vpt_kernels_iso_depth.h)
     uint32_t multi_passes;       // > 1: the fused (MODE 1) kernels run that many passes per pixel in one launch (VPT_PLAY_FUSED)
     void *frame;                 // tile order
     void *acc;                   // tile order (ping-pong collapsed: each pixel reads and writes only itself)

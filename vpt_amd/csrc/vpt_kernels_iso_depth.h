@@ -177,3 +177,123 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_depth_reset(PassArgs a) {  // Dep
     Pix p = map_pixel(a.pm);
     if (p.tile) ((float *)a.acc)[p.k] = 0.0f;
 }
+
+// =============================================================================================
+// LAO — src/glsl/renderers/LAORenderer.glsl.  An experimental shader of the reference: its
+// "random" numbers are rand(vPosition * seed) with a constant seed — one fixed value per pixel — and frames do not
+// accumulate (integrate copies the frame).  frame / accumulation: RGBA8 (LAORenderer.js:217-243).
+// =============================================================================================
+// mixins/rand.glsl:3-13 (mat2 is column-major; the dot products are fma chains, first column first)
+VPT_DEV f2 lao_rand(float px, float py) {
+    const float m00 = 23.14069263277926f, m01 = 2.665144142690225f, m10 = 12.98987893203892f, m11 = 78.23376739376591f;
+    float dx = fmaf(m10, py, m00 * px), dy = fmaf(m11, py, m01 * px);
+    float s, c, s2, c2;
+    vpt_sincosf(dx, s, c); vpt_sincosf(dy, s2, c2);
+    float ax = c * 1235.6789f, ay = s2 * 4378.5453f;
+    return f2{ ax - floorf(ax), ay - floorf(ay) };
+}
+// generate/fragment main(): LAORenderer.glsl:97-191; vLight (:25) = (M^-1 * (uLightPosition, 1)).xyz, no divide
+template <int V>
+VPT_DEV uint32_t lao_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
+    float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
+    f3 rf, rt;
+    unproject(px, py, a.mvp_inv, rf, rt);
+    f3 dir = sub3(rt, rf);
+    f2 tb = intersect_cube(rf, dir);
+    tb.x = vmax(tb.x, 0.0f); tb.y = vmax(tb.y, 0.0f);
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+    if (!(tb.x >= tb.y)) {
+        const LaoParams &lp = a.lao;
+        float4 lh = mat4_mul_point(a.mvp_inv, lp.light_position[0], lp.light_position[1], lp.light_position[2]);
+        const f3 vl = { lh.x, lh.y, lh.z };
+        const float vs = 1.0f / 32.0f;                                   // voxelSize, :59
+        const float rs = lao_rand(3.14f, 2.71f).x;                        // rand(seed).x
+        f3 from = mix3(rf, rt, tb.x), to = mix3(rf, rt, tb.y);
+        const float R = lao_rand(px * 3.14f, py * 2.71f).x;               // every rand(vPosition * seed) of the shader
+        float tt = vclamp01((R * a.step) * 1.5f);
+        float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;
+        while (tt < 1.0f && aw < 0.99f) {
+            if (aw > 0.98f) break;
+            f3 pos = mix3(from, to, tt);
+            tt += a.step;
+            f3 grad;
+            grad.x = sample_volume<V>(a.vol, t, f3{ pos.x - vs, pos.y, pos.z }) - sample_volume<V>(a.vol, t, f3{ pos.x + vs, pos.y, pos.z });
+            grad.y = sample_volume<V>(a.vol, t, f3{ pos.x, pos.y - vs, pos.z }) - sample_volume<V>(a.vol, t, f3{ pos.x, pos.y + vs, pos.z });
+            grad.z = sample_volume<V>(a.vol, t, f3{ pos.x, pos.y, pos.z - vs }) - sample_volume<V>(a.vol, t, f3{ pos.x, pos.y, pos.z + vs });
+            float value = sample_volume<V>(a.vol, t, pos);
+            ns += 7;
+            float lao = 0.0f, soft = 0.0f;
+            if (lp.local_ambient_occlusion) {
+                float acc = 0.0f;                                         // accumuLAOContribution: not reset between samples
+                for (int samp = 0; samp < lp.num_lao_samples; samp++) {
+                    for (float u = 0.001f; u < 1.0f; u += lp.lao_step_size) {
+                        float rc = -1.0f + 2.0f * R;
+                        f3 rd = normalize3(f3{ rc, rc, rc });
+                        rd = f3{ rd.x * R, rd.y * R, rd.z * R };
+                        float m = mixf(0.0f, lp.light_radius, u);
+                        f3 hv = normalize3(f3{ (vl.x + rd.x * m) - pos.x, (vl.y + rd.y * m) - pos.y, (vl.z + rd.z * m) - pos.z });
+                        f3 sp = { pos.x + hv.x * u, pos.y + hv.y * u, pos.z + hv.z * u };
+                        acc += sample_volume<V>(a.vol, t, sp) * vpt_powf(1.0f - u, 2.0f);
+                        ns++;
+                        if (!(lp.lao_step_size > 0.0f)) break;             // a zero step would never end: one sample then
+                    }
+                    acc /= lp.light_coefficient;
+                    acc = vclamp01(acc);
+                    lao += acc;
+                }
+                lao /= (float)lp.num_lao_samples;
+            }
+            if (lp.soft_shadows) {
+                float acc = 0.0f;
+                for (int samp = 0; samp < lp.num_shadow_samples; samp++) {
+                    f3 rd = normalize3(f3{ -1.0f + vl.x * R, vl.y + R * vl.z, -1.0f + 2.0f * rs });
+                    rd = f3{ rd.x * R, rd.y * R, rd.z * R };
+                    f3 sp = { pos.x + rd.x * lp.light_radius, pos.y + rd.y * lp.light_radius, pos.z + rd.z * lp.light_radius };
+                    float v1 = sample_volume<V>(a.vol, t, sp);             // the shader samples this position twice
+                    acc += (v1 * (v1 * 0.2f)) * vpt_powf(length3(rd), 1.0f);
+                    ns += 2;
+                }
+                acc = vpt_powf(acc, 1.0f);
+                acc /= (float)lp.num_shadow_samples;
+                acc *= 20.0f;
+                acc = vclamp01(acc);
+                soft = mixf(1.0f - soft, acc, 1.2f);
+            }
+            soft /= 1.3f;
+            soft = vclamp01(soft);
+            float4 c = sample_tf2d(a.tf, a.tf_w, a.tf_h, value, length3(grad));   // getColor(value, gradientMagnitude(grad))
+            float w1 = lao * lp.lao_weight, w2 = soft * lp.shadows_weight;
+            c = make_float4(mixf(c.x, c.x * 0.15f, w1), mixf(c.y, c.y * 0.18f, w1), mixf(c.z, c.z * 0.32f, w1), mixf(c.w, c.w * 1.0f, w1));
+            c = make_float4(mixf(c.x, c.x * 0.15f, w2), mixf(c.y, c.y * 0.18f, w2), mixf(c.z, c.z * 0.22f, w2), mixf(c.w, c.w * 1.0f, w2));
+            float k = 1.0f - aw;
+            ax += (k * c.x) * value; ay += (k * c.y) * value; az += (k * c.z) * value;
+            aw += ((k * value) * a.extinction) / 100.0f;
+            if (aw > 0.9f) break;
+        }
+        if (aw > 1.0f) { ax /= aw; ay /= aw; az /= aw; }
+        ox = ax; oy = ay; oz = az;
+    }
+    return to_unorm8(ox) | (to_unorm8(oy) << 8) | (to_unorm8(oz) << 16) | (to_unorm8(1.0f) << 24);
+}
+// MODE 0: _generateFrame only.  MODE 1: the whole render(): generate, integrate (copy, LAORenderer.glsl:225-227), renderFrame
+template <int MODE, int V>
+__global__ void __launch_bounds__(VPT_BLOCK) k_lao(PassArgs a) {
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    Pix p = map_pixel(a.pm);
+    uint32_t ns = 0;
+    if (p.valid) {
+        uint32_t q = lao_pixel<V>(a, t, p, ns);
+        if (MODE == 0) {
+            ((uint32_t *)a.frame)[p.k] = q;
+        } else {
+            ((uint32_t *)a.acc)[p.k] = q;
+            a.render[(size_t)p.l * a.pm.W + p.i] = eam_to_half4(q);
+        }
+    }
+    count_samples(a.samples, ns);
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_lao_integrate(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (p.valid) ((uint32_t *)a.acc)[p.k] = ((const uint32_t *)a.frame)[p.k];
+}

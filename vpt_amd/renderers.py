@@ -180,7 +180,7 @@ class AbstractRenderer(PropertyBag):
         elif buffer in (N.BUFFER_FRAME, N.BUFFER_ACCUM):
             if self._KIND == N.RENDERER_MIP:
                 arr = np.empty((rows, w), dtype=np.uint8)
-            elif self._KIND == N.RENDERER_EAM:
+            elif self._KIND in (N.RENDERER_EAM, N.RENDERER_LAO):
                 arr = np.empty((rows, w, 4), dtype=np.uint8)
             elif self._KIND == N.RENDERER_ISO:
                 arr = np.empty((rows, w, 4), dtype=np.float16)
@@ -575,10 +575,80 @@ for _cls in (MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer, ISORenderer, De
     _cls._BASE = _cls
 
 
+class LAORenderer(AbstractRenderer):
+    """src/js/renderers/LAORenderer.js:13-245: emission-absorption with local ambient occlusion
+    and soft shadows; each frame replaces the accumulator (LAORenderer.glsl:225-227)"""
+    _KIND = N.RENDERER_LAO
+
+    def __init__(self, gl, volume, camera, environmentTexture, options=None):
+        super().__init__(gl, volume, camera, environmentTexture, options)
+        self.registerProperties([                                  # :17-108
+            {'name': 'extinction', 'label': 'Extinction', 'type': 'spinner', 'value': 100, 'min': 0},
+            {'name': 'localAmbientOcclusion', 'label': 'Local Ambient Occlusion', 'type': 'checkbox', 'value': True},
+            {'name': 'LAOWeight', 'label': 'LAO Weight', 'type': 'spinner', 'value': 0.69, 'min': 0, 'max': 1},
+            {'name': 'numLAOSamples', 'label': '# of LAO Samples', 'type': 'spinner', 'value': 1, 'min': 1},
+            {'name': 'LAOStepSize', 'label': 'LAO Stem Size', 'type': 'spinner', 'value': 0.05, 'min': 0},
+            {'name': 'softShadows', 'label': 'Soft Shadows', 'type': 'checkbox', 'value': True},
+            {'name': 'shadowsWeight', 'label': 'Shadows Weight', 'type': 'spinner', 'value': 0.54, 'min': 0, 'max': 1},
+            {'name': 'numShadowSamples', 'label': '# of Shadow Samples', 'type': 'spinner', 'value': 10, 'min': 1},
+            {'name': 'lightRadious', 'label': 'Light Radious', 'type': 'spinner', 'value': 0.19, 'min': 0},
+            {'name': 'lightPosition', 'label': 'Light position', 'type': 'vector-spinner', 'value': [2, 12, 3]},
+            {'name': 'lightCoeficient', 'label': 'Light Coeficient', 'type': 'spinner', 'value': 1.0, 'min': 0},
+            {'name': 'slices', 'label': 'Slices', 'type': 'spinner', 'value': 64, 'min': 1},
+            dict(_TF_PROPERTY),
+        ])
+        _install_change_handler(self, ('extinction', 'slices', 'transferFunction'))   # :110-124
+
+    def lao_params(self):
+        """the gl.uniform* block of :159-169 as struct vpt_lao_params"""
+        p = N.LaoParams()
+        p.local_ambient_occlusion = int(bool(self.localAmbientOcclusion))
+        p.lao_weight = _f32(self.LAOWeight)
+        p.num_lao_samples = int(self.numLAOSamples)
+        p.lao_step_size = _f32(self.LAOStepSize)
+        p.soft_shadows = int(bool(self.softShadows))
+        p.shadows_weight = _f32(self.shadowsWeight)
+        p.num_shadow_samples = int(self.numShadowSamples)
+        p.light_radius = _f32(self.lightRadious)
+        p.light_coefficient = _f32(self.lightCoeficient)
+        for i in range(3):
+            p.light_position[i] = _f32(self.lightPosition[i])
+        return p
+
+    def _resetFrame(self):                                         # :138-145
+        N.check(N.lib().vpt_renderer_reset(self._h, None))
+
+    def _prepare_generate(self):                                   # :147-186
+        u = self._new_uniforms()
+        u.step_size = _f32(1 / self.slices)
+        u.extinction = _f32(self.extinction)
+        u.offset = _f32(self.rng())                                # :170 draws Math.random() although the shader never reads uOffset
+        N.check(N.lib().vpt_renderer_set_lao_params(self._h, C.byref(self.lao_params())))
+        self._u = u
+        return u
+
+    def _generateFrame(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_generate(self._h, C.byref(self._prepare_generate())))
+
+    def _integrateFrame(self):                                     # :188-203
+        N.check(N.lib().vpt_renderer_integrate(self._h, C.byref(self._u)))
+
+    def _renderFrame(self):                                        # :205-217
+        N.check(N.lib().vpt_renderer_render_frame(self._h, None))
+
+    def _prepare_frame_uniforms(self):
+        return self._prepare_generate()
+
+    def _renderFused(self):
+        self._bind_volume()
+        N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
+
+
 def RendererFactory(which):
-    """src/js/renderers/RendererFactory.js:10-23 ('lao' and 'dos' are not built)."""
+    """src/js/renderers/RendererFactory.js:10-23 ('dos' is not built: its shaders need a feedback loop over slices)."""
     classes = {'mip': MIPRenderer, 'eam': EAMRenderer, 'mcs': MCSRenderer, 'mcm': MCMRenderer,
-               'iso': ISORenderer, 'depth': DepthRenderer}
+               'iso': ISORenderer, 'depth': DepthRenderer, 'lao': LAORenderer}
     if which not in classes:
         raise RuntimeError('No suitable class')
     return classes[which]
