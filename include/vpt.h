@@ -40,6 +40,7 @@ extern "C" {
 #define VPT_RENDERER_ISO   4   /* src/js/renderers/ISORenderer.js, src/glsl/renderers/ISORenderer.glsl */
 #define VPT_RENDERER_DEPTH 5   /* src/js/renderers/DepthRenderer.js, src/glsl/renderers/DepthRenderer.glsl */
 #define VPT_RENDERER_LAO   6   /* src/js/renderers/LAORenderer.js, src/glsl/renderers/LAORenderer.glsl */
+#define VPT_RENDERER_DOS   7   /* src/js/renderers/DOSRenderer.js, src/glsl/renderers/DOSRenderer.glsl */
 
 /* Volume.js:115-125 setFilter('linear' | 'nearest') */
 #define VPT_FILTER_NEAREST 0
@@ -58,6 +59,8 @@ extern "C" {
 #define VPT_BUFFER_MCM_DIRECTION     4   /* RGBA32F [dir.xyz, bounces]      */
 #define VPT_BUFFER_MCM_TRANSMITTANCE 5   /* RGBA32F [transmittance.rgb, 0]  */
 #define VPT_BUFFER_MCM_RADIANCE      6   /* RGBA32F [radiance.rgb, samples] */
+#define VPT_BUFFER_DOS_OCCLUSION     7   /* R32F, the DOS renderer's second accumulation attachment (DOSRenderer.js:295-305);
+                                            its colour attachment (RGBA32F) is VPT_BUFFER_ACCUM */
 
 typedef struct vpt_context  vpt_context;
 typedef struct vpt_volume   vpt_volume;
@@ -190,6 +193,17 @@ struct vpt_lao_params {
     float light_position[3];        /* uLightPosition (2, 12, 3) */
 };
 VPT_API int vpt_renderer_set_lao_params(vpt_renderer *r, const struct vpt_lao_params *p);
+/* The DOS renderer (directional occlusion shading) sweeps the volume front to back, one view-aligned slice per
+ * full-screen pass, each pass reading its neighbours' occlusion from the pass before (DOSRenderer.js:199-259):
+ *   vpt_renderer_set_occlusion_samples  the RG32F texel row built by generateOcclusionSamples() (DOSRenderer.js:103-140),
+ *                                       count x (x, y);
+ *   vpt_renderer_integrate_slices       _integrateFrame(): `count` passes; pass s takes uOcclusionScale = slices[3s], slices[3s+1]
+ *                                       and uDepth = slices[3s+2] (the `correction` vector of :243-252), uSliceDistance =
+ *                                       u->step_size, uExtinction = u->extinction, uMvpInverseMatrix = u->mvp_inverse.
+ * reset / render_frame / read work as for the other renderers (generate is the reference's empty hook); integrate, the
+ * single-launch vpt_renderer_render, frame sequences and sharding are refused for this renderer. */
+VPT_API int vpt_renderer_set_occlusion_samples(vpt_renderer *r, const float *xy, int count);
+VPT_API int vpt_renderer_integrate_slices(vpt_renderer *r, const struct vpt_uniforms *u, const float *slices, int count);
 /* volume samples executed since creation / last clear (SURVEY §8d metric) */
 VPT_API int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count);
 VPT_API int vpt_renderer_clear_sample_count(vpt_renderer *r);

@@ -139,6 +139,10 @@ def lib():
         L.vpo_lao_integrate.restype = None; L.vpo_lao_integrate.argtypes = [FP, P, P]
         L.vpo_lao_render.restype = None; L.vpo_lao_render.argtypes = [FP, P, P]
         L.vpo_lao_reset.restype = None; L.vpo_lao_reset.argtypes = [FP, P]
+        L.vpo_dos_reset.restype = None; L.vpo_dos_reset.argtypes = [FP, P, P]
+        L.vpo_dos_integrate_slice.restype = C.c_uint64
+        L.vpo_dos_integrate_slice.argtypes = [SP, FP, P, P, C.c_int32, P, P, P, P]
+        L.vpo_dos_render.restype = None; L.vpo_dos_render.argtypes = [FP, P, P]
         L.vpo_mcm_reset.restype = None; L.vpo_mcm_reset.argtypes = [FP, P, P, P, P]
         L.vpo_mcm_integrate.restype = C.c_uint64; L.vpo_mcm_integrate.argtypes = [SP, FP, P, P, P, P]
         L.vpo_mcm_render.restype = None; L.vpo_mcm_render.argtypes = [FP, P, P]
@@ -227,13 +231,30 @@ class OracleRenderer:
             self.frame = np.zeros(n, np.float32); self.acc = np.zeros(n, np.float32)            # R32F
         elif kind == "mcm":
             self.state = [np.zeros(4 * n, np.float32) for _ in range(4)]
+        elif kind == "dos":                               # colour (RGBA32F) and occlusion (R32F), each double-buffered
+            self.color = [np.zeros(4 * n, np.float32) for _ in range(2)]
+            self.occlusion = [np.zeros(n, np.float32) for _ in range(2)]
+            self.cur = 0
         else:
             raise ValueError(kind)
         self.out = np.zeros(4 * n, np.uint16)
         self.samples = 0
 
+    def integrate_slices(self, fr, slices, samples):
+        """DOSRenderer.js:240-259: one full-screen pass per row of `slices` (uOcclusionScale.xy, uDepth), ping-ponging"""
+        slices = np.ascontiguousarray(slices, np.float32).reshape(-1, 3)
+        samples = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        for sl in slices:
+            a, b = self.cur, 1 - self.cur
+            self.samples += lib().vpo_dos_integrate_slice(C.byref(self.scene.c), C.byref(fr), _ptr(sl), _ptr(samples), samples.size // 2,
+                                                          _ptr(self.color[a]), _ptr(self.occlusion[a]), _ptr(self.color[b]), _ptr(self.occlusion[b]))
+            self.cur = b
+
     def reset(self, fr):
         L = lib()
+        if self.kind == "dos":
+            L.vpo_dos_reset(C.byref(fr), _ptr(self.color[self.cur]), _ptr(self.occlusion[self.cur]))
+            return
         if self.kind == "mcm":
             L.vpo_mcm_reset(C.byref(fr), *[_ptr(s) for s in self.state])
         else:
@@ -260,7 +281,9 @@ class OracleRenderer:
 
     def render_frame(self, fr):
         L = lib()
-        if self.kind == "mcm":
+        if self.kind == "dos":
+            L.vpo_dos_render(C.byref(fr), _ptr(self.color[self.cur]), _ptr(self.out))
+        elif self.kind == "mcm":
             L.vpo_mcm_render(C.byref(fr), _ptr(self.state[3]), _ptr(self.out))
         elif self.kind == "iso":                      # the ISO render pass samples the volume (gradient + material)
             self.samples += L.vpo_iso_render(C.byref(self.scene.c), C.byref(fr), _ptr(self.acc), _ptr(self.out))

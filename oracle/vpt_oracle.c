@@ -884,6 +884,89 @@ VPO_API void vpo_lao_render(const vpo_frame *fr, const uint8_t *acc, uint16_t *o
 VPO_API void vpo_lao_reset(const vpo_frame *fr, uint8_t *acc) { vpo_eam_reset(fr, acc); }
 
 /* ==========================================================================================
+ * DOS  (DOSRenderer.glsl) — SURVEY section 8f row 3: directional occlusion shading.  The image is swept front to back
+ * one view-aligned slice per full-screen pass; every pass reads the previous pass's colour (RGBA32F, NEAREST) and
+ * occlusion (R32F, LINEAR, default wrap = REPEAT: DOSRenderer.js:287-305 sets none) buffers and writes the next ones
+ * (DOSRenderer.js:199-259).  Buffers here: row-major, row 0 = bottom.
+ * ======================================================================================== */
+/* reset: DOSRenderer.glsl:137-144 */
+VPO_API void vpo_dos_reset(const vpo_frame *fr, float *color, float *occlusion) {
+    size_t n = (size_t)fr->width * fr->height;
+    for (size_t k = 0; k < n; k++) { color[4 * k] = 0.0f; color[4 * k + 1] = 0.0f; color[4 * k + 2] = 0.0f; color[4 * k + 3] = 0.0f; occlusion[k] = 1.0f; }
+}
+/* LINEAR / REPEAT tap pair.  Contract: u = s*n - 0.5; a coordinate that is NaN or beyond 1e9 texels reads texel 0. */
+static inline void repeat_coord(float s, int32_t n, int32_t *i0, int32_t *i1, float *f) {
+    float u = fmaf(s, (float)n, -0.5f);
+    if (!(fabsf(u) < 1.0e9f)) u = 0.0f;
+    float fl = floorf(u);
+    *f = u - fl;
+    int32_t i = (int32_t)fl % n;
+    if (i < 0) i += n;
+    *i0 = i; *i1 = (i + 1 == n) ? 0 : i + 1;
+}
+static float sample_occlusion(const float *occ, int32_t w, int32_t h, float s, float t) {
+    int32_t x0, x1, y0, y1; float fx, fy;
+    repeat_coord(s, w, &x0, &x1, &fx);
+    repeat_coord(t, h, &y0, &y1, &fy);
+    float a = lerpf(occ[(size_t)y0 * w + x0], occ[(size_t)y0 * w + x1], fx);
+    float b = lerpf(occ[(size_t)y1 * w + x0], occ[(size_t)y1 * w + x1], fx);
+    return lerpf(a, b, fy);
+}
+/* one slice = one draw of integrate/fragment main(): DOSRenderer.glsl:73-89 (vertex :17-23: vPosition3D = unprojected
+ * (position, uDepth), evaluated at the pixel's own NDC).  uSliceDistance = fr->step, uExtinction = fr->extinction,
+ * slice[3] = (uOcclusionScale.x, uOcclusionScale.y, uDepth), samples = the RG32F texel row of DOSRenderer.js:103-140.
+ * Returns the number of volume samples. */
+VPO_API uint64_t vpo_dos_integrate_slice(const vpo_scene *sc, const vpo_frame *fr, const float *slice, const float *samples, int32_t nsamples,
+                                         const float *color_in, const float *occ_in, float *color_out, float *occ_out) {
+    scene_tables t; tables_init(&t, sc);
+    uint64_t ns = 0; int nth = clamp_threads(fr);
+    const int32_t W = fr->width, H = fr->height;
+    const float sd = fr->step;
+    FOR_ROWS(fr) {
+        for (int32_t i = 0; i < W; i++) {
+            size_t k = (size_t)j * W + i;
+            float px = pixel_ndc(i, W), py = pixel_ndc(j, H);
+            float uvx = ndc_to_uv(px), uvy = ndc_to_uv(py);
+            const float *prev = color_in + 4 * k;
+            float prev_occ = occ_in[k];                              /* texture() at the texel's own centre */
+            v4 hp = mat4_mul_point(fr->mvp_inv, px, py, slice[2]);
+            float rw = vpo_rcp_nr(hp.w);
+            v3 pos = { hp.x * rw, hp.y * rw, hp.z * rw };
+            float *oc = color_out + 4 * k;
+            if (pos.x > 1.0f || pos.y > 1.0f || pos.z > 1.0f || pos.x < 0.0f || pos.y < 0.0f || pos.z < 0.0f) {
+                oc[0] = prev[0]; oc[1] = prev[1]; oc[2] = prev[2]; oc[3] = prev[3];
+                occ_out[k] = prev_occ;
+            } else {
+                v4 ts = sample_volume_color(&t, pos, &ns);
+                float ext = ts.w * fr->extinction;
+                float e = vpo_expf((-ext) * sd);
+                float alpha = 1.0f - e;
+                float k1 = 1.0f - prev[3];
+                oc[0] = prev[0] + ((ts.x * prev_occ) * alpha) * k1;
+                oc[1] = prev[1] + ((ts.y * prev_occ) * alpha) * k1;
+                oc[2] = prev[2] + ((ts.z * prev_occ) * alpha) * k1;
+                oc[3] = vmin(prev[3] + alpha, 1.0f);
+                float o = 0.0f;                                       /* calculateOcclusion: :61-70 */
+                for (int32_t q = 0; q < nsamples; q++)
+                    o += sample_occlusion(occ_in, W, H, uvx + samples[2 * q] * slice[0], uvy + samples[2 * q + 1] * slice[1]);
+                occ_out[k] = (o / (float)nsamples) * e;
+            }
+        }
+    }
+    tables_free(&t);
+    return ns;
+}
+/* render: DOSRenderer.glsl:113-116 — mix(vec4(1), vec4(color.rgb, 1), color.a) */
+VPO_API void vpo_dos_render(const vpo_frame *fr, const float *color, uint16_t *out) {
+    for (int32_t j = fr->y0; j < fr->y1; j++)
+        for (int32_t i = 0; i < fr->width; i++) {
+            size_t k = (size_t)j * fr->width + i;
+            const float *c = color + 4 * k;
+            store_half4(out + 4 * k, mixf(1.0f, c[0], c[3]), mixf(1.0f, c[1], c[3]), mixf(1.0f, c[2], c[3]), mixf(1.0f, 1.0f, c[3]));
+        }
+}
+
+/* ==========================================================================================
  * MCS  (MCSRenderer.glsl)
  * ======================================================================================== */
 #define VPO_MAX_TRACK_ITERS 65536u   /* safety net shared with the GPU kernels */

@@ -15,7 +15,7 @@ from vpt_amd.synthetic import GoldenRatioRng
 pytestmark = pytest.mark.gpu
 
 MCM_BUFFERS = [N.BUFFER_MCM_POSITION, N.BUFFER_MCM_DIRECTION, N.BUFFER_MCM_TRANSMITTANCE, N.BUFFER_MCM_RADIANCE]
-KINDS = ["mip", "eam", "mcs", "mcm", "iso", "depth", "lao"]
+KINDS = ["mip", "eam", "mcs", "mcm", "iso", "depth", "lao"]      # dos: tests/test_gpu_dos.py (slice sweep, own driver)
 
 
 def same_bits(got, want, what):

@@ -9,7 +9,7 @@ from .context import Context
 from .volume import Volume
 from .loaders import AbstractLoader, BlobLoader, FileLoader, LoaderFactory
 from .readers import AbstractReader, RAWReader, ZIPReader, BVPReader, ReaderFactory
-from .renderers import (AbstractRenderer, MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer, ISORenderer, DepthRenderer, LAORenderer,
+from .renderers import (AbstractRenderer, MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer, ISORenderer, DepthRenderer, LAORenderer, DOSRenderer,
                         RendererFactory)
 from .tonemappers import (AbstractToneMapper, ArtisticToneMapper, RangeToneMapper, ReinhardToneMapper, Reinhard2ToneMapper,
                           Uncharted2ToneMapper, FilmicToneMapper, UnrealToneMapper, AcesToneMapper, LottesToneMapper,
@@ -22,7 +22,7 @@ __all__ = [
     'PropertyBag', 'EventTarget', 'Event', 'CustomEvent', 'Node', 'Transform', 'PerspectiveCamera',
     'mat4', 'quat', 'vec3', 'default_camera', 'mvp_inverse_matrix', 'Context', 'Volume', 'RAWReader',
     'AbstractLoader', 'BlobLoader', 'FileLoader', 'LoaderFactory', 'AbstractReader', 'ZIPReader', 'BVPReader', 'ReaderFactory',
-    'AbstractRenderer', 'MIPRenderer', 'EAMRenderer', 'MCSRenderer', 'MCMRenderer', 'ISORenderer', 'DepthRenderer', 'LAORenderer', 'RendererFactory', 'VptError',
+    'AbstractRenderer', 'MIPRenderer', 'EAMRenderer', 'MCSRenderer', 'MCMRenderer', 'ISORenderer', 'DepthRenderer', 'LAORenderer', 'DOSRenderer', 'RendererFactory', 'VptError',
     'AbstractToneMapper', 'ArtisticToneMapper', 'RangeToneMapper', 'ReinhardToneMapper', 'Reinhard2ToneMapper',
     'Uncharted2ToneMapper', 'FilmicToneMapper', 'UnrealToneMapper', 'AcesToneMapper', 'LottesToneMapper',
     'UchimuraToneMapper', 'ToneMapperFactory', 'RenderingContext', 'CircleAnimator',

@@ -11,11 +11,13 @@ OPTION_MCS_PERSISTENT = 0
 OPTION_MCM_PERSISTENT = 1
 OPTION_MCM_STAGGER = 2
 PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED = 0, 1, 2
-RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO = 0, 1, 2, 3, 4, 5, 6
+RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO, RENDERER_DOS = 0, 1, 2, 3, 4, 5, 6, 7
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 FORMAT_R8, FORMAT_RG8 = 0, 1
 BUFFER_RENDER, BUFFER_FRAME, BUFFER_ACCUM = 0, 1, 2
 BUFFER_MCM_POSITION, BUFFER_MCM_DIRECTION, BUFFER_MCM_TRANSMITTANCE, BUFFER_MCM_RADIANCE = 3, 4, 5, 6
+BUFFER_DOS_OCCLUSION = 7
+ERR_INVALID, ERR_HIP, ERR_NO_VOLUME, ERR_UNSUPPORTED = -1, -2, -3, -4
 (PROBE_LOG, PROBE_SIN, PROBE_COS, PROBE_ASIN, PROBE_ATAN2, PROBE_PCG, PROBE_UNIFORM, PROBE_F16,
  PROBE_RCP, PROBE_RSQRT, PROBE_MIN, PROBE_MAX, PROBE_LOG_UNIFORM, PROBE_RCPZ, PROBE_SQRT, PROBE_EXP, PROBE_POW) = range(17)
 TONEMAPPER_OPTION_TABLE, TONEMAPPER_TABLE_NEVER, TONEMAPPER_TABLE_ALWAYS, TONEMAPPER_TABLE_AUTO = 0, 0, 1, 2
@@ -34,7 +36,7 @@ SYMBOLS = [
     "vpt_renderer_reset", "vpt_renderer_generate", "vpt_renderer_integrate", "vpt_renderer_render_frame",
     "vpt_renderer_render", "vpt_renderer_play", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
     "vpt_renderer_set_render_target",
-    "vpt_renderer_set_option", "vpt_renderer_set_lao_params", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
+    "vpt_renderer_set_option", "vpt_renderer_set_lao_params", "vpt_renderer_set_occlusion_samples", "vpt_renderer_integrate_slices", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile",
     "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play", "vpt_gather_set_root",
     "vpt_gather_synchronize",
@@ -118,6 +120,7 @@ def lib():
         "vpt_renderer_set_render_target": [P, P, SZ],
         "vpt_renderer_set_option": [P, I, I],
         "vpt_renderer_set_lao_params": [P, C.POINTER(LaoParams)],
+        "vpt_renderer_set_occlusion_samples": [P, P, I], "vpt_renderer_integrate_slices": [P, UP, P, I],
         "vpt_renderer_sample_count": [P, C.POINTER(C.c_uint64)], "vpt_renderer_clear_sample_count": [P],
         "vpt_renderer_set_profiling": [P, I],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],

@@ -84,6 +84,8 @@ struct vpt_renderer {
     uint32_t *work_counter;        // tile counter of the persistent MCS kernel
     bool mcs_persistent;           // use k_mcs_persist (active-ray compaction) for the MCS generate pass
     LaoParams lao;                 // LAO renderer parameters (vpt_renderer_set_lao_params; defaults LAORenderer.js:17-108)
+    float2 *dos_samples; int dos_nsamples;   // DOS: uOcclusionSamples (vpt_renderer_set_occlusion_samples)
+    int dos_cur;                   // DOS: which of colour st[0|1] / occlusion st[2|3] holds the latest slice
     int mcm_stagger;               // VPT_OPTION_MCM_STAGGER: phase-stagger quantum (10 ns ticks) | pattern << 24; 0 = off
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
@@ -109,6 +111,7 @@ static size_t frame_elem(int kind) {
         case VPT_RENDERER_ISO: return 8;      // RGBA16F (ISORenderer.js:165-197)
         case VPT_RENDERER_DEPTH: return 4;    // R32F (DepthRenderer.js:165-189)
         case VPT_RENDERER_LAO: return 4;      // RGBA8 (LAORenderer.js:217-243)
+        case VPT_RENDERER_DOS: return 0;      // colour RGBA32F + occlusion R32F, both double-buffered, ROW-MAJOR: st[0..3] (DOSRenderer.js:273-313)
         default: return 0;
     }
 }
@@ -321,6 +324,7 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     renderer_free_buffers(r);
+    r->dos_cur = 0;
     int nblocks = (r->H + r->R - 1) / r->R;                 // row blocks in the image
     int mine = (nblocks - r->g + r->G - 1) / r->G;          // blocks b with b % G == g
     int max_blocks = (nblocks + r->G - 1) / r->G;           // every rank pads to this (equal-size gather)
@@ -396,7 +400,7 @@ extern "C" int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba
 }
 extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int height, vpt_renderer **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
-    if (kind < VPT_RENDERER_MIP || kind > VPT_RENDERER_LAO) return fail(VPT_ERR_INVALID, "No suitable class");  // RendererFactory.js:21
+    if (kind < VPT_RENDERER_MIP || kind > VPT_RENDERER_DOS) return fail(VPT_ERR_INVALID, "No suitable class");  // RendererFactory.js:21
     if (width < 1 || height < 1 || width > 32768 || height > 32768) return fail(VPT_ERR_INVALID, "resolution %dx%d out of range", width, height);
     HIP_TRY(hipSetDevice(c->device));
     vpt_renderer *r = new vpt_renderer();
@@ -439,6 +443,7 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (r->tf) hipFree(r->tf);
     if (r->env) hipFree(r->env);
     if (r->samples) hipFree(r->samples);
+    if (r->dos_samples) hipFree(r->dos_samples);
     if (r->work_counter) hipFree(r->work_counter);
     if (r->frame_table) hipFree(r->frame_table);
     if (r->frame_staging) hipHostFree(r->frame_staging);
@@ -451,6 +456,8 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
 extern "C" int vpt_renderer_set_shard(vpt_renderer *r, int rank, int world, int rows_per_block) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
     if (world < 1 || rank < 0 || rank >= world || rows_per_block < 1) return fail(VPT_ERR_INVALID, "bad shard %d/%d rows %d", rank, world, rows_per_block);
+    if (r->kind == VPT_RENDERER_DOS && world > 1)
+        return fail(VPT_ERR_UNSUPPORTED, "the DOS renderer does not shard: every slice reads its neighbours' occlusion across rows");
     r->G = world; r->g = rank; r->R = rows_per_block;
     return renderer_alloc_buffers(r);
 }
@@ -511,13 +518,16 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         a->mix = u->mix; a->blur = u->blur;
         a->isovalue = u->isovalue; a->gradient_step = u->gradient_step; a->threshold = u->threshold;
     }
-    a->lao = r->lao;
+    if (r->kind == VPT_RENDERER_LAO) a->lao = r->lao;
     a->stagger_ticks = (uint32_t)(r->mcm_stagger & 0xffffff); a->stagger_pattern = (uint32_t)(r->mcm_stagger >> 24) & 1u;
     a->stagger_blocks = 256u * 7u;                  // the workgroups resident at launch: 256 CUs x 7 (28 waves per CU)
     a->inv_w = (float)(1.0 / (double)r->W);     // gl.uniform2f(uInverseResolution, 1/res, 1/res): MCMRenderer.js:91,155
     a->inv_h = (float)(1.0 / (double)r->H);
     a->frame = r->frame; a->acc = r->acc;
     a->st0 = r->st[0]; a->st1 = r->st[1]; a->st2 = r->st[2]; a->st3 = r->st[3];
+    if (r->kind == VPT_RENDERER_DOS) {            // (colour, occlusion) in = the latest pair, out = the other one
+        a->st0 = r->st[r->dos_cur]; a->st1 = r->st[1 - r->dos_cur]; a->st2 = r->st[2 + r->dos_cur]; a->st3 = r->st[3 - r->dos_cur];
+    }
     a->render = r->render_target ? r->render_target : r->render;
     a->samples = r->samples;
     return VPT_OK;
@@ -576,6 +586,7 @@ static int variant_of(const vpt_renderer *r) {
 #define K_DEPTH1(V) (k_depth<1, V>)
 #define K_LAO0(V) (k_lao<0, V>)
 #define K_LAO1(V) (k_lao<1, V>)
+#define K_DOS(V) (k_dos_slice<V>)
 #define K_MCM0(V) (k_mcm_integrate<false, V>)
 #define K_MCM1(V) (k_mcm_integrate<true, V>)
 
@@ -673,12 +684,15 @@ extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_ISO: LAUNCH(k_iso_reset, r, a, 0); break;
         case VPT_RENDERER_DEPTH: LAUNCH(k_depth_reset, r, a, 0); break;
         case VPT_RENDERER_LAO: LAUNCH(k_eam_reset, r, a, 0); break;           // LAORenderer.glsl:285-287: (0, 0, 0, 1) into RGBA8
+        case VPT_RENDERER_DOS: LAUNCH(k_dos_reset, r, a, 0); break;
     }
     HIP_TRY(hipGetLastError());
     return VPT_OK;
 }
 extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
-    if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
+    if (!r) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind == VPT_RENDERER_DOS) return VPT_OK;                 // DOSRenderer.js has no _generateFrame (AbstractRenderer.js:122-124: empty)
+    if (!u) return fail(VPT_ERR_INVALID, "null argument");
     if (r->kind == VPT_RENDERER_MCM) return VPT_OK;                 // MCMRenderer.js:118-119: empty
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind != VPT_RENDERER_MCS) VPT_TRY(check_step(u));
@@ -701,6 +715,7 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
 }
 extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_INVALID, "the DOS integrate step is a sequence of slices: call vpt_renderer_integrate_slices");
     HIP_TRY(hipSetDevice(r->ctx->device));
     PassArgs a;
     VPT_TRY(make_args(r, u, r->kind == VPT_RENDERER_MCM, &a));
@@ -730,6 +745,7 @@ extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u)
         case VPT_RENDERER_ISO: LAUNCH_S(K_ISOR, r, a); break;
         case VPT_RENDERER_DEPTH: LAUNCH(k_depth_render, r, a, 0); break;
         case VPT_RENDERER_LAO: LAUNCH(k_eam_render, r, a, 0); break;           // LAORenderer.glsl:259-261
+        case VPT_RENDERER_DOS: LAUNCH(k_dos_render, r, a, 0); break;
         case VPT_RENDERER_MIP: LAUNCH(k_mip_render, r, a, 0); break;
         case VPT_RENDERER_EAM: LAUNCH(k_eam_render, r, a, 0); break;
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_render, r, a, 0); break;
@@ -755,6 +771,7 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
 }
 extern "C" int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "the DOS renderer has no single-launch render(): its slices depend on each other across pixels");
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind != VPT_RENDERER_MCS && r->kind != VPT_RENDERER_MCM) VPT_TRY(check_step(u));
     if (r->kind == VPT_RENDERER_ISO) VPT_TRY(check_iso(u));
@@ -850,6 +867,7 @@ static bool play_key_equal(const PassArgs &x, const PassArgs &y) { return memcmp
 
 extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int use_graph) {
     if (!r || !base || !frame_vars) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "frame sequences are not defined for the DOS renderer: drive it slice by slice");
     vpt_context *c = r->ctx;
     HIP_TRY(hipSetDevice(c->device));
     PassArgs a;
@@ -928,6 +946,15 @@ extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t 
         return VPT_OK;
     }
     const void *src = nullptr; size_t elem = 0;
+    if (r->kind == VPT_RENDERER_DOS) {            // row-major already: no tile order to undo
+        if (buffer == VPT_BUFFER_ACCUM) { src = r->st[r->dos_cur]; elem = 16; }
+        else if (buffer == VPT_BUFFER_DOS_OCCLUSION) { src = r->st[2 + r->dos_cur]; elem = 4; }
+        else return fail(VPT_ERR_INVALID, "the DOS renderer holds VPT_BUFFER_ACCUM (colour) and VPT_BUFFER_DOS_OCCLUSION; its frame buffer is never written");
+        if (nbytes < npix * elem) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, npix * elem);
+        HIP_TRY(hipMemcpyAsync(dst, src, npix * elem, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return VPT_OK;
+    }
     if (buffer == VPT_BUFFER_FRAME || buffer == VPT_BUFFER_ACCUM) {
         elem = frame_elem(r->kind);
         if (!elem) return fail(VPT_ERR_INVALID, "MCM has no frame/accumulation colour buffer; read the MCM state buffers");
@@ -962,6 +989,40 @@ extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t
     size_t need = (size_t)r->W * r->local_h * 8;
     if (ptr && nbytes < need) return fail(VPT_ERR_INVALID, "render target too small: %zu < %zu", nbytes, need);
     r->render_target = (uint2 *)ptr;
+    return VPT_OK;
+}
+// uOcclusionSamples: the RG32F row of DOSRenderer.js:103-140
+extern "C" int vpt_renderer_set_occlusion_samples(vpt_renderer *r, const float *xy, int count) {
+    if (!r || !xy) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind != VPT_RENDERER_DOS) return fail(VPT_ERR_INVALID, "not a DOS renderer");
+    if (count < 1 || count > 4096) return fail(VPT_ERR_INVALID, "occlusion sample count %d out of range (1..4096)", count);
+    vpt_context *c = r->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (r->dos_samples) { HIP_TRY(hipFree(r->dos_samples)); r->dos_samples = nullptr; r->dos_nsamples = 0; }
+    HIP_TRY(hipMalloc(&r->dos_samples, (size_t)count * sizeof(float2)));
+    HIP_TRY(hipMemcpy(r->dos_samples, xy, (size_t)count * sizeof(float2), hipMemcpyHostToDevice));
+    r->dos_nsamples = count;
+    return VPT_OK;
+}
+// _integrateFrame of the DOS renderer (DOSRenderer.js:199-259): `count` full-screen passes, pass s with
+// (uOcclusionScale.x, uOcclusionScale.y, uDepth) = slices[3s .. 3s+2]; uSliceDistance = u->step_size, uExtinction = u->extinction
+extern "C" int vpt_renderer_integrate_slices(vpt_renderer *r, const vpt_uniforms *u, const float *slices, int count) {
+    if (!r || !u || (!slices && count > 0)) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind != VPT_RENDERER_DOS) return fail(VPT_ERR_INVALID, "not a DOS renderer");
+    if (count < 0 || count > 65536) return fail(VPT_ERR_INVALID, "slice count %d out of range (0..65536)", count);
+    if (!r->dos_samples) return fail(VPT_ERR_INVALID, "no occlusion samples set (vpt_renderer_set_occlusion_samples)");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    PassArgs a;
+    VPT_TRY(make_args(r, u, true, &a));
+    Timed t(r, true, (uint32_t)(count > 0 ? count : 1));
+    for (int s = 0; s < count; s++) {
+        a.st0 = r->st[r->dos_cur]; a.st1 = r->st[1 - r->dos_cur]; a.st2 = r->st[2 + r->dos_cur]; a.st3 = r->st[3 - r->dos_cur];
+        a.dos = DosParams{ r->dos_samples, r->dos_nsamples, slices[3 * s], slices[3 * s + 1], slices[3 * s + 2] };
+        LAUNCH_S(K_DOS, r, a);
+        r->dos_cur ^= 1;
+    }
+    HIP_TRY(hipGetLastError());
     return VPT_OK;
 }
 extern "C" int vpt_renderer_set_lao_params(vpt_renderer *r, const struct vpt_lao_params *p) {

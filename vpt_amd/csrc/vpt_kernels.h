@@ -74,6 +74,9 @@ struct LaoParams {               // = struct vpt_lao_params (include/vpt.h)
     int soft_shadows; float shadows_weight; int num_shadow_samples; float light_radius; float light_coefficient;
     float light_position[3];
 };
+// DOS slice pass: uOcclusionSamples / uOcclusionSamplesCount / uOcclusionScale / uDepth (DOSRenderer.js:212-254); the colour
+// and occlusion ping-pong buffers travel in st0 (colour in), st1 (colour out), st2 (occlusion in), st3 (occlusion out)
+struct DosParams { const float2 *samples; int nsamples; float scale_x, scale_y, depth; };
 struct PassArgs {
     PixMap pm;
     DevVolume vol;
@@ -86,7 +89,10 @@ struct PassArgs {
     float mix, blur, inv_w, inv_h;
     float isovalue, gradient_step, threshold;   // ISO / Depth (vpt_kernels_iso_depth.h)
     uint32_t stagger_ticks, stagger_blocks, stagger_pattern;   // MCM phase staggering (k_mcm_integrate), 0 = off
-    LaoParams lao;               // LAO renderer (vpt_kernels_iso_depth.h)
+    union {
+        LaoParams lao;           // LAO renderer (vpt_kernels_iso_depth.h)
+        DosParams dos;           // DOS renderer: one slice (vpt_kernels_iso_depth.h)
+    };
     uint32_t multi_passes;       // > 1: the fused (MODE 1) kernels run that many passes per pixel in one launch (VPT_PLAY_FUSED)
     void *frame;                 // tile order
     void *acc;                   // tile order (ping-pong collapsed: each pixel reads and writes only itself)

@@ -297,3 +297,83 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_lao_integrate(PassArgs a) {
     Pix p = map_pixel(a.pm);
     if (p.valid) ((uint32_t *)a.acc)[p.k] = ((const uint32_t *)a.frame)[p.k];
 }
+
+// =============================================================================================
+// DOS — DOSRenderer.glsl: one launch per view-aligned slice; each reads the previous slice's colour
+// (RGBA32F, own texel) and occlusion (R32F, LINEAR / REPEAT: neighbour reads, hence separate in / out buffers and ROW-MAJOR
+// layout instead of the tile order of the other renderers) and writes the next ones (DOSRenderer.js:240-259)
+// =============================================================================================
+// LINEAR / REPEAT tap pair; contract: a coordinate that is NaN or beyond 1e9 texels reads texel 0 (oracle repeat_coord)
+VPT_DEV void repeat_taps(float s, int n, int &i0, int &i1, float &f) {
+    float u = fmaf(s, (float)n, -0.5f);
+    if (!(fabsf(u) < 1.0e9f)) u = 0.0f;
+    float fl = floorf(u);
+    f = u - fl;
+    int i = (int)fl % n;
+    if (i < 0) i += n;
+    i0 = i; i1 = (i + 1 == n) ? 0 : i + 1;
+}
+VPT_DEV float sample_occlusion(const float *occ, int w, int h, float s, float t) {
+    int x0, x1, y0, y1; float fx, fy;
+    repeat_taps(s, w, x0, x1, fx);
+    repeat_taps(t, h, y0, y1, fy);
+    float a = lerpf(occ[(size_t)y0 * w + x0], occ[(size_t)y0 * w + x1], fx);
+    float b = lerpf(occ[(size_t)y1 * w + x0], occ[(size_t)y1 * w + x1], fx);
+    return lerpf(a, b, fy);
+}
+// integrate/fragment main(): DOSRenderer.glsl:73-89; vertex :17-23 (vPosition3D = the unprojected (position, uDepth))
+template <int V>
+__global__ void __launch_bounds__(VPT_BLOCK) k_dos_slice(PassArgs a) {
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    Pix p = map_pixel(a.pm);
+    uint32_t ns = 0;
+    if (p.valid) {
+        const DosParams &d = a.dos;
+        const int W = a.pm.W, H = a.pm.H;
+        const size_t k = (size_t)p.j * W + p.i;
+        const float *occ_in = (const float *)a.st2;
+        float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
+        float4 prev = a.st0[k];
+        float prev_occ = occ_in[k];
+        f3 pos = dehomogenize(mat4_mul_point(a.mvp_inv, px, py, d.depth));
+        float4 oc = prev; float oo = prev_occ;
+        if (!(pos.x > 1.0f || pos.y > 1.0f || pos.z > 1.0f || pos.x < 0.0f || pos.y < 0.0f || pos.z < 0.0f)) {
+            float4 ts = sample_volume_color<V>(a, t, pos);
+            ns = 1;
+            float ext = ts.w * a.extinction;
+            float e = vpt_expf((-ext) * a.step);
+            float alpha = 1.0f - e;
+            float k1 = 1.0f - prev.w;
+            oc.x = prev.x + ((ts.x * prev_occ) * alpha) * k1;
+            oc.y = prev.y + ((ts.y * prev_occ) * alpha) * k1;
+            oc.z = prev.z + ((ts.z * prev_occ) * alpha) * k1;
+            oc.w = vmin(prev.w + alpha, 1.0f);
+            float uvx = ndc_to_uv(px), uvy = ndc_to_uv(py);
+            float o = 0.0f;                                        // calculateOcclusion: :61-70
+            for (int q = 0; q < d.nsamples; q++) {
+                float2 off = d.samples[q];
+                o += sample_occlusion(occ_in, W, H, uvx + off.x * d.scale_x, uvy + off.y * d.scale_y);
+            }
+            oo = (o / (float)d.nsamples) * e;
+        }
+        a.st1[k] = oc;
+        ((float *)a.st3)[k] = oo;
+    }
+    count_samples(a.samples, ns);
+}
+// reset: DOSRenderer.glsl:137-144 into the current (st0 / st2) pair
+__global__ void __launch_bounds__(VPT_BLOCK) k_dos_reset(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    size_t k = (size_t)p.j * a.pm.W + p.i;
+    a.st0[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    ((float *)a.st2)[k] = 1.0f;
+}
+// render: DOSRenderer.glsl:113-116
+__global__ void __launch_bounds__(VPT_BLOCK) k_dos_render(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    float4 c = a.st0[(size_t)p.j * a.pm.W + p.i];
+    a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(mixf(1.0f, c.x, c.w), mixf(1.0f, c.y, c.w), mixf(1.0f, c.z, c.w), mixf(1.0f, 1.0f, c.w));
+}

@@ -186,8 +186,12 @@ class AbstractRenderer(PropertyBag):
                 arr = np.empty((rows, w, 4), dtype=np.float16)
             elif self._KIND == N.RENDERER_DEPTH:
                 arr = np.empty((rows, w), dtype=np.float32)
+            elif self._KIND == N.RENDERER_DOS and buffer == N.BUFFER_FRAME:
+                raise N.VptError(N.ERR_INVALID, "the DOS renderer's frame buffer is never written")
             else:
                 arr = np.empty((rows, w, 4), dtype=np.float32)
+        elif buffer == N.BUFFER_DOS_OCCLUSION:
+            arr = np.empty((rows, w), dtype=np.float32)
         else:
             arr = np.empty((rows, w, 4), dtype=np.float32)
         N.check(N.lib().vpt_renderer_read(self._h, buffer, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
@@ -571,8 +575,6 @@ class DepthRenderer(AbstractRenderer):
         N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
 
 
-for _cls in (MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer, ISORenderer, DepthRenderer):
-    _cls._BASE = _cls
 
 
 class LAORenderer(AbstractRenderer):
@@ -645,10 +647,116 @@ class LAORenderer(AbstractRenderer):
         N.check(N.lib().vpt_renderer_render(self._h, C.byref(self._prepare_frame_uniforms())))
 
 
+class DOSRenderer(AbstractRenderer):
+    """src/js/renderers/DOSRenderer.js:14-316: directional occlusion shading — the volume is swept
+    front to back in view-aligned slices, `steps` slices per render() call until the far corner is passed; every slice
+    is one native pass that reads its neighbours' occlusion from the slice before"""
+    _KIND = N.RENDERER_DOS
+
+    def __init__(self, gl, volume, camera, environmentTexture, options=None):
+        super().__init__(gl, volume, camera, environmentTexture, options)
+        self.registerProperties([                                  # :18-63
+            {'name': 'steps', 'label': 'Steps', 'type': 'spinner', 'value': 50, 'min': 1},
+            {'name': 'slices', 'label': 'Slices', 'type': 'spinner', 'value': 200, 'min': 1},
+            {'name': 'extinction', 'label': 'Extinction', 'type': 'spinner', 'value': 100, 'min': 0},
+            {'name': 'aperture', 'label': 'Aperture', 'type': 'spinner', 'value': 30, 'min': 0, 'max': 89},
+            {'name': 'samples', 'label': 'Samples', 'type': 'spinner', 'value': 8, 'min': 1, 'max': 200, 'step': 1},
+            dict(_TF_PROPERTY),
+        ])
+
+        def on_samples(e):                                         # :72-74, before the reset of :76-84
+            if e.detail['name'] == 'samples':
+                self.generateOcclusionSamples()
+        self.addEventListener('change', on_samples)
+        _install_change_handler(self, ('slices', 'extinction', 'aperture', 'samples', 'transferFunction'))
+        self._depth = 0
+        self._minDepth = 0
+        self._maxDepth = 0
+        self.fused = False                                         # there is no single-launch form of this renderer
+        self.generateOcclusionSamples()
+
+    def generateOcclusionSamples(self):                            # :103-140
+        n = int(self.samples)
+        data = np.zeros(2 * n, dtype=np.float32)                   # Float32Array: every store rounds
+        averagex = 0.0
+        averagey = 0.0
+        for i in range(n):
+            r = math.sqrt(self.rng())
+            phi = self.rng() * 2 * math.pi
+            x = r * math.cos(phi)
+            y = r * math.sin(phi)
+            averagex += x / n
+            averagey += y / n
+            data[2 * i + 0] = x
+            data[2 * i + 1] = y
+        for i in range(n):
+            data[2 * i + 0] = float(data[2 * i + 0]) - averagex
+            data[2 * i + 1] = float(data[2 * i + 1]) - averagey
+        self._occlusionSamples = data
+        N.check(N.lib().vpt_renderer_set_occlusion_samples(self._h, data.ctypes.data_as(C.c_void_p), n))
+
+    def calculateDepth(self):                                      # :142-167
+        from .scene import mat4, vec3
+        centerMatrix = mat4.fromTranslation(mat4.create(), [-0.5, -0.5, -0.5])
+        modelMatrix = self._volumeTransform.globalMatrix
+        viewMatrix = self._camera.transform.inverseGlobalMatrix
+        matrix = mat4.create()
+        mat4.multiply(matrix, centerMatrix, matrix)
+        mat4.multiply(matrix, modelMatrix, matrix)
+        mat4.multiply(matrix, viewMatrix, matrix)
+        corners = [[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)]
+        depths = [-vec3.transformMat4(v, v, matrix)[2] for v in corners]      # plain arrays: double results
+        return [min(depths), max(depths)]
+
+    def _resetFrame(self):                                         # :169-185
+        self._minDepth, self._maxDepth = self.calculateDepth()
+        self._minDepth = max(self._minDepth, 0)
+        self._depth = self._minDepth
+        N.check(N.lib().vpt_renderer_reset(self._h, None))
+
+    def _prepare_slices(self):
+        """the uniforms of :212-236 and, per pass of the loop :240-259, (uOcclusionScale.x, uOcclusionScale.y, uDepth)"""
+        from .scene import PerspectiveCamera, vec3
+        u = self._new_uniforms()
+        u.extinction = _f32(self.extinction)
+        sliceDistance = (self._maxDepth - self._minDepth) / self.slices
+        u.step_size = _f32(sliceDistance)
+        projectionMatrix = self._camera.getComponent(PerspectiveCamera).projectionMatrix
+        rows = []
+        for _ in range(int(self.steps)):
+            if self._depth > self._maxDepth:
+                break
+            correction = [1, 1, -self._depth]
+            vec3.transformMat4(correction, correction, projectionMatrix)
+            occlusionExtent = sliceDistance * math.tan(self.aperture * math.pi / 180)
+            correction[0] *= occlusionExtent
+            correction[1] *= occlusionExtent
+            rows.append(correction)
+            self._depth += sliceDistance
+        self._u = u
+        return u, np.array(rows, dtype=np.float32).reshape(-1, 3)
+
+    def _integrateFrame(self):                                     # :187-262
+        self._bind_volume()
+        u, slices = self._prepare_slices()
+        self._slices = slices
+        N.check(N.lib().vpt_renderer_integrate_slices(self._h, C.byref(u), slices.ctypes.data_as(C.c_void_p), len(slices)))
+
+    def _renderFrame(self):                                        # :264-277
+        N.check(N.lib().vpt_renderer_render_frame(self._h, None))
+
+    def play(self, count, use_graph=True, fused=False):
+        raise N.VptError(N.ERR_UNSUPPORTED, 'frame sequences are not defined for the DOS renderer: drive it slice by slice')
+
+
+for _cls in (MIPRenderer, EAMRenderer, MCSRenderer, MCMRenderer, ISORenderer, DepthRenderer, LAORenderer, DOSRenderer):
+    _cls._BASE = _cls
+
+
 def RendererFactory(which):
-    """src/js/renderers/RendererFactory.js:10-23 ('dos' is not built: its shaders need a feedback loop over slices)."""
+    """src/js/renderers/RendererFactory.js:10-23 (all eight names)."""
     classes = {'mip': MIPRenderer, 'eam': EAMRenderer, 'mcs': MCSRenderer, 'mcm': MCMRenderer,
-               'iso': ISORenderer, 'depth': DepthRenderer, 'lao': LAORenderer}
+               'iso': ISORenderer, 'depth': DepthRenderer, 'lao': LAORenderer, 'dos': DOSRenderer}
     if which not in classes:
         raise RuntimeError('No suitable class')
     return classes[which]
