@@ -267,6 +267,22 @@ static napi_value RendererSetLaoParams(napi_env env, napi_callback_info info) {
     VPT_CHECK(vpt_renderer_set_lao_params(r, (const vpt_lao_params *)p));
     return undefined(env);
 }
+// rendererSetOcclusionSamples(handle, xy: Float32Array of 2 floats per sample) — DOSRenderer.js:103-140
+static napi_value RendererSetOcclusionSamples(napi_env env, napi_callback_info info) {
+    napi_value a[2]; vpt_renderer *r; void *p; size_t n;
+    if (!get_args(env, info, 2, a) || !get_handle(env, a[0], &r) || !get_bytes(env, a[1], &p, &n)) return nullptr;
+    if (n % (2 * sizeof(float)) != 0) { napi_throw_range_error(env, nullptr, "occlusion samples are 2 floats each"); return nullptr; }
+    VPT_CHECK(vpt_renderer_set_occlusion_samples(r, (const float *)p, (int)(n / (2 * sizeof(float)))));
+    return undefined(env);
+}
+// rendererIntegrateSlices(handle, uniforms, slices: Float32Array of 3 floats per slice) — DOSRenderer.js:199-259
+static napi_value RendererIntegrateSlices(napi_env env, napi_callback_info info) {
+    napi_value a[3]; vpt_renderer *r; const vpt_uniforms *u; void *p; size_t n;
+    if (!get_args(env, info, 3, a) || !get_handle(env, a[0], &r) || !get_uniforms(env, a[1], &u, false) || !get_bytes(env, a[2], &p, &n)) return nullptr;
+    if (n % (3 * sizeof(float)) != 0) { napi_throw_range_error(env, nullptr, "slices are 3 floats each"); return nullptr; }
+    VPT_CHECK(vpt_renderer_integrate_slices(r, u, (const float *)p, (int)(n / (3 * sizeof(float)))));
+    return undefined(env);
+}
 // rendererPlay(handle, baseUniforms, frameVars: Float32Array of 8 floats per frame, useGraph)
 static bool get_frame_vars(napi_env env, napi_value v, const float **vars, int *count) {
     void *p; size_t n;
@@ -417,7 +433,8 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("rendererRenderFrame", RendererRenderFrame); EXPORT("rendererRender", RendererRender); EXPORT("rendererRead", RendererRead);
     EXPORT("rendererSampleCount", RendererSampleCount); EXPORT("rendererClearSampleCount", RendererClearSampleCount);
     EXPORT("rendererSetProfiling", RendererSetProfiling); EXPORT("rendererProfile", RendererProfile);
-    EXPORT("rendererSetOption", RendererSetOption); EXPORT("rendererSetLaoParams", RendererSetLaoParams); EXPORT("rendererPlay", RendererPlay);
+    EXPORT("rendererSetOption", RendererSetOption); EXPORT("rendererSetLaoParams", RendererSetLaoParams);
+    EXPORT("rendererSetOcclusionSamples", RendererSetOcclusionSamples); EXPORT("rendererIntegrateSlices", RendererIntegrateSlices); EXPORT("rendererPlay", RendererPlay);
     EXPORT("tonemapperCreate", TonemapperCreate); EXPORT("tonemapperDestroy", TonemapperDestroy); EXPORT("tonemapperResize", TonemapperResize);
     EXPORT("tonemapperSetSource", TonemapperSetSource); EXPORT("tonemapperSetSourceImage", TonemapperSetSourceImage);
     EXPORT("tonemapperSetOption", TonemapperSetOption); CONST(VPT_TONEMAPPER_OPTION_TABLE); CONST(VPT_TONEMAPPER_TABLE_NEVER);
@@ -432,7 +449,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     CONST(VPT_OPTION_MCS_PERSISTENT); CONST(VPT_OPTION_MCM_PERSISTENT); CONST(VPT_OPTION_MCM_STAGGER);
     CONST(VPT_PLAY_EAGER); CONST(VPT_PLAY_GRAPH); CONST(VPT_PLAY_FUSED);
     CONST(VPT_RENDERER_MIP); CONST(VPT_RENDERER_EAM); CONST(VPT_RENDERER_MCS); CONST(VPT_RENDERER_MCM);
-    CONST(VPT_RENDERER_ISO); CONST(VPT_RENDERER_DEPTH); CONST(VPT_RENDERER_LAO);
+    CONST(VPT_RENDERER_ISO); CONST(VPT_RENDERER_DEPTH); CONST(VPT_RENDERER_LAO); CONST(VPT_RENDERER_DOS); CONST(VPT_BUFFER_DOS_OCCLUSION);
     CONST(VPT_FILTER_NEAREST); CONST(VPT_FILTER_LINEAR); CONST(VPT_FORMAT_R8); CONST(VPT_FORMAT_RG8);
     CONST(VPT_BUFFER_RENDER); CONST(VPT_BUFFER_FRAME); CONST(VPT_BUFFER_ACCUM);
     CONST(VPT_BUFFER_MCM_POSITION); CONST(VPT_BUFFER_MCM_DIRECTION); CONST(VPT_BUFFER_MCM_TRANSMITTANCE); CONST(VPT_BUFFER_MCM_RADIANCE);

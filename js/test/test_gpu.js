@@ -228,6 +228,33 @@ async function main() {
         lao.LAOStepSize = 0;
         assert.throws(() => lao.render(), /step size/);
         lao.destroy();
+        // DOS: the slice sweep driven by the Node host: progressive, ends past the far corner, occlusion darkens, repeatable
+        const mk = () => new vpt.DOSRenderer(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });
+        const dos = mk();
+        assert.deepStrictEqual(dos.properties.map(p => p.name), ['steps', 'slices', 'extinction', 'aperture', 'samples', 'transferFunction']);
+        assert.strictEqual(dos._occlusionSamples.length, 16);
+        dos.slices = 40; dos.steps = 25;
+        dos.reset();
+        assert.ok(dos._minDepth > 0 && dos._maxDepth > dos._minDepth);
+        let nslices = 0;
+        for (let k = 0; k < 3; k++) { dos.render(); nslices += dos._slices.length / 3; }
+        assert.ok((nslices === 40 || nslices === 41) && dos._slices.length === 0, 'dos slices ' + nslices);
+        const col = new Float32Array(W * H * 4), occ = new Float32Array(W * H);
+        dos.read(N.VPT_BUFFER_ACCUM, col); dos.read(N.VPT_BUFFER_DOS_OCCLUSION, occ);
+        let opaque = 0, empty = 0, shadowed = 0;
+        for (let i = 0; i < W * H; i++) {
+            assert.ok(occ[i] >= 0 && occ[i] <= 1 && col[4 * i + 3] >= 0 && col[4 * i + 3] <= 1);
+            if (col[4 * i + 3] > 0.5) { opaque++; } else if (col[4 * i + 3] === 0) { empty++; }
+            if (occ[i] < 0.5) { shadowed++; }
+        }
+        assert.ok(opaque > 50 && empty > 50 && shadowed > 50, 'dos opaque ' + opaque + ' empty ' + empty + ' shadowed ' + shadowed);
+        const dosImg = dos.getTexture().data;
+        const dos2 = mk(); dos2.slices = 40; dos2.steps = 25; dos2.reset();
+        for (let k = 0; k < 3; k++) { dos2.render(); }
+        assert.deepStrictEqual(dos2.getTexture().data, dosImg);
+        assert.throws(() => dos.play(2), /frame sequences/);
+        assert.throws(() => N.rendererIntegrate(dos._h, dos._u), /integrate_slices/);
+        dos.destroy(); dos2.destroy();
     }
 
     // ---- errors are thrown Errors carrying the native message

@@ -51,7 +51,8 @@ let seen = null;
 bag.addEventListener('change', e => { seen = e.detail; });
 bag.dispatchEvent(new vpt.CustomEvent('change', { detail: { name: 'steps', value: 8 } }));
 assert.deepStrictEqual(seen, { name: 'steps', value: 8 });
-assert.throws(() => vpt.RendererFactory('dos'), /No suitable class/);
+assert.throws(() => vpt.RendererFactory('nope'), /No suitable class/);
+assert.strictEqual(vpt.RendererFactory('dos'), vpt.DOSRenderer);
 assert.strictEqual(vpt.RendererFactory('lao'), vpt.LAORenderer);
 assert.strictEqual(vpt.RendererFactory('iso'), vpt.ISORenderer); assert.strictEqual(vpt.RendererFactory('depth'), vpt.DepthRenderer);
 assert.strictEqual(vpt.RendererFactory('mcm'), vpt.MCMRenderer);

@@ -5,6 +5,6 @@ module.exports = Object.assign({},
     require('./Context.js'), require('./animators.js'), require('./png.js'), require('./loaders/loaders.js'), require('./readers/readers.js'), require('./Volume.js'), require('./FrameGather.js'),
     require('./renderers/AbstractRenderer.js'), require('./renderers/MIPRenderer.js'), require('./renderers/EAMRenderer.js'),
     require('./renderers/MCSRenderer.js'), require('./renderers/MCMRenderer.js'), require('./renderers/ISORenderer.js'),
-    require('./renderers/DepthRenderer.js'), require('./renderers/LAORenderer.js'), require('./renderers/RendererFactory.js'),
+    require('./renderers/DepthRenderer.js'), require('./renderers/LAORenderer.js'), require('./renderers/DOSRenderer.js'), require('./renderers/RendererFactory.js'),
     require('./tonemappers/AbstractToneMapper.js'), require('./tonemappers/ArtisticToneMapper.js'), require('./tonemappers/RangeToneMapper.js'),
     require('./tonemappers/CurveToneMappers.js'), require('./tonemappers/ToneMapperFactory.js'), require('./RenderingContext.js'));

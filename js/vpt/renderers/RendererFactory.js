@@ -1,5 +1,5 @@
 'use strict';
-// src/js/renderers/RendererFactory.js:10-23 ('dos' is not built)
+// src/js/renderers/RendererFactory.js:10-23 (all eight names)
 const { MIPRenderer } = require('./MIPRenderer.js');
 const { EAMRenderer } = require('./EAMRenderer.js');
 const { MCSRenderer } = require('./MCSRenderer.js');
@@ -7,6 +7,7 @@ const { MCMRenderer } = require('./MCMRenderer.js');
 const { ISORenderer } = require('./ISORenderer.js');
 const { DepthRenderer } = require('./DepthRenderer.js');
 const { LAORenderer } = require('./LAORenderer.js');
+const { DOSRenderer } = require('./DOSRenderer.js');
 
 function RendererFactory(which) {
     switch (which) {
@@ -17,6 +18,7 @@ function RendererFactory(which) {
         case 'iso': return ISORenderer;
         case 'depth': return DepthRenderer;
         case 'lao': return LAORenderer;
+        case 'dos': return DOSRenderer;
         default: throw new Error('No suitable class');
     }
 }

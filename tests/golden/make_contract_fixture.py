@@ -30,8 +30,20 @@ def scenes():
         dict(name="iso", kind="iso", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=3,
              kw=dict(steps=40, mcm_steps=40, isovalue=0.35, gradient_step=0.005, light_dir=(0.32444283, -0.48666424, -0.81110704))),
         dict(name="depth", kind="depth", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=3, kw=dict(steps=48, extinction=60.0, threshold=0.15)),
+        dict(name="lao", kind="lao", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=1, kw=dict(steps=24, extinction=80.0)),
+        dict(name="dos", kind="dos", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=2, kw=dict(steps=50, extinction=60.0)),
         dict(name="mcm_hg", kind="mcm", vol=vol, filter="linear", tf=tf, w=96, h=64, frames=4, kw=dict(extinction=8.0, anisotropy=0.5, max_bounces=3, mcm_steps=6)),
     ], default_matrix
+
+
+def dos_inputs(frame):
+    """the DOS scene's explicit per-slice uniforms (uOcclusionScale.xy, uDepth) for render() call `frame`, and its six
+    occlusion samples"""
+    seq = lambda k: (k * 0.61803398875) % 1.0
+    samples = np.array([[2 * seq(2 * i + 1) - 1, 2 * seq(2 * i + 2) - 1] for i in range(6)], np.float32)
+    depths = np.linspace(0.866, 0.923, 16, dtype=np.float32)[8 * frame:8 * frame + 8]       # the cube spans NDC depth 0.8685 .. 0.9219
+    slices = np.array([[0.021, 0.033, d] for d in depths], np.float32)
+    return slices, samples
 
 
 def digest(*arrays):
@@ -50,8 +62,11 @@ def run(oracle, sc, default_matrix):
     o.reset(fr)
     for k in range(sc["frames"]):
         fr.seed = seq(k + 2); fr.offset = seq(k + 2); fr.mix = float(np.float32(1.0 / (k + 1)))
-        o.render(fr)
-    bufs = o.state if sc["kind"] == "mcm" else [o.acc]
+        if sc["kind"] == "dos":
+            o.integrate_slices(fr, *dos_inputs(k)); o.render_frame(fr)
+        else:
+            o.render(fr)
+    bufs = o.state if sc["kind"] == "mcm" else [o.color[o.cur], o.occlusion[o.cur]] if sc["kind"] == "dos" else [o.acc]
     return {"buffers": digest(*bufs), "render_f16": digest(o.out), "samples": int(o.samples)}
 
 

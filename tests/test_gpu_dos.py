@@ -168,3 +168,24 @@ def test_dos_full_size_oracle(gpu_ctx, oracle):
     r.slices = 24; r.steps = 12
     sweep(sc, oracle, r, 1, "dos 1080p", nthreads=8)
     r.destroy(); sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_dos_random_scene(gpu_ctx, oracle, seed):
+    """the random scenes of test_gpu_fuzz.py (image / volume shapes down to 1, RG8, NEAREST, cameras inside, outside and
+    looking away, scaled / rotated models, 2-D transfer functions) swept by the DOS renderer"""
+    from test_gpu_fuzz import random_case, random_camera
+    rng, vol, (w, h), tf, env, filt, model = random_case(7000 + seed)
+    camera = random_camera(rng, w / h)
+    sc = Scene.__new__(Scene)
+    sc.vol, sc.w, sc.h, sc.tf, sc.ctx = vol, w, h, tf, gpu_ctx
+    sc.osc = oracle.OracleScene(vol, filt, tf=tf)
+    sc.gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, filt)
+    sc.camera, sc.transform = camera, model
+    sc.m = mvp_inverse_matrix(camera, model)
+    r = sc.renderer(rng=GoldenRatioRng(int(rng.integers(1, 50))))
+    r.slices = int(rng.choice([1, 6, 17, 40])); r.steps = int(rng.choice([1, 5, 50])); r.extinction = float(rng.choice([0.0, 10.0, 100.0, 1000.0]))
+    r.aperture = float(rng.choice([0, 10, 30, 75, 89])); r.samples = int(rng.choice([1, 2, 8, 33]))
+    r.generateOcclusionSamples()
+    sweep(sc, oracle, r, 3, "dos seed %d (%dx%d image, volume %s, %s)" % (seed, w, h, vol.shape, filt), nthreads=2)
+    r.destroy(); sc.gvol.destroy()

@@ -330,7 +330,7 @@ def test_native_rccl_gather_single_rank(gpu_ctx, oracle):
 
 def test_errors_are_loud(gpu_ctx):
     with pytest.raises(RuntimeError, match="No suitable class"):
-        vpt_amd.RendererFactory('dos')
+        vpt_amd.RendererFactory('nope')
     r = vpt_amd.MIPRenderer(gpu_ctx, None, default_camera(), None, {'resolution': 32})
     r.reset()
     with pytest.raises(vpt_amd.VptError, match="no ready volume"):
@@ -475,8 +475,15 @@ def test_gpu_matches_committed_contract_digests(gpu_ctx):
         N.check(L.vpt_renderer_reset(r._h, C.byref(u)))
         for k in range(sc["frames"]):
             u.rand_seed = seq(k + 2); u.offset = seq(k + 2); u.mix = float(np.float32(1.0 / (k + 1)))
-            N.check(L.vpt_renderer_render(r._h, C.byref(u)))
-        bufs = [r.read(b) for b in MCM_BUFFERS] if sc["kind"] == "mcm" else [r.read(N.BUFFER_ACCUM)]
+            if sc["kind"] == "dos":
+                slices, samples = mod.dos_inputs(k)
+                N.check(L.vpt_renderer_set_occlusion_samples(r._h, samples.ctypes.data_as(C.c_void_p), len(samples)))
+                N.check(L.vpt_renderer_integrate_slices(r._h, C.byref(u), slices.ctypes.data_as(C.c_void_p), len(slices)))
+                N.check(L.vpt_renderer_render_frame(r._h, None))
+            else:
+                N.check(L.vpt_renderer_render(r._h, C.byref(u)))
+        bufs = [r.read(b) for b in MCM_BUFFERS] if sc["kind"] == "mcm" else \
+               [r.read(N.BUFFER_ACCUM), r.read(N.BUFFER_DOS_OCCLUSION)] if sc["kind"] == "dos" else [r.read(N.BUFFER_ACCUM)]
         got = {"buffers": mod.digest(*bufs), "render_f16": mod.digest(r.getTexture().view(np.uint16)), "samples": r.sample_count()}
         assert got == want[sc["name"]], sc["name"]
         r.destroy(); vol.destroy()

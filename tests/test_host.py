@@ -25,7 +25,8 @@ def test_renderer_factory_names():
     assert vpt_amd.RendererFactory('mcs') is vpt_amd.MCSRenderer
     assert vpt_amd.RendererFactory('mcm') is vpt_amd.MCMRenderer
     assert vpt_amd.RendererFactory('iso') is vpt_amd.ISORenderer and vpt_amd.RendererFactory('depth') is vpt_amd.DepthRenderer
-    for name in ('dos', 'nope'):
+    assert vpt_amd.RendererFactory('lao') is vpt_amd.LAORenderer and vpt_amd.RendererFactory('dos') is vpt_amd.DOSRenderer
+    for name in ('nope', ''):
         with pytest.raises(RuntimeError, match='No suitable class'):      # RendererFactory.js:21
             vpt_amd.RendererFactory(name)
 

@@ -85,7 +85,7 @@ struct vpt_renderer {
     bool mcs_persistent;           // use k_mcs_persist (active-ray compaction) for the MCS generate pass
     LaoParams lao;                 // LAO renderer parameters (vpt_renderer_set_lao_params; defaults LAORenderer.js:17-108)
     float2 *dos_samples; int dos_nsamples;   // DOS: uOcclusionSamples (vpt_renderer_set_occlusion_samples)
-    int dos_cur;                   // DOS: which of colour st[0|1] / occlusion st[2|3] holds the latest slice
+    int dos_cur;                   // DOS: which of the occlusion buffers st[2|3] holds the latest slice (colour: st[0], in place)
     int mcm_stagger;               // VPT_OPTION_MCM_STAGGER: phase-stagger quantum (10 ns ticks) | pattern << 24; 0 = off
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
@@ -111,7 +111,7 @@ static size_t frame_elem(int kind) {
         case VPT_RENDERER_ISO: return 8;      // RGBA16F (ISORenderer.js:165-197)
         case VPT_RENDERER_DEPTH: return 4;    // R32F (DepthRenderer.js:165-189)
         case VPT_RENDERER_LAO: return 4;      // RGBA8 (LAORenderer.js:217-243)
-        case VPT_RENDERER_DOS: return 0;      // colour RGBA32F + occlusion R32F, both double-buffered, ROW-MAJOR: st[0..3] (DOSRenderer.js:273-313)
+        case VPT_RENDERER_DOS: return 0;      // colour RGBA32F (st[0]) + occlusion R32F double-buffered (st[2], st[3]), ROW-MAJOR (DOSRenderer.js:273-313)
         default: return 0;
     }
 }
@@ -525,8 +525,8 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
     a->inv_h = (float)(1.0 / (double)r->H);
     a->frame = r->frame; a->acc = r->acc;
     a->st0 = r->st[0]; a->st1 = r->st[1]; a->st2 = r->st[2]; a->st3 = r->st[3];
-    if (r->kind == VPT_RENDERER_DOS) {            // (colour, occlusion) in = the latest pair, out = the other one
-        a->st0 = r->st[r->dos_cur]; a->st1 = r->st[1 - r->dos_cur]; a->st2 = r->st[2 + r->dos_cur]; a->st3 = r->st[3 - r->dos_cur];
+    if (r->kind == VPT_RENDERER_DOS) {            // colour: st[0], in place; occlusion: in = the latest of st[2|3], out = the other
+        a->st1 = nullptr; a->st2 = r->st[2 + r->dos_cur]; a->st3 = r->st[3 - r->dos_cur];
     }
     a->render = r->render_target ? r->render_target : r->render;
     a->samples = r->samples;
@@ -947,7 +947,7 @@ extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t 
     }
     const void *src = nullptr; size_t elem = 0;
     if (r->kind == VPT_RENDERER_DOS) {            // row-major already: no tile order to undo
-        if (buffer == VPT_BUFFER_ACCUM) { src = r->st[r->dos_cur]; elem = 16; }
+        if (buffer == VPT_BUFFER_ACCUM) { src = r->st[0]; elem = 16; }
         else if (buffer == VPT_BUFFER_DOS_OCCLUSION) { src = r->st[2 + r->dos_cur]; elem = 4; }
         else return fail(VPT_ERR_INVALID, "the DOS renderer holds VPT_BUFFER_ACCUM (colour) and VPT_BUFFER_DOS_OCCLUSION; its frame buffer is never written");
         if (nbytes < npix * elem) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, npix * elem);
@@ -1017,7 +1017,7 @@ extern "C" int vpt_renderer_integrate_slices(vpt_renderer *r, const vpt_uniforms
     VPT_TRY(make_args(r, u, true, &a));
     Timed t(r, true, (uint32_t)(count > 0 ? count : 1));
     for (int s = 0; s < count; s++) {
-        a.st0 = r->st[r->dos_cur]; a.st1 = r->st[1 - r->dos_cur]; a.st2 = r->st[2 + r->dos_cur]; a.st3 = r->st[3 - r->dos_cur];
+        a.st2 = r->st[2 + r->dos_cur]; a.st3 = r->st[3 - r->dos_cur];
         a.dos = DosParams{ r->dos_samples, r->dos_nsamples, slices[3 * s], slices[3 * s + 1], slices[3 * s + 2] };
         LAUNCH_S(K_DOS, r, a);
         r->dos_cur ^= 1;

@@ -75,7 +75,7 @@ struct LaoParams {               // = struct vpt_lao_params (include/vpt.h)
     float light_position[3];
 };
 // DOS slice pass: uOcclusionSamples / uOcclusionSamplesCount / uOcclusionScale / uDepth (DOSRenderer.js:212-254); the colour
-// and occlusion ping-pong buffers travel in st0 (colour in), st1 (colour out), st2 (occlusion in), st3 (occlusion out)
+// buffer (updated in place) travels in st0, the occlusion ping-pong pair in st2 (in) and st3 (out)
 struct DosParams { const float2 *samples; int nsamples; float scale_x, scale_y, depth; };
 struct PassArgs {
     PixMap pm;
