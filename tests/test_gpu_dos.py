@@ -189,3 +189,29 @@ def test_dos_random_scene(gpu_ctx, oracle, seed):
     r.generateOcclusionSamples()
     sweep(sc, oracle, r, 3, "dos seed %d (%dx%d image, volume %s, %s)" % (seed, w, h, vol.shape, filt), nthreads=2)
     r.destroy(); sc.gvol.destroy()
+
+
+def test_dos_matrix_changes_mid_sweep_and_volume_partly_off_screen(gpu_ctx, oracle):
+    """the native side only launches the tiles of the volume's screen bounding box; moving the camera between render() calls
+    without a reset (the C-ABI allows it) must still give the oracle's buffers everywhere, and so must a volume that
+    leaves the image or is off screen altogether"""
+    cam = orbit_camera(160 / 120, dist=3.5)                          # small on screen: most tiles are never launched
+    sc = Scene(gpu_ctx, oracle, sphere_volume(24, noise=40.0), 160, 120, tf=colour_tf(32, 1), camera=cam)
+    r = sc.renderer()
+    r.slices = 30; r.steps = 6; r.extinction = 90
+    o = oracle.OracleRenderer('dos', sc.osc, sc.w, sc.h)
+    r.reset(); o.reset(oracle.make_frame(sc.w, sc.h, sc.m))
+    moves = [None, [1.2, 0.3, 2.6], [-2.4, -0.2, 2.2], [0.0, 0.0, 60.0], [9.0, 0.0, 2.0], None]     # sideways, far away, off screen
+    for k, mv in enumerate(moves):
+        if mv is not None:
+            cam.transform.localTranslation = mv
+        r.render()
+        u = r._u
+        fr = oracle.make_frame(sc.w, sc.h, np.array(list(u.mvp_inverse), np.float32), extinction=u.extinction, nthreads=4)
+        fr.step = u.step_size
+        o.integrate_slices(fr, r._slices, r._occlusionSamples); o.render_frame(fr)
+        same_bits(r.read(N.BUFFER_ACCUM), o.color[o.cur], "colour after move %d" % k)
+        same_bits(r.read(N.BUFFER_DOS_OCCLUSION), o.occlusion[o.cur], "occlusion after move %d" % k)
+        same_bits(r.getTexture().view(np.uint16), o.out, "render after move %d" % k)
+    assert r.sample_count() == o.samples and o.samples > 0
+    r.destroy(); sc.gvol.destroy()

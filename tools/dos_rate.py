@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """DOS renderer: time of one full sweep (reset + ceil(slices/steps) render() calls) at 1920x1080, per slice and per sweep.
-Algorithmic bytes per pixel and slice: colour 16 B read + 16 B written, occlusion 4 B read + 4 B written (the
-`samples` bilinear taps land next to the pixel: L1 / L2 hits), 1 volume sample on the pixels the slice covers.
+A reference-shaped pass moves 40 B per pixel and slice over the WHOLE image (colour 16 B read + 16 B written, occlusion
+4 B read + 4 B written); the native pass only launches the tiles of the volume's screen bounding box and updates the
+colour in place, so `whole_image_equivalent_GB_per_s` (40 B x W x H per slice) is a comparison figure, not traffic.
 Usage: python tools/dos_rate.py [--volume 256] [--slices 200] [--samples 8] [--sweeps 5]"""
 import argparse
 import json
@@ -52,7 +53,7 @@ def main():
     ns = r.sample_count() / (args.sweeps + 1)
     print(json.dumps({"renderer": "dos", "volume": args.volume, "image": [W, H], "slices_per_sweep": total // args.sweeps, "occlusion_samples": args.samples,
                       "ms_per_sweep": dt * 1e3, "us_per_slice": per_slice * 1e6, "volume_samples_per_sweep": ns,
-                      "buffer_GB_per_s": 40.0 * W * H / per_slice / 1e9}))
+                      "whole_image_equivalent_GB_per_s": 40.0 * W * H / per_slice / 1e9}))
     r.destroy(); vol.destroy(); ctx.destroy()
 
 

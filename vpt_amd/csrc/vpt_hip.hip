@@ -85,6 +85,7 @@ struct vpt_renderer {
     bool mcs_persistent;           // use k_mcs_persist (active-ray compaction) for the MCS generate pass
     LaoParams lao;                 // LAO renderer parameters (vpt_renderer_set_lao_params; defaults LAORenderer.js:17-108)
     float2 *dos_samples; int dos_nsamples;   // DOS: uOcclusionSamples (vpt_renderer_set_occlusion_samples)
+    int dos_rect[4]; bool dos_rect_valid;   // DOS: tile rectangle [x0, y0, x1, y1) of the previous integrate call (see dos_tile_rect)
     int dos_cur;                   // DOS: which of the occlusion buffers st[2|3] holds the latest slice (colour: st[0], in place)
     int mcm_stagger;               // VPT_OPTION_MCM_STAGGER: phase-stagger quantum (10 ns ticks) | pattern << 24; 0 = off
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
@@ -324,7 +325,7 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     renderer_free_buffers(r);
-    r->dos_cur = 0;
+    r->dos_cur = 0; r->dos_rect_valid = false;
     int nblocks = (r->H + r->R - 1) / r->R;                 // row blocks in the image
     int mine = (nblocks - r->g + r->G - 1) / r->G;          // blocks b with b % G == g
     int max_blocks = (nblocks + r->G - 1) / r->G;           // every rank pads to this (equal-size gather)
@@ -542,7 +543,7 @@ static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)(r->tiles_x
 // the default camera only ~20 % of the tiles cross the cube, about one resident round of 4-wave workgroups, which the
 // dispatcher cannot rebalance (measured: 3.3e11 samples/s against 5.7e11 when every tile crosses the cube).
 static bool wave_blocks(const vpt_renderer *r) {
-    return r->kind != VPT_RENDERER_MCM && lds_bytes(r) * 28 <= 150 * 1024;
+    return r->kind != VPT_RENDERER_MCM && r->kind != VPT_RENDERER_DOS && lds_bytes(r) * 28 <= 150 * 1024;
 }
 template <typename K>
 static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigned) {
@@ -586,7 +587,6 @@ static int variant_of(const vpt_renderer *r) {
 #define K_DEPTH1(V) (k_depth<1, V>)
 #define K_LAO0(V) (k_lao<0, V>)
 #define K_LAO1(V) (k_lao<1, V>)
-#define K_DOS(V) (k_dos_slice<V>)
 #define K_MCM0(V) (k_mcm_integrate<false, V>)
 #define K_MCM1(V) (k_mcm_integrate<true, V>)
 
@@ -684,7 +684,7 @@ extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_ISO: LAUNCH(k_iso_reset, r, a, 0); break;
         case VPT_RENDERER_DEPTH: LAUNCH(k_depth_reset, r, a, 0); break;
         case VPT_RENDERER_LAO: LAUNCH(k_eam_reset, r, a, 0); break;           // LAORenderer.glsl:285-287: (0, 0, 0, 1) into RGBA8
-        case VPT_RENDERER_DOS: LAUNCH(k_dos_reset, r, a, 0); break;
+        case VPT_RENDERER_DOS: LAUNCH(k_dos_reset, r, a, 0); r->dos_rect_valid = false; break;
     }
     HIP_TRY(hipGetLastError());
     return VPT_OK;
@@ -1005,6 +1005,66 @@ extern "C" int vpt_renderer_set_occlusion_samples(vpt_renderer *r, const float *
     r->dos_nsamples = count;
     return VPT_OK;
 }
+// The tiles a DOS slice has to touch.  A pixel whose ray never meets the volume keeps colour 0 and occlusion 1 for the whole
+// sweep, and a pixel outside the volume at two consecutive slices already has the right value in the occlusion buffer
+// about to be written (it was copied there two slices ago) — so a pass only needs the screen bounding box of the
+// volume: the 8 corners of [0,1]^3 taken through the inverse of uMvpInverseMatrix (double precision), padded by one tile
+// against the kernel's own fp32 evaluation.  Any corner at or behind the eye plane (w <= 1e-4), or a matrix that does not
+// invert, gives the whole image.
+static void dos_tile_rect(const vpt_renderer *r, const float *mvp_inverse, int rect[4]) {
+    const int tx = r->tiles_x, ty = r->tiles_y;
+    rect[0] = 0; rect[1] = 0; rect[2] = tx; rect[3] = ty;
+    double a[4][8];                                  // [M^-1 | I], column-major source -> row-major work matrix
+    for (int row = 0; row < 4; row++)
+        for (int col = 0; col < 4; col++) { a[row][col] = (double)mvp_inverse[col * 4 + row]; a[row][4 + col] = row == col ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; col++) {              // Gauss-Jordan with partial pivoting
+        int piv = col;
+        for (int row = col + 1; row < 4; row++) if (fabs(a[row][col]) > fabs(a[piv][col])) piv = row;
+        if (!(fabs(a[piv][col]) > 1e-300)) return;
+        if (piv != col) for (int k = 0; k < 8; k++) std::swap(a[piv][k], a[col][k]);
+        double inv = 1.0 / a[col][col];
+        for (int k = 0; k < 8; k++) a[col][k] *= inv;
+        for (int row = 0; row < 4; row++) if (row != col) { double f = a[row][col]; for (int k = 0; k < 8; k++) a[row][k] -= f * a[col][k]; }
+    }
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int c = 0; c < 8; c++) {
+        double p[4] = { (double)(c & 1), (double)((c >> 1) & 1), (double)((c >> 2) & 1), 1.0 }, q[4];
+        for (int row = 0; row < 4; row++) q[row] = a[row][4] * p[0] + a[row][5] * p[1] + a[row][6] * p[2] + a[row][7] * p[3];
+        if (!(q[3] > 1e-4)) return;
+        double x = q[0] / q[3], y = q[1] / q[3];
+        if (!(fabs(x) < 1e6) || !(fabs(y) < 1e6)) return;
+        xmin = std::min(xmin, x); xmax = std::max(xmax, x); ymin = std::min(ymin, y); ymax = std::max(ymax, y);
+    }
+    // pixel i has its centre at NDC (2i + 1) / W - 1
+    double i0 = floor(((xmin + 1.0) * r->W - 1.0) * 0.5), i1 = ceil(((xmax + 1.0) * r->W - 1.0) * 0.5);
+    double j0 = floor(((ymin + 1.0) * r->H - 1.0) * 0.5), j1 = ceil(((ymax + 1.0) * r->H - 1.0) * 0.5);
+    int x0 = (int)std::max(0.0, std::min((double)tx, floor(i0 / VPT_TILE) - 1.0)), x1 = (int)std::max(0.0, std::min((double)tx, floor(i1 / VPT_TILE) + 2.0));
+    int y0 = (int)std::max(0.0, std::min((double)ty, floor(j0 / VPT_TILE) - 1.0)), y1 = (int)std::max(0.0, std::min((double)ty, floor(j1 / VPT_TILE) + 2.0));
+    if (x1 <= x0 || y1 <= y0) { x0 = x1 = y0 = y1 = 0; }                      // the volume is off screen: nothing to launch
+    rect[0] = x0; rect[1] = y0; rect[2] = x1; rect[3] = y1;
+}
+template <typename K>
+static int launch_dos_slice(K kernel, vpt_renderer *r, PassArgs &a, const int rect[4]) {
+    size_t lds = lds_bytes(r);
+    if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    a.dos.tile_x0 = rect[0]; a.dos.tile_y0 = rect[1];
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(rect[2] - rect[0]), (unsigned)(rect[3] - rect[1])), dim3(VPT_BLOCK), lds, r->ctx->stream, a);
+    return VPT_OK;
+}
+static int launch_dos(vpt_renderer *r, PassArgs &a, const int rect[4]) {
+    if (rect[2] <= rect[0] || rect[3] <= rect[1]) return VPT_OK;
+    switch (variant_of(r)) {
+        case 0: return launch_dos_slice(k_dos_slice<0>, r, a, rect);
+        case 1: return launch_dos_slice(k_dos_slice<1>, r, a, rect);
+        case 2: return launch_dos_slice(k_dos_slice<2>, r, a, rect);
+        case 3: return launch_dos_slice(k_dos_slice<3>, r, a, rect);
+        case 8: return launch_dos_slice(k_dos_slice<8>, r, a, rect);
+        case 9: return launch_dos_slice(k_dos_slice<9>, r, a, rect);
+        case 10: return launch_dos_slice(k_dos_slice<10>, r, a, rect);
+        default: return launch_dos_slice(k_dos_slice<11>, r, a, rect);
+    }
+}
 // _integrateFrame of the DOS renderer (DOSRenderer.js:199-259): `count` full-screen passes, pass s with
 // (uOcclusionScale.x, uOcclusionScale.y, uDepth) = slices[3s .. 3s+2]; uSliceDistance = u->step_size, uExtinction = u->extinction
 extern "C" int vpt_renderer_integrate_slices(vpt_renderer *r, const vpt_uniforms *u, const float *slices, int count) {
@@ -1015,13 +1075,22 @@ extern "C" int vpt_renderer_integrate_slices(vpt_renderer *r, const vpt_uniforms
     HIP_TRY(hipSetDevice(r->ctx->device));
     PassArgs a;
     VPT_TRY(make_args(r, u, true, &a));
+    int rect[4], first[4];
+    dos_tile_rect(r, u->mvp_inverse, rect);
+    memcpy(first, rect, sizeof(rect));
+    if (r->dos_rect_valid && r->dos_rect[2] > r->dos_rect[0]) {     // the matrix may have moved since the previous call: its
+        if (first[2] <= first[0]) memcpy(first, r->dos_rect, sizeof(first));   // rectangle is swept once more (first slice only)
+        else { first[0] = std::min(first[0], r->dos_rect[0]); first[1] = std::min(first[1], r->dos_rect[1]);
+               first[2] = std::max(first[2], r->dos_rect[2]); first[3] = std::max(first[3], r->dos_rect[3]); }
+    }
     Timed t(r, true, (uint32_t)(count > 0 ? count : 1));
     for (int s = 0; s < count; s++) {
         a.st2 = r->st[2 + r->dos_cur]; a.st3 = r->st[3 - r->dos_cur];
-        a.dos = DosParams{ r->dos_samples, r->dos_nsamples, slices[3 * s], slices[3 * s + 1], slices[3 * s + 2] };
-        LAUNCH_S(K_DOS, r, a);
+        a.dos = DosParams{ r->dos_samples, r->dos_nsamples, slices[3 * s], slices[3 * s + 1], slices[3 * s + 2], 0, 0 };
+        VPT_TRY(launch_dos(r, a, s == 0 ? first : rect));
         r->dos_cur ^= 1;
     }
+    if (count > 0) { memcpy(r->dos_rect, rect, sizeof(rect)); r->dos_rect_valid = true; }
     HIP_TRY(hipGetLastError());
     return VPT_OK;
 }

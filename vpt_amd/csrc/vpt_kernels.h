@@ -76,7 +76,8 @@ struct LaoParams {               // = struct vpt_lao_params (include/vpt.h)
 };
 // DOS slice pass: uOcclusionSamples / uOcclusionSamplesCount / uOcclusionScale / uDepth (DOSRenderer.js:212-254); the colour
 // buffer (updated in place) travels in st0, the occlusion ping-pong pair in st2 (in) and st3 (out)
-struct DosParams { const float2 *samples; int nsamples; float scale_x, scale_y, depth; };
+// tile_x0 / tile_y0: first 16x16 tile of the launch rectangle (the screen bounding box of the volume; the grid covers it)
+struct DosParams { const float2 *samples; int nsamples; float scale_x, scale_y, depth; int tile_x0, tile_y0; };
 struct PassArgs {
     PixMap pm;
     DevVolume vol;

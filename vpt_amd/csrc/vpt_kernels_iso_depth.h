@@ -326,10 +326,14 @@ template <int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_dos_slice(PassArgs a) {
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
-    Pix p = map_pixel(a.pm);
+    // plain 2-D grid over the tiles of the launch rectangle (row-major buffers: no tile order, no XCD interleave to keep)
+    const DosParams &d = a.dos;
+    Pix p;
+    p.i = (d.tile_x0 + (int)blockIdx.x) * VPT_TILE + ((int)threadIdx.x & (VPT_TILE - 1));
+    p.j = (d.tile_y0 + (int)blockIdx.y) * VPT_TILE + ((int)threadIdx.x / VPT_TILE);
+    p.valid = p.i < a.pm.W && p.j < a.pm.H;
     uint32_t ns = 0;
     if (p.valid) {
-        const DosParams &d = a.dos;
         const int W = a.pm.W, H = a.pm.H;
         const size_t k = (size_t)p.j * W + p.i;
         const float *occ_in = (const float *)a.st2;
@@ -365,13 +369,15 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_dos_slice(PassArgs a) {
     }
     count_samples(a.samples, ns);
 }
-// reset: DOSRenderer.glsl:137-144 into the current (st0 / st2) pair
+// reset: DOSRenderer.glsl:137-144.  BOTH occlusion buffers are set: a pixel outside the launch rectangle is never
+// written again, and it reads 1.0 whichever of the two is current
 __global__ void __launch_bounds__(VPT_BLOCK) k_dos_reset(PassArgs a) {
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
     size_t k = (size_t)p.j * a.pm.W + p.i;
     a.st0[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     ((float *)a.st2)[k] = 1.0f;
+    ((float *)a.st3)[k] = 1.0f;
 }
 // render: DOSRenderer.glsl:113-116
 __global__ void __launch_bounds__(VPT_BLOCK) k_dos_render(PassArgs a) {
