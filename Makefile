@@ -20,6 +20,7 @@ fixtures:         ## regenerate the golden fixtures (build container only: needs
 	$(PY) tests/golden/make_tonemap_fixture.py
 	$(PY) tests/golden/make_reader_fixture.py
 	cd tests/golden && node --no-warnings --experimental-loader ./esm_loader.mjs run_reference_animator.mjs > circle_animator_r01.json
+	cd tests/golden && node --no-warnings --experimental-loader ./esm_loader.mjs run_reference_orbit.mjs > orbit_animator_r01.json
 
 clean:
 	$(MAKE) -C vpt_amd/csrc clean

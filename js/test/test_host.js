@@ -35,6 +35,41 @@ for (const c of anim.cases) {
         assert.deepStrictEqual(Array.from(new Uint32Array(node.transform.localRotation.buffer)), f.rotation_bits);
     }
 }
+// OrbitCameraAnimator against the reference's own, on scripted input (tests/golden/orbit_animator_r01.json)
+{
+    const orbit = JSON.parse(fs.readFileSync(path.join(__dirname, '..', '..', 'tests', 'golden', 'orbit_animator_r01.json')));
+    let checked = 0;
+    for (const c of orbit.cases) {
+        const node = new vpt.Node();
+        node.transform.localTranslation = c.start;
+        let clock = 1000;
+        const a = new vpt.OrbitCameraAnimator(node, null, Object.assign({}, c.options, { now: () => clock }));
+        for (const f of c.frames) {
+            const s = f.step, v0 = node.transform.version;
+            let thrown = null;
+            try {
+                switch (s[0]) {
+                    case 'rotate': a._rotateAroundFocus(s[1], s[2]); break;
+                    case 'zoom': a._zoom(s[1]); break;
+                    case 'move': a._move(s[1].slice()); break;
+                    case 'pointerdown': a._handlePointerDown({ button: s[1] }); break;
+                    case 'pointerup': a._handlePointerUp({}); break;
+                    case 'pointermove': a._handlePointerMove({ movementX: s[1], movementY: s[2], shiftKey: s[3] }); break;
+                    case 'wheel': a._handleWheel({ deltaY: s[1] }); break;
+                    case 'keydown': a._handleKeyDown({ key: s[1] }); break;
+                    case 'keyup': a._handleKeyUp({ key: s[1] }); break;
+                    case 'tick': clock += s[1]; a._update(); break;
+                }
+            } catch (e) { thrown = e.constructor.name; }
+            assert.strictEqual(thrown, f.throws);
+            if (f.translation_bits === null) { assert.strictEqual(node.transform.version, v0); continue; }
+            assert.deepStrictEqual(Array.from(new Uint32Array(node.transform.localTranslation.buffer)), f.translation_bits);
+            assert.deepStrictEqual(Array.from(new Uint32Array(node.transform.localRotation.buffer)), f.rotation_bits);
+            checked++;
+        }
+    }
+    assert.ok(checked >= 15);
+}
 // PNG encoder: signature, IHDR, CRCs
 {
     const png = vpt.encodePNG({ data: new Uint8Array([255, 0, 0, 255, 0, 255, 0, 255]), width: 1, height: 2 }, true);

@@ -5,6 +5,7 @@
 //   new RenderingContext({ resolution, filter, device, rng })     resolution: number or { width, height }
 const { EventTarget, CustomEvent } = require('./EventTarget.js');
 const { Context } = require('./Context.js');
+const { OrbitCameraAnimator } = require('./animators.js');
 const { Node, Transform, PerspectiveCamera } = require('./scene.js');
 const { Volume } = require('./Volume.js');
 const { RendererFactory } = require('./renderers/RendererFactory.js');
@@ -31,7 +32,7 @@ constructor(options) {
     this.volumeTransform = new Transform(new Node());                                 // :57
     this.renderer = null;
     this.toneMapper = null;
-    this.cameraAnimator = null;       // the reference installs an OrbitCameraAnimator (UI); assign a CircleAnimator to record
+    this.cameraAnimator = new OrbitCameraAnimator(this.camera, null);                 // :54 (headless: no canvas to listen on)
     const size = this._size();
     this.resize(size[0], size[1]);
 }

@@ -17,6 +17,18 @@ const vec3 = {
         out[2] = (m[2] * x + m[6] * y + m[10] * z + m[14]) / w;
         return out;
     },
+    add(out, a, b) { out[0] = a[0] + b[0]; out[1] = a[1] + b[1]; out[2] = a[2] + b[2]; return out; },
+    distance(a, b) { return Math.hypot(b[0] - a[0], b[1] - a[1], b[2] - a[2]); },
+    transformQuat(out, a, q) {
+        const qx = q[0], qy = q[1], qz = q[2], qw = q[3], x = a[0], y = a[1], z = a[2];
+        let uvx = qy * z - qz * y, uvy = qz * x - qx * z, uvz = qx * y - qy * x;
+        let uuvx = qy * uvz - qz * uvy, uuvy = qz * uvx - qx * uvz, uuvz = qx * uvy - qy * uvx;
+        const w2 = qw * 2;
+        uvx *= w2; uvy *= w2; uvz *= w2;
+        uuvx *= 2; uuvy *= 2; uuvz *= 2;
+        out[0] = x + uvx + uuvx; out[1] = y + uvy + uuvy; out[2] = z + uvz + uuvz;
+        return out;
+    },
     cross(out, a, b) {
         const ax = a[0], ay = a[1], az = a[2], bx = b[0], by = b[1], bz = b[2];
         out[0] = ay * bz - az * by; out[1] = az * bx - ax * bz; out[2] = ax * by - ay * bx;
@@ -39,6 +51,18 @@ const quat = {
         const dot = a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
         const invDot = dot ? 1.0 / dot : 0;
         out[0] = -a0 * invDot; out[1] = -a1 * invDot; out[2] = -a2 * invDot; out[3] = a3 * invDot;
+        return out;
+    },
+    rotateX(out, a, rad) {
+        rad *= 0.5;
+        const ax = a[0], ay = a[1], az = a[2], aw = a[3], bx = Math.sin(rad), bw = Math.cos(rad);
+        out[0] = ax * bw + aw * bx; out[1] = ay * bw + az * bx; out[2] = az * bw - ay * bx; out[3] = aw * bw - ax * bx;
+        return out;
+    },
+    rotateY(out, a, rad) {
+        rad *= 0.5;
+        const ax = a[0], ay = a[1], az = a[2], aw = a[3], by = Math.sin(rad), bw = Math.cos(rad);
+        out[0] = ax * bw - az * by; out[1] = ay * bw + aw * by; out[2] = az * bw + ax * by; out[3] = aw * bw - ay * by;
         return out;
     },
     setAxisAngle(out, axis, rad) {

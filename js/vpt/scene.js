@@ -30,6 +30,12 @@ get localMatrix() {
     return mat4.fromRotationTranslationScale(mat4.create(), this._localRotation, this._localTranslation, this._localScale);
 }
 
+get globalTranslation() {                                                          // Transform.js:35-37
+    const m = this.globalMatrix, out = vec3.create();
+    out[0] = m[12]; out[1] = m[13]; out[2] = m[14];
+    return out;
+}
+
 get globalMatrix() {
     const parent = this.node ? this.node.parent : null;
     if (parent) {

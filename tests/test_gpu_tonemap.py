@@ -256,6 +256,46 @@ def test_record_animation_to_image_sequence(gpu_ctx, oracle, tmp_path):
     rc.destroy()
 
 
+def test_orbit_camera_turntable_through_rendering_context(gpu_ctx, oracle):
+    """the context's default animator is an OrbitCameraAnimator (RenderingContext.js:54); a scripted drag / wheel / WASD
+    sequence moves the camera, every move resets the renderer (:42-46), and each frame equals the oracle's for that pose"""
+    from vpt_amd.readers import RAWReader
+    from vpt_amd.scene import mvp_inverse_matrix
+    vol = sphere_volume(24, noise=30.0)
+    rc = vpt_amd.RenderingContext({'resolution': (80, 60), 'rng': GoldenRatioRng()})
+    assert isinstance(rc.cameraAnimator, vpt_amd.OrbitCameraAnimator) and rc.cameraAnimator._focusDistance == 2.0
+    rc.setVolume(RAWReader(vol, {'width': 24, 'height': 24, 'depth': 24}))
+    rc.chooseRenderer('mip'); rc.chooseToneMapper('range')
+    rc.renderer.steps = 30
+    clock = [0.0]
+    orbit = rc.cameraAnimator
+    orbit.now = lambda: clock[0]; orbit._time = 0.0
+    osc = oracle.OracleScene(vol, 'linear')
+    script = [lambda: (orbit._handlePointerDown({'button': 0}), orbit._handlePointerMove({'movementX': 60, 'movementY': -25})),
+              lambda: orbit._handlePointerMove({'movementX': -140, 'movementY': 80}),
+              lambda: (orbit._handlePointerUp(), orbit._handleWheel({'deltaY': -300})),
+              lambda: (orbit._handleKeyDown({'key': 'a'}), clock.__setitem__(0, clock[0] + 120), orbit._update(), orbit._handleKeyUp({'key': 'a'}))]
+    poses = set()
+    for k, act in enumerate(script):
+        rc.render()
+        before = rc.renderer.read(N.BUFFER_ACCUM).copy()
+        act()                                                       # camera 'change' -> renderer.reset()
+        assert (rc.renderer.read(N.BUFFER_ACCUM) == 0).all() and before.any()
+        rng_probe = GoldenRatioRng()
+        rc.renderer.rng = GoldenRatioRng()                          # restart the jitter sequence: the oracle below starts from draw 1
+        o = oracle.OracleRenderer('mip', osc, 80, 60)
+        m = mvp_inverse_matrix(rc.camera, rc.volumeTransform)
+        o.reset(oracle.make_frame(80, 60, m))
+        for _ in range(2):
+            rc.render()
+            o.render(oracle.make_frame(80, 60, m, steps=30, offset=np.float32(rng_probe())))
+        same(rc.renderer.getTexture().view(np.uint16), o.out.reshape(60, 80, 4), "orbit pose %d" % k)
+        same(rc.getFrame(), oracle.tonemap('range', rc.renderer.getTexture()), "orbit pose %d tone mapped" % k)
+        poses.add(tuple(rc.camera.transform.localTranslation.tolist()))
+    assert len(poses) == 4
+    rc.destroy()
+
+
 def test_tonemapper_survives_its_renderer(gpu_ctx, oracle):
     """destroying the bound renderer unbinds it: the tone mapper falls back to the white placeholder instead of reading freed memory"""
     gvol = vpt_amd.Volume.from_array(gpu_ctx, sphere_volume(16, noise=20.0), 'linear')

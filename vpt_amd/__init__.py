@@ -15,7 +15,7 @@ from .tonemappers import (AbstractToneMapper, ArtisticToneMapper, RangeToneMappe
                           Uncharted2ToneMapper, FilmicToneMapper, UnrealToneMapper, AcesToneMapper, LottesToneMapper,
                           UchimuraToneMapper, ToneMapperFactory)
 from .rendering_context import RenderingContext
-from .animators import CircleAnimator
+from .animators import CircleAnimator, OrbitCameraAnimator
 from ._native import VptError
 
 __all__ = [
@@ -25,5 +25,5 @@ __all__ = [
     'AbstractRenderer', 'MIPRenderer', 'EAMRenderer', 'MCSRenderer', 'MCMRenderer', 'ISORenderer', 'DepthRenderer', 'LAORenderer', 'DOSRenderer', 'RendererFactory', 'VptError',
     'AbstractToneMapper', 'ArtisticToneMapper', 'RangeToneMapper', 'ReinhardToneMapper', 'Reinhard2ToneMapper',
     'Uncharted2ToneMapper', 'FilmicToneMapper', 'UnrealToneMapper', 'AcesToneMapper', 'LottesToneMapper',
-    'UchimuraToneMapper', 'ToneMapperFactory', 'RenderingContext', 'CircleAnimator',
+    'UchimuraToneMapper', 'ToneMapperFactory', 'RenderingContext', 'CircleAnimator', 'OrbitCameraAnimator',
 ]

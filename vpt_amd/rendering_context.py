@@ -4,6 +4,7 @@ recording): where the reference blits the tone mapper's texture to the canvas (:
 """
 import numpy as np
 
+from .animators import OrbitCameraAnimator
 from .context import Context
 from .property_bag import EventTarget, CustomEvent
 from .renderers import RendererFactory
@@ -30,7 +31,7 @@ class RenderingContext(EventTarget):
         self.volumeTransform = Transform(Node())                                      # :57
         self.renderer = None
         self.toneMapper = None
-        self.cameraAnimator = None          # the reference installs an OrbitCameraAnimator (UI); assign a CircleAnimator to record
+        self.cameraAnimator = OrbitCameraAnimator(self.camera, None)                  # :54 (headless: no canvas to listen on)
         self.resize(*self._size())
 
     def _size(self):

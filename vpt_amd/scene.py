@@ -49,6 +49,29 @@ class vec3:
         return out
 
     @staticmethod
+    def add(out, a, b):
+        out[0], out[1], out[2] = float(a[0]) + float(b[0]), float(a[1]) + float(b[1]), float(a[2]) + float(b[2])
+        return out
+
+    @staticmethod
+    def distance(a, b):
+        """gl-matrix 3.4.1 vec3.distance: Math.hypot of the differences"""
+        return math.hypot(float(b[0]) - float(a[0]), float(b[1]) - float(a[1]), float(b[2]) - float(a[2]))
+
+    @staticmethod
+    def transformQuat(out, a, q):
+        """gl-matrix 3.4.1 vec3.transformQuat"""
+        qx, qy, qz, qw = (float(v) for v in q)
+        x, y, z = float(a[0]), float(a[1]), float(a[2])
+        uvx, uvy, uvz = qy * z - qz * y, qz * x - qx * z, qx * y - qy * x
+        uuvx, uuvy, uuvz = qy * uvz - qz * uvy, qz * uvx - qx * uvz, qx * uvy - qy * uvx
+        w2 = qw * 2
+        uvx *= w2; uvy *= w2; uvz *= w2
+        uuvx *= 2; uuvy *= 2; uuvz *= 2
+        out[0], out[1], out[2] = x + uvx + uuvx, y + uvy + uuvy, z + uvz + uuvz
+        return out
+
+    @staticmethod
     def cross(out, a, b):
         ax, ay, az = float(a[0]), float(a[1]), float(a[2])
         bx, by, bz = float(b[0]), float(b[1]), float(b[2])
@@ -92,6 +115,24 @@ class quat:
         rad = rad * 0.5
         s = math.sin(rad)
         out[0], out[1], out[2], out[3] = s * axis[0], s * axis[1], s * axis[2], math.cos(rad)
+        return out
+
+    @staticmethod
+    def rotateX(out, a, rad):
+        """gl-matrix 3.4.1 quat.rotateX"""
+        rad *= 0.5
+        ax, ay, az, aw = (float(v) for v in a)
+        bx, bw = math.sin(rad), math.cos(rad)
+        out[0], out[1], out[2], out[3] = ax * bw + aw * bx, ay * bw + az * bx, az * bw - ay * bx, aw * bw - ax * bx
+        return out
+
+    @staticmethod
+    def rotateY(out, a, rad):
+        """gl-matrix 3.4.1 quat.rotateY"""
+        rad *= 0.5
+        ax, ay, az, aw = (float(v) for v in a)
+        by, bw = math.sin(rad), math.cos(rad)
+        out[0], out[1], out[2], out[3] = ax * bw - az * by, ay * bw + aw * by, az * bw + ax * by, aw * bw - ay * by
         return out
 
     @staticmethod
@@ -332,6 +373,11 @@ class Transform(Component):
         self._localScale = vec3.clone(value)
         self.version += 1
         self.dispatchEvent(Event('change'))
+
+    @property
+    def globalTranslation(self):               # Transform.js:35-37 (mat4.getTranslation: elements 12..14)
+        m = self.globalMatrix
+        return _f32([float(m[12]), float(m[13]), float(m[14])])
 
     @property
     def localMatrix(self):
