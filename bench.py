@@ -53,6 +53,10 @@ def parse():
                          "auto = time both during the warm-up (rank 0 receives the frame either way) and keep the faster")
     ap.add_argument("--gather", default="native", choices=["native", "torch"],
                     help="frame gather for N > 1: 'native' = RCCL pipeline below the C ABI (vpt_gather_*), 'torch' = torch.distributed all_gather")
+    ap.add_argument("--safe-first", type=int, default=1,
+                    help="N > 1 with the native gather: measure over torch.distributed's all_gather first, then the native pipeline "
+                         "under --native-deadline; print the faster (or the first, if the native phase does not finish)")
+    ap.add_argument("--native-deadline", type=int, default=150, help="seconds the native gather phase may take (see --safe-first)")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
     return ap.parse_args()
 
@@ -135,6 +139,17 @@ def main():
     watchdog = threading.Timer(args.watchdog, _give_up)
     watchdog.daemon = True
     watchdog.start()
+    state = {"fallback": None, "make_line": None, "stream_gbs": None}
+
+    def _native_gave_up():
+        # the library's own RCCL pipeline did not finish its measurement in time: report the torch.distributed one
+        sys.stderr.write("bench.py: the native gather pipeline did not finish within %d s - reporting the torch.distributed measurement\n" % args.native_deadline)
+        sys.stderr.flush()
+        if int(os.environ.get("RANK", "0")) == 0 and state["fallback"] is not None and state["make_line"] is not None:
+            line = state["make_line"](state["fallback"])
+            line["config"]["note"] = "native RCCL gather pipeline timed out; torch.distributed all_gather measurement reported"
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        os._exit(0)
     lib_path = os.path.join(ROOT, "vpt_amd", "libvpt_hip.so")
     if not os.path.exists(lib_path):                       # git-ignored artefact: a bare checkout builds it (one rank, the others wait)
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -215,16 +230,68 @@ def main():
         fpl = args.frames_per_launch or 1             # measured: sequences do not beat frame-by-frame enqueue
         if fpl > 1 and native is None and use_dist:
             fpl = 1                                   # the torch.distributed gather is driven frame by frame
+        use_native = [native is not None]            # which gather pipeline the steps below drive
+
+        def make_line(res):
+            """the JSON line of one measurement (rank 0)"""
+            per_launch_samples = res["samples_local"] / max(args.steps, 1)
+            avg_ms = res["kernel_ms"] / res["launches"] if res["launches"] else res["dt"] / args.steps * 1e3
+            bps = B_ALG_MCM if args.renderer == "mcm" else 8.0
+            achieved = bps * per_launch_samples / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("%s_%d_%dx%d_n%d" % (args.renderer, args.volume, W, H, world))
+                except Exception:
+                    traffic = None
+            stream_gbs = state["stream_gbs"]
+            f = fpl if (res["native"] or not use_dist) else 1
+            if not use_dist:
+                par = "single GPU"
+            elif res["native"]:
+                par = "image rows sharded over %d GPU(s), per-frame RCCL %s (native pipeline below the C ABI)" % (
+                    world, ("gather to rank %d" % res["root"]) if res["root"] >= 0 else "all_gather")
+            else:
+                par = "image rows sharded over %d GPU(s), per-frame RCCL all_gather (torch.distributed pipeline)" % world
+            line = {
+                "metric": "volume samples/s, MCM %d^3 @ %dx%d" % (args.volume, W, H) if args.renderer == "mcm"
+                          else "volume samples/s, %s %d^3 @ %dx%d" % (args.renderer.upper(), args.volume, W, H),
+                "value": res["samples"] / res["dt_max"], "unit": "volume samples/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": res["dt_max"] / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%s renderer, synthetic %d^3 u8 volume (radial sphere + lattice noise), %dx%d, "
+                                       "default camera, default 2x1 transfer function, extinction %g, anisotropy 0, bounces 8, "
+                                       "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
+                           "parallelism": par,
+                           "gather_calibration": res["gather_choice"],
+                           "frames_per_launch": f, "hipgraph": bool(args.graph) and f > 1 and not res["native"] and not args.fused_passes,
+                           "fused_passes": bool(args.fused_passes) and f > 1,
+                           "samples_per_step": res["samples"] / args.steps},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                             "peak_measured_stream_read": stream_gbs,
+                             "frac_of_measured": (achieved / stream_gbs) if stream_gbs else None,
+                             "kernel": "k_mcm_integrate<fused render>" if args.renderer == "mcm" else "k_%s<fused>" % args.renderer,
+                             "kernel_avg_ms": avg_ms, "launches": res["launches"],
+                             "bytes_per_sample": bps},
+                "frame_check": res["ok"],
+            }
+            if "other_pipeline_ms_per_step" in res:
+                line["config"]["other_pipeline_ms_per_step"] = res["other_pipeline_ms_per_step"]
+            return line
+        state["make_line"] = make_line
 
         def step_many(n):
             """n frames by one native call: per-frame uniforms in a device table, optionally one hipGraph replay"""
-            if native is not None:
+            if use_native[0]:
                 native.play(n, fused=bool(args.fused_passes))   # no graph mode: graphs holding RCCL collectives are slower here (DESIGN.md section 7)
             else:
                 r.play(n, use_graph=bool(args.graph) and n == fpl, fused=bool(args.fused_passes))   # one cached graph: only full-size chunks replay it
 
         def step(k):
-            if native is not None:
+            if use_native[0]:
                 native.render()                      # kernel + async RCCL all_gather, one enqueue each, below the C ABI
                 return
             b = k & 1
@@ -234,7 +301,7 @@ def main():
             gather.gather(b)
 
         def drain():
-            if native is not None:
+            if use_native[0]:
                 native.synchronize()
             else:
                 gather.wait(0); gather.wait(1)
@@ -243,141 +310,133 @@ def main():
 
         def run_steps(nsteps):
             frames_done[0] += nsteps
-            if fpl <= 1:
+            f = fpl if (use_native[0] or not use_dist) else 1
+            if f <= 1:
                 for k in range(nsteps):
                     step(k)
                 return
             done = 0
             while done < nsteps:
-                n = min(fpl, nsteps - done)
+                n = min(f, nsteps - done)
                 if n == 1:
                     step(done)
                 else:
                     step_many(n)
                 done += n
 
-        r.set_profiling(args.profile_kernel)          # before the warm-up so that a captured graph carries its timing events
-        warm = args.warmup
-        gather_choice = None
-        if native is not None and args.gather_root == "auto":
-            # which exchange is faster on this node is a property of RCCL's p2p and collective paths: measure both
-            trial = {}
-            for root in (0, -1):
-                native.set_root(root)
-                run_steps(8); drain(); dist.barrier(); torch.cuda.synchronize()
-                t_ = time.perf_counter()
-                run_steps(40); drain(); torch.cuda.synchronize()
-                tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=device)
-                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-                trial[root] = float(tt_[0]) / 40
-            best = min(trial, key=trial.get)
-            native.set_root(best)
-            gather_choice = {"chosen_root": best, "ms_per_frame_root0": trial[0] * 1e3, "ms_per_frame_all_gather": trial[-1] * 1e3}
-        run_steps(warm)                               # the first frame sequence runs eagerly (lazy allocations) ...
-        if fpl > 1:
-            run_steps(2 * fpl)                        # ... the next ones capture and replay the graph, outside the timed region
-        drain()
-        torch.cuda.synchronize()
-        r.clear_sample_count()
-        r.set_profiling(args.profile_kernel)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        drain()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        kernel_ms, launches = r.profile()
-        r.set_profiling(False)
+        def measure():
+            """W warm-up steps, then EXACTLY K timed steps between barriers; max over ranks; the gathered frame checked"""
+            res = {"native": use_native[0], "gather_choice": None}
+            r.set_profiling(args.profile_kernel)          # before the warm-up so that a captured graph carries its timing events
+            if use_native[0] and args.gather_root == "auto":
+                # which exchange is faster on this node is a property of RCCL's p2p and collective paths: measure both
+                trial = {}
+                for root in (0, -1):
+                    native.set_root(root)
+                    run_steps(8); drain(); dist.barrier(); torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    run_steps(40); drain(); torch.cuda.synchronize()
+                    tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=device)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    trial[root] = float(tt_[0]) / 40
+                best = min(trial, key=trial.get)
+                native.set_root(best)
+                res["gather_choice"] = {"chosen_root": best, "ms_per_frame_root0": trial[0] * 1e3, "ms_per_frame_all_gather": trial[-1] * 1e3}
+            run_steps(args.warmup)                        # the first frame sequence runs eagerly (lazy allocations) ...
+            if fpl > 1 and (use_native[0] or not use_dist):
+                run_steps(2 * fpl)                        # ... the next ones capture and replay the graph, outside the timed region
+            drain()
+            torch.cuda.synchronize()
+            r.clear_sample_count()
+            r.set_profiling(args.profile_kernel)
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            drain()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["dt"] = dt
+            res["kernel_ms"], res["launches"] = r.profile()
+            r.set_profiling(False)
+            res["samples_local"] = r.sample_count()
+            tt = torch.tensor([dt, float(res["samples_local"])], dtype=torch.float64, device=device)
+            if use_dist:
+                tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+                res["dt_max"], res["samples"] = float(tmax[0]), float(tsum[1])
+            else:
+                res["dt_max"], res["samples"] = dt, float(res["samples_local"])
+            ok = True
+            if args.check and use_dist:
+                # the gathered frame must hold this rank's own rows unchanged
+                rows_np = r.global_rows()
+                valid_np = rows_np >= 0
+                if use_native[0]:
+                    if native.receives():
+                        frame = native.frame()                          # [H][W][4] float16 on the host
+                        own = r.read(N.BUFFER_RENDER)                   # the buffer the last frame was rendered into
+                        ok = bool((frame[rows_np[valid_np]].view(np.uint16) == own[valid_np].view(np.uint16)).all())
+                        ok = ok and bool(np.isfinite(frame.astype(np.float32)).all()) and bool((frame[..., 3] == 1).all())
+                        # and the whole frame, rendered again UNSHARDED on this GPU with the same per-frame draws, must be
+                        # bit-identical to what the ranks produced together (outside the timed region)
+                        o2 = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng(), 'fused': bool(args.fused)}
+                        whole = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, o2)
+                        if args.extinction is not None:
+                            whole.extinction = args.extinction
+                        whole.reset()
+                        for _ in range(frames_done[0]):
+                            whole.render()
+                        same = bool((whole.getTexture().view(np.uint16) == frame.view(np.uint16)).all())
+                        whole.destroy()
+                        ok = ok and same
+                else:
+                    b = (args.steps - 1) & 1
+                    frame = gather.frame(b)
+                    rows = torch.as_tensor(rows_np, device=device)
+                    valid = rows >= 0
+                    ok = bool(torch.equal(frame.index_select(0, rows[valid]), gather.send[b][valid]))
+            torch.cuda.synchronize()
+            res["ok"] = ok
+            res["root"] = native.root if use_native[0] else -1
+            return res
+
+        # N > 1 with the native pipeline: FIRST a complete measurement over torch.distributed's own all_gather (the
+        # well-trodden path), so that a result exists whatever the library's RCCL pipeline does on this node; THEN the
+        # native pipeline under a deadline.  The line printed is the faster of the two; if the native phase does not
+        # finish in time, the first measurement is printed instead and the run ends cleanly.
+        results = []
+        if use_dist and native is not None and args.safe_first and (world > 1 or args.safe_first > 1):
+            use_native[0] = False
+            results.append(measure())
+            state["fallback"] = results[0]
+            deadline = threading.Timer(args.native_deadline, _native_gave_up)
+            deadline.daemon = True
+            deadline.start()
+            use_native[0] = True
+            results.append(measure())
+            deadline.cancel()
+            state["fallback"] = None
+        else:
+            results.append(measure())
+        res = min(results, key=lambda x: x["dt_max"])
+        if len(results) > 1:
+            res["other_pipeline_ms_per_step"] = [x["dt_max"] / args.steps * 1e3 for x in results if x is not res][0]
         stream_gbs = None
         if rank == 0 and args.stream_probe:
             try:
                 stream_gbs = ctx.stream_read_rate(4 << 30, 10)      # 4 GiB: far beyond the 256 MB Infinity Cache
             except Exception:                                       # reporting only
                 stream_gbs = None
-        samples_local = r.sample_count()
+        state["stream_gbs"] = stream_gbs
 
-        tt = torch.tensor([dt, float(samples_local)], dtype=torch.float64, device=device)
-        if use_dist:
-            tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-            dt_max, samples = float(tmax[0]), float(tsum[1])
-        else:
-            dt_max, samples = dt, float(samples_local)
-
-        ok = True
-        if args.check and use_dist:
-            # the gathered frame must hold this rank's own rows unchanged
-            rows_np = r.global_rows()
-            valid_np = rows_np >= 0
-            if native is not None:
-                if native.receives():
-                    frame = native.frame()                          # [H][W][4] float16 on the host
-                    own = r.read(N.BUFFER_RENDER)                   # the buffer the last frame was rendered into
-                    ok = bool((frame[rows_np[valid_np]].view(np.uint16) == own[valid_np].view(np.uint16)).all())
-                    ok = ok and bool(np.isfinite(frame.astype(np.float32)).all()) and bool((frame[..., 3] == 1).all())
-                    # and the whole frame, rendered again UNSHARDED on this GPU with the same per-frame draws, must be
-                    # bit-identical to what the ranks produced together (outside the timed region)
-                    o2 = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng(), 'fused': bool(args.fused)}
-                    whole = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, o2)
-                    if args.extinction is not None:
-                        whole.extinction = args.extinction
-                    whole.reset()
-                    for _ in range(frames_done[0]):
-                        whole.render()
-                    same = bool((whole.getTexture().view(np.uint16) == frame.view(np.uint16)).all())
-                    whole.destroy()
-                    ok = ok and same
-            else:
-                b = (args.steps - 1) & 1
-                frame = gather.frame(b)
-                rows = torch.as_tensor(rows_np, device=device)
-                valid = rows >= 0
-                ok = bool(torch.equal(frame.index_select(0, rows[valid]), gather.send[b][valid]))
-        torch.cuda.synchronize()
-
+    ok = res["ok"]
     if rank == 0:
-        per_launch_samples = samples_local / max(args.steps, 1)
-        avg_ms = kernel_ms / launches if launches else dt / args.steps * 1e3
-        achieved = (B_ALG_MCM if args.renderer == "mcm" else 8.0) * per_launch_samples / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                t = json.load(open(tpath))
-                key = "%s_%d_%dx%d_n%d" % (args.renderer, args.volume, W, H, world)
-                traffic = t.get(key)
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "volume samples/s, MCM %d^3 @ %dx%d" % (args.volume, W, H) if args.renderer == "mcm"
-                      else "volume samples/s, %s %d^3 @ %dx%d" % (args.renderer.upper(), args.volume, W, H),
-            "value": samples / dt_max, "unit": "volume samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s renderer, synthetic %d^3 u8 volume (radial sphere + lattice noise), %dx%d, "
-                                   "default camera, default 2x1 transfer function, extinction %g, anisotropy 0, bounces 8, "
-                                   "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
-                       "parallelism": ("image rows sharded over %d GPU(s), per-frame RCCL %s (%s pipeline)" % (
-                           world, ("gather to rank %d" % native.root) if (native is not None and native.root >= 0) else "all_gather", args.gather)) if use_dist else "single GPU",
-                       "gather_calibration": gather_choice,
-                       "frames_per_launch": fpl, "hipgraph": bool(args.graph) and fpl > 1 and native is None and not args.fused_passes,
-                       "fused_passes": bool(args.fused_passes) and fpl > 1,
-                       "samples_per_step": samples / args.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "peak_measured_stream_read": stream_gbs,
-                         "frac_of_measured": (achieved / stream_gbs) if stream_gbs else None,
-                         "kernel": "k_mcm_integrate<fused render>" if args.renderer == "mcm" else "k_%s<fused>" % args.renderer,
-                         "kernel_avg_ms": avg_ms, "launches": launches,
-                         "bytes_per_sample": B_ALG_MCM if args.renderer == "mcm" else 8.0},
-            "frame_check": ok,
-        }
+        out = make_line(res)
         if world == 1 and args.cpu_baseline and args.renderer == "mcm":
             try:
                 out["cpu_baseline"] = cpu_baseline(vol, args, r._matrix(), None)
