@@ -4,6 +4,7 @@ progressive sweep over several render() calls, REPEAT wrap of the occlusion taps
 Parity unpinned by the reference itself: it holds no output fixture for this renderer."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -170,7 +171,7 @@ def test_dos_full_size_oracle(gpu_ctx, oracle):
     r.destroy(); sc.gvol.destroy()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(*[int(v) for v in os.environ.get("VPT_FUZZ_SEEDS", "0:24").split(":")]))
 def test_dos_random_scene(gpu_ctx, oracle, seed):
     """the random scenes of test_gpu_fuzz.py (image / volume shapes down to 1, RG8, NEAREST, cameras inside, outside and
     looking away, scaled / rotated models, 2-D transfer functions) swept by the DOS renderer"""

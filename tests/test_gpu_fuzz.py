@@ -3,6 +3,7 @@ cameras (outside, inside, grazing, looking away), transfer functions (1..256 wid
 filters and renderer parameters (zero extinction, zero bounces, one step, strong anisotropy ...), several frames
 each — every buffer of every pass must equal the CPU oracle bit for bit.  Seeds are fixed: the cases never change."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -83,8 +84,12 @@ def random_case(seed):
     return rng, vol, (w, h), tf, env, filt, model
 
 
+# VPT_FUZZ_SEEDS=a:b widens the sweep (e.g. 40:400); the default 40 seeds keep the suite short
+_SEEDS = range(*[int(v) for v in os.environ.get("VPT_FUZZ_SEEDS", "0:40").split(":")])
+
+
 @pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_random_scene(gpu_ctx, oracle, kind, seed):
     rng, vol, (w, h), tf, env, filt, model = random_case(seed * 6 + KINDS.index(kind) if kind != "lao" else 5000 + seed)
     camera = random_camera(rng, w / h)
