@@ -148,8 +148,8 @@ VPT_API int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u);
  * share; frame_vars holds count x 8 floats {rand_seed, offset, mix, 0, light.x, light.y, light.z, 0} — the uniforms
  * that change per frame.  mode VPT_PLAY_EAGER: count launches with the per-frame uniforms in their arguments.
  * VPT_PLAY_GRAPH: the launch sequence is captured once into a hipGraph and replayed (uniforms from a device table read
- * through a device-side frame counter).  VPT_PLAY_FUSED (all renderers but ISO): ONE launch runs all `count` passes
- * of a pixel back to back with the photon state (MCM) or the accumulator (MIP, EAM, MCS, Depth) in registers — no
+ * through a device-side frame counter).  VPT_PLAY_FUSED (MIP, EAM, MCS, MCM, ISO, Depth): ONE launch runs all `count` passes
+ * of a pixel back to back with the photon state (MCM) or the accumulator (MIP, EAM, MCS, ISO, Depth) in registers — no
  * round trip through HBM between passes.  In every mode the buffers afterwards are identical to `count` calls of
  * vpt_renderer_render. */
 #define VPT_PLAY_EAGER 0

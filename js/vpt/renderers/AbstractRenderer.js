@@ -106,7 +106,7 @@ getTexture() {
 }
 
 // extension: `count` render() passes by one native call.  mode: native().VPT_PLAY_EAGER | _GRAPH | _FUSED (one launch,
-// state / accumulator in registers between passes; not ISO).  The per-frame draws are taken exactly as render() would.
+// state / accumulator in registers between passes; not LAO / DOS).  The per-frame draws are taken exactly as render() would.
 play(count, mode) {
     this._bindVolume();
     const vars = new Float32Array(8 * count);

@@ -525,9 +525,6 @@ def test_play_frame_sequences_equal_render_calls(gpu_ctx, oracle, kind):
         fusedr.play(2, use_graph=True); ref.render(); ref.render()          # the graph path's device frame counter stayed in step
         assert_same_bits(fusedr.read(buf), ref.read(buf), "graph replay after fused passes")
         fusedr.destroy()
-    elif kind == "iso":
-        with pytest.raises(vpt_amd.VptError, match="not implemented for the ISO renderer"):
-            eager.play(2, fused=True)
     else:
         fusedr = make()
         fusedr.play(4, fused=True); fusedr.play(1, fused=True); fusedr.render(); fusedr.play(4, fused=True)

@@ -898,7 +898,6 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
         g->ran = true;
     } else if (use_graph == VPT_PLAY_FUSED && r->kind != VPT_RENDERER_MCM) {
         // the accumulating renderers: the pass loop lives in their fused kernels (PassArgs.multi_passes)
-        if (r->kind == VPT_RENDERER_ISO) return fail(VPT_ERR_UNSUPPORTED, "fused passes are not implemented for the ISO renderer");
         if (r->kind == VPT_RENDERER_LAO) return fail(VPT_ERR_UNSUPPORTED, "fused passes are pointless for the LAO renderer: its frames do not accumulate");
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
         a.multi_passes = (uint32_t)count;
