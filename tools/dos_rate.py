@@ -22,15 +22,17 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--sweeps", type=int, default=5)
+    ap.add_argument("--filter", default="linear", choices=["linear", "nearest"])
+    ap.add_argument("--extinction", type=float, default=100.0)
     args = ap.parse_args()
     import vpt_amd
     from vpt_amd.scene import default_camera, Transform, Node
     from vpt_amd.synthetic import sphere_volume, GoldenRatioRng
     W, H = args.width, args.height
     ctx = vpt_amd.Context(0)
-    vol = vpt_amd.Volume.from_array(ctx, sphere_volume(args.volume, noise=40.0), 'linear')
+    vol = vpt_amd.Volume.from_array(ctx, sphere_volume(args.volume, noise=40.0), args.filter)
     r = vpt_amd.DOSRenderer(ctx, vol, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
-    r.slices = args.slices; r.steps = args.steps; r.samples = args.samples
+    r.slices = args.slices; r.steps = args.steps; r.samples = args.samples; r.extinction = args.extinction
     r.generateOcclusionSamples()
 
     def sweep():

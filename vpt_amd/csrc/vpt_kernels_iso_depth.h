@@ -313,49 +313,58 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_lao_integrate(PassArgs a) {
 // (RGBA32F, own texel: st0, in place) and occlusion (R32F, LINEAR / REPEAT: neighbour reads, hence separate in / out buffers
 // st2 / st3 and ROW-MAJOR layout instead of the tile order of the other renderers) and writes the next ones (DOSRenderer.js:240-259)
 // =============================================================================================
-// LINEAR / REPEAT tap pair; contract: a coordinate that is NaN or beyond 1e9 texels reads texel 0 (oracle repeat_coord)
-VPT_DEV void repeat_taps(float s, int n, int &i0, int &i1, float &f) {
-    float u = fmaf(s, (float)n, -0.5f);
+// LINEAR / REPEAT tap pair at texel coordinate u = s*n - 0.5; contract: a coordinate that is NaN or beyond 1e9 texels reads
+// texel 0 (oracle repeat_coord)
+VPT_DEV void repeat_taps_u(float u, int n, int &i0, int &i1, float &f) {
     if (!(fabsf(u) < 1.0e9f)) u = 0.0f;
     float fl = floorf(u);
     f = u - fl;
-    int i = (int)fl % n;
-    if (i < 0) i += n;
+    int i = (int)fl;
+    if ((unsigned)i >= (unsigned)n) {           // outside the image: wrap (an integer division, ~40 instructions — kept off the common path)
+        i %= n;
+        if (i < 0) i += n;
+    }
     i0 = i; i1 = (i + 1 == n) ? 0 : i + 1;
-}
-VPT_DEV float sample_occlusion(const float *occ, int w, int h, float s, float t) {
-    int x0, x1, y0, y1; float fx, fy;
-    repeat_taps(s, w, x0, x1, fx);
-    repeat_taps(t, h, y0, y1, fy);
-    float a = lerpf(occ[(size_t)y0 * w + x0], occ[(size_t)y0 * w + x1], fx);
-    float b = lerpf(occ[(size_t)y1 * w + x0], occ[(size_t)y1 * w + x1], fx);
-    return lerpf(a, b, fy);
 }
 // integrate/fragment main(): DOSRenderer.glsl:73-89; vertex :17-23 (vPosition3D = the unprojected (position, uDepth))
 template <int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_dos_slice(PassArgs a) {
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     // plain 2-D grid over the tiles of the launch rectangle (row-major buffers: no tile order, no XCD interleave to keep)
     const DosParams &d = a.dos;
     Pix p;
     p.i = (d.tile_x0 + (int)blockIdx.x) * VPT_TILE + ((int)threadIdx.x & (VPT_TILE - 1));
     p.j = (d.tile_y0 + (int)blockIdx.y) * VPT_TILE + ((int)threadIdx.x / VPT_TILE);
     p.valid = p.i < a.pm.W && p.j < a.pm.H;
+    const int W = a.pm.W, H = a.pm.H;
+    const size_t k = (size_t)p.j * W + p.i;
+    const float *occ_in = (const float *)a.st2;
+    float px = 0.0f, py = 0.0f, prev_occ = 0.0f;
+    float4 prev = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    f3 pos = { -1.0f, -1.0f, -1.0f };
+    bool in_volume = false;
+    if (p.valid) {
+        px = ndc_col(a.pm, p.i); py = ndc_row(a.pm, p.j);
+        prev_occ = occ_in[k];
+        prev = a.st0[k];                          // in flight together with the occlusion texel (both come from beyond the L2 after a kernel boundary)
+        pos = dehomogenize(mat4_mul_point(a.mvp_inv, px, py, d.depth));
+        in_volume = !(pos.x > 1.0f || pos.y > 1.0f || pos.z > 1.0f || pos.x < 0.0f || pos.y < 0.0f || pos.z < 0.0f);
+    }
+    // a tile the slice does not touch copies its occlusion and is done: no table staging, no sampling (at either end of the
+    // sweep that is every tile of the rectangle)
+    if (!__syncthreads_or(in_volume)) {
+        if (p.valid) ((float *)a.st3)[k] = prev_occ;
+        return;
+    }
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     uint32_t ns = 0;
     if (p.valid) {
-        const int W = a.pm.W, H = a.pm.H;
-        const size_t k = (size_t)p.j * W + p.i;
-        const float *occ_in = (const float *)a.st2;
-        float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
-        float prev_occ = occ_in[k];
-        f3 pos = dehomogenize(mat4_mul_point(a.mvp_inv, px, py, d.depth));
         float oo = prev_occ;
         // a pixel outside the volume keeps its colour: the colour buffer is updated IN PLACE (a pass reads only the
         // pixel's own colour texel, so the reference's ping-pong is not needed for it), and such pixels — most of the
         // image with the default camera — move 8 bytes instead of 40
-        if (!(pos.x > 1.0f || pos.y > 1.0f || pos.z > 1.0f || pos.x < 0.0f || pos.y < 0.0f || pos.z < 0.0f)) {
-            float4 prev = a.st0[k], oc;
+        if (in_volume) {
+            float4 oc;
             float4 ts = sample_volume_color<V>(a, t, pos);
             ns = 1;
             float ext = ts.w * a.extinction;
@@ -368,12 +377,20 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_dos_slice(PassArgs a) {
             oc.w = vmin(prev.w + alpha, 1.0f);
             float uvx = ndc_to_uv(px), uvy = ndc_to_uv(py);
             float o = 0.0f;                                        // calculateOcclusion: :61-70
-            for (int q = 0; q < d.nsamples; q++) {
+            const float fW = (float)W, fH = (float)H;
+#pragma unroll 4
+            for (int q = 0; q < d.nsamples; q++) {                 // (a batch of 8 taps in flight costs 126 VGPRs and half the waves: slower)
                 float2 off = d.samples[q];
-                o += sample_occlusion(occ_in, W, H, uvx + off.x * d.scale_x, uvy + off.y * d.scale_y);
+                int x0, x1, y0, y1; float fx, fy;
+                repeat_taps_u(fmaf(uvx + off.x * d.scale_x, fW, -0.5f), W, x0, x1, fx);
+                repeat_taps_u(fmaf(uvy + off.y * d.scale_y, fH, -0.5f), H, y0, y1, fy);
+                o += lerpf(lerpf(occ_in[(size_t)y0 * W + x0], occ_in[(size_t)y0 * W + x1], fx),
+                           lerpf(occ_in[(size_t)y1 * W + x0], occ_in[(size_t)y1 * W + x1], fx), fy);
             }
             oo = (o / (float)d.nsamples) * e;
-            a.st0[k] = oc;
+            // an opaque pixel (prev.a == 1) gets its old colour back bit for bit: the store is skipped then
+            if (__float_as_uint(oc.x) != __float_as_uint(prev.x) || __float_as_uint(oc.y) != __float_as_uint(prev.y) ||
+                __float_as_uint(oc.z) != __float_as_uint(prev.z) || __float_as_uint(oc.w) != __float_as_uint(prev.w)) a.st0[k] = oc;
         }
         ((float *)a.st3)[k] = oo;
     }
