@@ -190,6 +190,23 @@ def test_full_size_tonemap(gpu_ctx, oracle):
         tm.destroy()
 
 
+def test_large_frame_lds_table_form(gpu_ctx, oracle):
+    """3328x2048 (6.8 Mpixel): from 6 Mpixel on the byte table is applied from LDS; whole frame == the direct form, a band
+    == the oracle, for the table-with-alpha mapper (range) and two of the others"""
+    w, h = 3328, 2048
+    img = hdr_image(w, h, seed=21)
+    for kind in ('range', 'reinhard', 'uchimura'):
+        tm = vpt_amd.ToneMapperFactory(kind)(gpu_ctx, img, {'resolution': (w, h)})
+        tm.render()
+        out = tm.getTexture()
+        same(out[1000:1008], oracle.tonemap(kind, img[1000:1008]), "%s rows 1000..1008" % kind)
+        same(out[-2:], oracle.tonemap(kind, img[-2:]), "%s last rows" % kind)
+        tm.set_option(N.TONEMAPPER_OPTION_TABLE, N.TONEMAPPER_TABLE_NEVER)
+        tm.render()
+        same(tm.getTexture(), out, "%s direct vs LDS table over the whole frame" % kind)
+        tm.destroy()
+
+
 def test_rendering_context_sequence(gpu_ctx, oracle):
     """the caller's sequence (RenderingContext.js:123-133,152-210,216-229): setVolume -> chooseRenderer -> chooseToneMapper ->
     N x render(), resolution change, renderer / tone mapper swaps, filter change — the frame equals the oracle chain"""

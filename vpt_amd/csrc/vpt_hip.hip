@@ -1302,6 +1302,23 @@ static void launch_tonemap(vpt_tonemapper *t, const uint2 *src, size_t n, const 
         else hipLaunchKernelGGL(k_tonemap_table<KIND>, dim3(256), dim3(256), 0, t->ctx->stream, t->table, p);
         t->table_params = p; t->table_valid = true;
     }
+    const size_t lds_table = ((VPT_TM_TABLE_ENTRIES + 15) / 16) * 16;
+    // table in LDS: up to 2 workgroups of 1024 per CU, grid-stride, >= 4 texels per thread (the global-memory forms below
+    // remain as the fallback should the 64 KiB of dynamic LDS be refused)
+    const size_t wgs = std::min<size_t>(512, (n + 4095) / 4096);
+    if (KIND != VPT_TM_ARTISTIC) {
+        auto k = (KIND == VPT_TM_RANGE) ? k_tonemap_apply_table_lds<true> : k_tonemap_apply_table_lds<false>;
+        if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_table) == hipSuccess) {
+            hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3(1024), lds_table, t->ctx->stream, src, t->out, n, t->table);
+            return;
+        }
+        (void)hipGetLastError();
+    } else if (hipFuncSetAttribute((const void *)k_tonemap_apply_table_artistic_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_table) == hipSuccess) {
+        hipLaunchKernelGGL(k_tonemap_apply_table_artistic_lds, dim3((unsigned)wgs), dim3(1024), lds_table, t->ctx->stream, src, t->out, n, t->table, p);
+        return;
+    } else {
+        (void)hipGetLastError();
+    }
     if (KIND == VPT_TM_ARTISTIC) hipLaunchKernelGGL(k_tonemap_apply_table_artistic, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, t->table, p);
     else if (KIND == VPT_TM_RANGE) hipLaunchKernelGGL(k_tonemap_apply_table<true>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, t->table);
     else hipLaunchKernelGGL(k_tonemap_apply_table<false>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, t->table);

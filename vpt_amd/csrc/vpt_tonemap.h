@@ -162,6 +162,55 @@ __global__ void __launch_bounds__(256) k_tonemap_apply_table(const uint2 *src, u
         dst[i] = r | (g << 8) | (b << 16) | a;
     }
 }
+// the same with the byte table copied into LDS first (64 KiB + 4 B per workgroup, two workgroups per CU): pays from about
+// 6 Mpixel on, where the global-memory form is bound by the texture path's byte gathers rather than by the image stream
+template <bool ALPHA_FROM_TABLE>
+__global__ void __launch_bounds__(1024) k_tonemap_apply_table_lds(const uint2 *src, uint32_t *dst, size_t n, const uint8_t *table) {
+    extern __shared__ uint32_t tm_lds[];
+    const uint4 *t4 = (const uint4 *)table;                     // the table allocation is padded to a multiple of 16 bytes
+    for (int i = threadIdx.x; i < (VPT_TM_TABLE_ENTRIES + 15) / 16; i += 1024) ((uint4 *)tm_lds)[i] = t4[i];
+    __syncthreads();
+    const uint8_t *lt = (const uint8_t *)tm_lds;
+    uint32_t alpha = (uint32_t)lt[65536] << 24;
+    const size_t stride = (size_t)gridDim.x * 1024;
+    for (size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint2 t[4];                                              // four texels in flight per thread
+#pragma unroll
+        for (int u = 0; u < 4; u++) { size_t i = i0 + (size_t)u * stride; t[u] = i < n ? src[i] : make_uint2(0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            size_t i = i0 + (size_t)u * stride;
+            uint32_t r = lt[t[u].x & 0xffffu], g = lt[t[u].x >> 16], b = lt[t[u].y & 0xffffu];
+            uint32_t a = ALPHA_FROM_TABLE ? ((uint32_t)lt[t[u].y >> 16] << 24) : alpha;
+            if (i < n) dst[i] = r | (g << 8) | (b << 16) | a;
+        }
+    }
+}
+// Artistic at saturation 1 with the table in LDS (k_tonemap_apply_table_artistic's arithmetic)
+__global__ void __launch_bounds__(1024) k_tonemap_apply_table_artistic_lds(const uint2 *src, uint32_t *dst, size_t n, const uint8_t *table, TonemapParams p) {
+    extern __shared__ uint32_t tm_lds[];
+    const uint4 *t4 = (const uint4 *)table;
+    for (int i = threadIdx.x; i < (VPT_TM_TABLE_ENTRIES + 15) / 16; i += 1024) ((uint4 *)tm_lds)[i] = t4[i];
+    __syncthreads();
+    const uint8_t *lt = (const uint8_t *)tm_lds;
+    const float range = p.high - p.low;
+    const size_t stride = (size_t)gridDim.x * 1024;
+    for (size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint2 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { size_t i = i0 + (size_t)u * stride; t[u] = i < n ? src[i] : make_uint2(0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            size_t i = i0 + (size_t)u * stride;
+            float4 c = half4_to_float4(t[u]);
+            f3 v = { (c.x - p.low) / range, (c.y - p.low) / range, (c.z - p.low) / range };
+            const float gray = 0.57735026918962576f;
+            float z = (dot3(v, f3{ gray, gray, gray }) * gray) * (1.0f - p.saturation);     // g * 0: a signed zero, or NaN
+            uint32_t rgb = (uint32_t)lt[t[u].x & 0xffffu] | ((uint32_t)lt[t[u].x >> 16] << 8) | ((uint32_t)lt[t[u].y & 0xffffu] << 16);
+            if (i < n) dst[i] = ((z == 0.0f) ? rgb : 0u) | 0xff000000u;
+        }
+    }
+}
 
 // n texels, grid-stride; src RGBA16F, dst RGBA8 (both row-major, same pixel order)
 template <int KIND>
