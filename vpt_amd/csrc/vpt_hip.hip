@@ -266,7 +266,7 @@ extern "C" int vpt_volume_finalize(vpt_volume *v) {
     HIP_TRY(hipSetDevice(c->device));
     int nbx = (v->nx + 3) / 4, nby = (v->ny + 3) / 4, nbz = (v->nz + 3) / 4;
     if (nby > 65535 || nbz > 65535) return fail(VPT_ERR_UNSUPPORTED, "too many bricks");
-    hipLaunchKernelGGL(k_brickify, dim3((unsigned)nbx, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->channels, v->tabc);
+    hipLaunchKernelGGL(k_brickify, dim3((unsigned)((nbx + VPT_BRICKIFY_RUN - 1) / VPT_BRICKIFY_RUN), (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->channels, v->tabc);
     HIP_TRY(hipGetLastError());
     v->dirty = false;
     return VPT_OK;
