@@ -114,7 +114,9 @@ def test_rng_and_half_probes(gpu_ctx, oracle):
     assert (goth == f.astype(np.float16).view(np.uint16)).all()
 
 
-@pytest.mark.parametrize("dims", [(32, 32, 32), (17, 23, 9), (4, 4, 4), (1, 1, 1), (5, 64, 3)])
+# the last two: rows of 196 and 128 voxels take the LDS-staged strip re-layout for their first 3 / 1 strips and the generic one
+# for the strip holding the last column; 68 = one whole strip plus 4 voxels
+@pytest.mark.parametrize("dims", [(32, 32, 32), (17, 23, 9), (4, 4, 4), (1, 1, 1), (5, 64, 3), (7, 13, 196), (6, 5, 128), (3, 9, 68)])
 @pytest.mark.parametrize("filt", ["linear", "nearest"])
 def test_volume_sampler_and_transfer_function(gpu_ctx, oracle, dims, filt):
     """texture(uVolume,p) -> texture(uTransferFunction,(r,0)): bricked Z-order + LDS TF vs linear volume + 2D bilinear"""

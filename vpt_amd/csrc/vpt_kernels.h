@@ -908,7 +908,7 @@ __global__ void k_blit_block(uint8_t *vol, int nx, int ny, const uint8_t *blk, i
 // a workgroup re-lays VPT_BRICKIFY_RUN consecutive bricks of a brick row (one brick per workgroup: 2^21 tiny workgroups for
 // 512^3, 0.74 ms = 0.5 TB/s, bound by workgroup launches)
 #define VPT_BRICKIFY_RUN 16
-__global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, int ch, const uint32_t *codes) {
+__global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, int ch, const uint32_t *codes, int first_brick) {
     const int by = (int)blockIdx.y, bz = (int)blockIdx.z;
     const int t = (int)threadIdx.x;
     const int nbx = (nx + VPT_BRICK - 1) / VPT_BRICK;
@@ -916,7 +916,7 @@ __global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *b
     const int y = min(by * VPT_BRICK + ly, ny - 1), z = min(bz * VPT_BRICK + lz, nz - 1);
     const size_t row = ((size_t)z * ny + y) * nx;
     const uint32_t cyz = codes[nx + 4 * by] + codes[nx + ny + 4 * bz];
-    const int bx0 = (int)blockIdx.x * VPT_BRICKIFY_RUN;
+    const int bx0 = first_brick + (int)blockIdx.x * VPT_BRICKIFY_RUN;
     for (int c = 0; c < ch; c++) {
         uint8_t v[VPT_BRICKIFY_RUN];
 #pragma unroll
@@ -933,6 +933,38 @@ __global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *b
                 bricks[slot + (size_t)c * 128 + t] = v[u];
             }
         }
+    }
+}
+
+// The same re-layout for one-channel volumes whose rows are dword-aligned (nx % 4 == 0), staged through LDS: a workgroup
+// takes a strip of 16 bricks along x (64 voxels + the apron column) — 25 source rows of 17 dwords, loaded as dwords —
+// and writes the 16 brick slots as dwords (4 LDS byte reads each).  The strip that holds the volume's last column, where
+// the apron replicates voxel nx-1, is left to k_brickify (launched on that strip only).
+__global__ void __launch_bounds__(256) k_brickify_strip(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, const uint32_t *codes) {
+    __shared__ uint32_t rows[25][17];
+    const int by = (int)blockIdx.y, bz = (int)blockIdx.z, t = (int)threadIdx.x;
+    const int x0 = (int)blockIdx.x * (VPT_BRICK * VPT_BRICKIFY_RUN);                 // multiple of 64; x0 + 64 < nx guaranteed by the launch
+    for (int q = t; q < 25 * 17; q += 256) {
+        int r = q / 17, d = q - r * 17;
+        int y = min(by * VPT_BRICK + (r % 5), ny - 1), z = min(bz * VPT_BRICK + (r / 5), nz - 1);
+        rows[r][d] = *(const uint32_t *)(lin + ((size_t)z * ny + y) * nx + x0 + 4 * d);
+    }
+    __syncthreads();
+    const uint8_t *lb = (const uint8_t *)rows;
+    const uint32_t cyz = codes[nx + 4 * by] + codes[nx + ny + 4 * bz];
+    for (int q = t; q < VPT_BRICKIFY_RUN * 32; q += 256) {
+        int u = q >> 5, w = q & 31;                          // brick u of the strip, dword w of its slot (bytes 4w .. 4w+3)
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int b = 4 * w + k;                               // byte b of the brick = voxel (lx, ly, lz), b = lx + 5 ly + 25 lz; 125..127 are padding
+            if (b < 125) {
+                int lz = b / 25, rem = b - 25 * lz, ly = rem / 5, lx = rem - 5 * ly;
+                out |= (uint32_t)lb[(lz * 5 + ly) * 68 + 4 * u + lx] << (8 * k);
+            }
+        }
+        size_t slot = (size_t)(codes[x0 + 4 * u] + cyz) << 7;
+        *(uint32_t *)(bricks + slot + 4 * w) = out;
     }
 }
 
