@@ -53,8 +53,8 @@ extern "C" {
 
 /* Buffers readable through vpt_renderer_read (SingleBuffer.js / DoubleBuffer.js attachments) */
 #define VPT_BUFFER_RENDER 0      /* RGBA16F, 8 B/pixel  (AbstractRenderer.js:142-155, getTexture() :114-116) */
-#define VPT_BUFFER_FRAME  1      /* MIP R8 | EAM RGBA8 | MCS RGBA32F | ISO RGBA16F | Depth R32F  (_getFrameBufferSpec) */
-#define VPT_BUFFER_ACCUM  2      /* same formats  (_getAccumulationBufferSpec, read side) */
+#define VPT_BUFFER_FRAME  1      /* MIP R8 | EAM, LAO RGBA8 | MCS RGBA32F | ISO RGBA16F | Depth R32F  (_getFrameBufferSpec); none for MCM, DOS */
+#define VPT_BUFFER_ACCUM  2      /* same formats; DOS: its RGBA32F colour attachment  (_getAccumulationBufferSpec, read side) */
 #define VPT_BUFFER_MCM_POSITION      3   /* RGBA32F [pos.xyz, 0]            (MCMRenderer.js:214-263) */
 #define VPT_BUFFER_MCM_DIRECTION     4   /* RGBA32F [dir.xyz, bounces]      */
 #define VPT_BUFFER_MCM_TRANSMITTANCE 5   /* RGBA32F [transmittance.rgb, 0]  */
