@@ -810,8 +810,8 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
         uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
         if (lin < a.stagger_blocks) {
             uint32_t g = a.stagger_pattern ? ((lin >> 3) & 3u) : ((lin >> 8) & 3u);
-            uint64_t until = wall_clock64() + (uint64_t)g * a.stagger_ticks;          // 100 MHz constant clock
-            while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+            uint64_t until = (uint64_t)wall_clock64() + (uint64_t)g * a.stagger_ticks;          // 100 MHz constant clock
+            while ((uint64_t)wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
         }
     }
     apply_frame_table(a);
