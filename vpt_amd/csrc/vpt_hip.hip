@@ -267,10 +267,10 @@ extern "C" int vpt_volume_finalize(vpt_volume *v) {
     int nbx = (v->nx + 3) / 4, nby = (v->ny + 3) / 4, nbz = (v->nz + 3) / 4;
     if (nby > 65535 || nbz > 65535) return fail(VPT_ERR_UNSUPPORTED, "too many bricks");
     const int strips = (nbx + VPT_BRICKIFY_RUN - 1) / VPT_BRICKIFY_RUN;
-    // strips whose 65 source columns all exist go through the LDS-staged kernel (dword loads and stores)
-    int fast = (v->channels == 1 && v->nx % 4 == 0) ? (v->nx - 1) / (VPT_BRICK * VPT_BRICKIFY_RUN) : 0;      // strips with x0 + 64 <= nx - 1
+    // one-channel volumes with dword-aligned rows go through the LDS-staged kernel (dword loads and stores)
+    int fast = (v->channels == 1 && v->nx % 4 == 0) ? strips : 0;
     if (fast > 0)
-        hipLaunchKernelGGL(k_brickify_strip, dim3((unsigned)fast, (unsigned)nby, (unsigned)nbz), dim3(256), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->tabc);
+        hipLaunchKernelGGL(k_brickify_strip, dim3((unsigned)fast, (unsigned)((nby + VPT_BRICKIFY_ROWS - 1) / VPT_BRICKIFY_ROWS), (unsigned)nbz), dim3(256), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->tabc);
     if (fast < strips)
         hipLaunchKernelGGL(k_brickify, dim3((unsigned)(strips - fast), (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->channels, v->tabc, fast * VPT_BRICKIFY_RUN);
     HIP_TRY(hipGetLastError());

@@ -942,32 +942,38 @@ __global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *b
 
 // The same re-layout for one-channel volumes whose rows are dword-aligned (nx % 4 == 0), staged through LDS: a workgroup
 // takes a strip of 16 bricks along x (64 voxels + the apron column) — 25 source rows of 17 dwords, loaded as dwords —
-// and writes the 16 brick slots as dwords (4 LDS byte reads each).  The strip that holds the volume's last column, where
-// the apron replicates voxel nx-1, is left to k_brickify (launched on that strip only).
+// and writes the brick slots as dwords (4 LDS byte reads each).
+#define VPT_BRICKIFY_ROWS 4       // brick rows (in y) per workgroup of k_brickify_strip: 16 x 4 bricks, 17 source rows per z slice
 __global__ void __launch_bounds__(256) k_brickify_strip(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, const uint32_t *codes) {
-    __shared__ uint32_t rows[25][17];
-    const int by = (int)blockIdx.y, bz = (int)blockIdx.z, t = (int)threadIdx.x;
-    const int x0 = (int)blockIdx.x * (VPT_BRICK * VPT_BRICKIFY_RUN);                 // multiple of 64; x0 + 64 < nx guaranteed by the launch
-    for (int q = t; q < 25 * 17; q += 256) {
+    constexpr int NR = VPT_BRICK * VPT_BRICKIFY_ROWS + 1;                             // 17 voxel rows incl. the apron row
+    __shared__ uint32_t rows[5 * NR][17];
+    const int by0 = (int)blockIdx.y * VPT_BRICKIFY_ROWS, bz = (int)blockIdx.z, t = (int)threadIdx.x;
+    const int nby = (ny + VPT_BRICK - 1) / VPT_BRICK;
+    const int x0 = (int)blockIdx.x * (VPT_BRICK * VPT_BRICKIFY_RUN);                 // multiple of 64; nx % 4 == 0 guaranteed by the launch
+    for (int q = t; q < 5 * NR * 17; q += 256) {
         int r = q / 17, d = q - r * 17;
-        int y = min(by * VPT_BRICK + (r % 5), ny - 1), z = min(bz * VPT_BRICK + (r / 5), nz - 1);
-        rows[r][d] = *(const uint32_t *)(lin + ((size_t)z * ny + y) * nx + x0 + 4 * d);
+        int y = min(by0 * VPT_BRICK + (r % NR), ny - 1), z = min(bz * VPT_BRICK + (r / NR), nz - 1);
+        const uint8_t *row = lin + ((size_t)z * ny + y) * nx;
+        // past the row's end (the apron of the last brick column, the unused tail of a partial strip): voxel nx-1 replicated
+        rows[r][d] = (x0 + 4 * d < nx) ? *(const uint32_t *)(row + x0 + 4 * d) : (uint32_t)row[nx - 1] * 0x01010101u;
     }
     __syncthreads();
     const uint8_t *lb = (const uint8_t *)rows;
-    const uint32_t cyz = codes[nx + 4 * by] + codes[nx + ny + 4 * bz];
-    for (int q = t; q < VPT_BRICKIFY_RUN * 32; q += 256) {
-        int u = q >> 5, w = q & 31;                          // brick u of the strip, dword w of its slot (bytes 4w .. 4w+3)
+    const uint32_t cz = codes[nx + ny + 4 * bz];
+    for (int q = t; q < VPT_BRICKIFY_RUN * VPT_BRICKIFY_ROWS * 32; q += 256) {
+        int u = q >> 5, w = q & 31;                          // brick u of the 16 x 4 block, dword w of its slot (bytes 4w .. 4w+3)
+        int ux = u & (VPT_BRICKIFY_RUN - 1), uy = u / VPT_BRICKIFY_RUN;
+        if (by0 + uy >= nby || x0 + 4 * ux >= nx) continue;
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int b = 4 * w + k;                               // byte b of the brick = voxel (lx, ly, lz), b = lx + 5 ly + 25 lz; 125..127 are padding
             if (b < 125) {
                 int lz = b / 25, rem = b - 25 * lz, ly = rem / 5, lx = rem - 5 * ly;
-                out |= (uint32_t)lb[(lz * 5 + ly) * 68 + 4 * u + lx] << (8 * k);
+                out |= (uint32_t)lb[(lz * NR + VPT_BRICK * uy + ly) * 68 + 4 * ux + lx] << (8 * k);
             }
         }
-        size_t slot = (size_t)(codes[x0 + 4 * u] + cyz) << 7;
+        size_t slot = (size_t)(codes[x0 + 4 * ux] + codes[nx + 4 * (by0 + uy)] + cz) << 7;
         *(uint32_t *)(bricks + slot + 4 * w) = out;
     }
 }
