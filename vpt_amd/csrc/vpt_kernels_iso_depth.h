@@ -203,8 +203,12 @@ VPT_DEV f2 lao_rand(float px, float py) {
     return f2{ ax - floorf(ax), ay - floorf(ay) };
 }
 // generate/fragment main(): LAORenderer.glsl:97-191; vLight (:25) = (M^-1 * (uLightPosition, 1)).xyz, no divide
+// pow(1 - u, 2) of the occlusion march depends on the tap index alone (u = 0.001, += uLAOStepSize in fp32): a workgroup
+// evaluates the first LAO_POW_TABLE of them once into LDS instead of a log + exp per tap (about a third of the kernel's
+// instructions); taps beyond the table (a step below 1/256) evaluate it in place.
+#define LAO_POW_TABLE 256
 template <int V>
-VPT_DEV uint32_t lao_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns) {
+VPT_DEV uint32_t lao_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, uint32_t &ns, const float *pow_table) {
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     f3 rf, rt;
     unproject(px, py, a.mvp_inv, rf, rt);
@@ -236,14 +240,15 @@ VPT_DEV uint32_t lao_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, 
             if (lp.local_ambient_occlusion) {
                 float acc = 0.0f;                                         // accumuLAOContribution: not reset between samples
                 for (int samp = 0; samp < lp.num_lao_samples; samp++) {
-                    for (float u = 0.001f; u < 1.0f; u += lp.lao_step_size) {
+                    int tap = 0;
+                    for (float u = 0.001f; u < 1.0f; u += lp.lao_step_size, tap++) {
                         float rc = -1.0f + 2.0f * R;
                         f3 rd = normalize3(f3{ rc, rc, rc });
                         rd = f3{ rd.x * R, rd.y * R, rd.z * R };
                         float m = mixf(0.0f, lp.light_radius, u);
                         f3 hv = normalize3(f3{ (vl.x + rd.x * m) - pos.x, (vl.y + rd.y * m) - pos.y, (vl.z + rd.z * m) - pos.z });
                         f3 sp = { pos.x + hv.x * u, pos.y + hv.y * u, pos.z + hv.z * u };
-                        acc += sample_volume<V>(a.vol, t, sp) * vpt_powf(1.0f - u, 2.0f);
+                        acc += sample_volume<V>(a.vol, t, sp) * (tap < LAO_POW_TABLE ? pow_table[tap] : vpt_powf(1.0f - u, 2.0f));
                         ns++;
                         if (!(lp.lao_step_size > 0.0f)) break;             // a zero step would never end: one sample then
                     }
@@ -289,11 +294,17 @@ VPT_DEV uint32_t lao_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, 
 template <int MODE, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_lao(PassArgs a) {
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    __shared__ float pow_table[LAO_POW_TABLE];
+    if (threadIdx.x < 64) {                                   // lane l evaluates taps l, l + 64, ...: every lane walks the same u chain
+        int tap = 0;
+        for (float u = 0.001f; u < 1.0f && tap < LAO_POW_TABLE; u += a.lao.lao_step_size, tap++)
+            if ((tap & 63) == (int)threadIdx.x) pow_table[tap] = vpt_powf(1.0f - u, 2.0f);
+    }
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);      // (its barrier also publishes pow_table)
     Pix p = map_pixel(a.pm);
     uint32_t ns = 0;
     if (p.valid) {
-        uint32_t q = lao_pixel<V>(a, t, p, ns);
+        uint32_t q = lao_pixel<V>(a, t, p, ns, pow_table);
         if (MODE == 0) {
             ((uint32_t *)a.frame)[p.k] = q;
         } else {
