@@ -260,14 +260,14 @@ VPT_DEV uint32_t lao_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, 
             }
             if (lp.soft_shadows) {
                 float acc = 0.0f;
-                for (int samp = 0; samp < lp.num_shadow_samples; samp++) {
-                    f3 rd = normalize3(f3{ -1.0f + vl.x * R, vl.y + R * vl.z, -1.0f + 2.0f * rs });
-                    rd = f3{ rd.x * R, rd.y * R, rd.z * R };
-                    f3 sp = { pos.x + rd.x * lp.light_radius, pos.y + rd.y * lp.light_radius, pos.z + rd.z * lp.light_radius };
-                    float v1 = sample_volume<V>(a.vol, t, sp);             // the shader samples this position twice
-                    acc += (v1 * (v1 * 0.2f)) * vpt_powf(length3(rd), 1.0f);
-                    ns += 2;
-                }
+                // every shadow "sample" of the shader is the same one (its random direction is a per-pixel constant): the
+                // position is fetched once (the shader samples it twice per iteration — counted) and the loop only accumulates
+                f3 rd = normalize3(f3{ -1.0f + vl.x * R, vl.y + R * vl.z, -1.0f + 2.0f * rs });
+                rd = f3{ rd.x * R, rd.y * R, rd.z * R };
+                f3 sp = { pos.x + rd.x * lp.light_radius, pos.y + rd.y * lp.light_radius, pos.z + rd.z * lp.light_radius };
+                const float v1 = sample_volume<V>(a.vol, t, sp);
+                const float term = (v1 * (v1 * 0.2f)) * vpt_powf(length3(rd), 1.0f);
+                for (int samp = 0; samp < lp.num_shadow_samples; samp++) { acc += term; ns += 2; }
                 acc = vpt_powf(acc, 1.0f);
                 acc /= (float)lp.num_shadow_samples;
                 acc *= 20.0f;
