@@ -71,7 +71,7 @@ VPT_DEV uint2 iso_shade(const PassArgs &a, const LdsTables &t, uint2 closest, ui
 }
 // MODE 0: _generateFrame only.  MODE 1: the whole render(): generate, integrate, renderFrame in one pass.
 template <int MODE, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) k_iso(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_iso(PassArgs a) {
     if (a.multi_passes > 1u) multi_pass_select(a, *a.frame_counter, 0); else apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
