@@ -32,7 +32,7 @@ extern "C" {
 #define VPT_ERR_NO_VOLUME   -3   /* renderer has no (ready) volume: Volume.getTexture() == null, Volume.js:107-113 */
 #define VPT_ERR_UNSUPPORTED -4
 
-/* RendererFactory.js:10-23 ('mip' | 'eam' | 'mcs' | 'mcm'; the other names are out of scope) */
+/* RendererFactory.js:10-23: all eight names ('mip' | 'iso' | 'eam' | 'lao' | 'mcs' | 'mcm' | 'dos' | 'depth') */
 #define VPT_RENDERER_MIP 0
 #define VPT_RENDERER_EAM 1
 #define VPT_RENDERER_MCS 2
@@ -172,11 +172,6 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * segments (LDS tables staged once per workgroup), 2 = the same with the next segment's photon state prefetched under
  * the current segment's events.  Measured 4-8 % slower than one workgroup per tile (register pressure), kept as options. */
 #define VPT_OPTION_MCM_PERSISTENT 1
-/* VPT_OPTION_MCM_STAGGER: phase staggering of the MCM integrate kernel (timing only, results identical).  value =
- * quantum in 10 ns ticks (bits 0..23) | pattern << 24; the workgroups resident at launch start g * quantum late
- * (g = 0..3), which takes the chip's waves out of lockstep so that photon-state streaming overlaps event compute
- * (DESIGN.md section 5).  0 = off. */
-#define VPT_OPTION_MCM_STAGGER 2
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
 /* the LAO renderer's own uniforms (gl.uniform* calls of LAORenderer.js:159-169; uStepSize and uExtinction travel in
  * vpt_uniforms); defaults are the reference's property defaults (LAORenderer.js:17-108) */

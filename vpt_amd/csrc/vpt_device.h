@@ -357,8 +357,14 @@ VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
         l1 = __builtin_amdgcn_alignbyte(q1.b, q1.a, s1); h1 = __builtin_amdgcn_alignbyte(q1.c, q1.b, s1);
     } else {
         uint64_t w0, w1;
+#if defined(VPT_X) && (VPT_X & 8)
+        typedef uint64_t u64_any __attribute__((aligned(1)));
+        w0 = __builtin_nontemporal_load((const u64_any *)a);
+        w1 = __builtin_nontemporal_load((const u64_any *)(a + 25));
+#else
         __builtin_memcpy(&w0, a, 8);
         __builtin_memcpy(&w1, a + 25, 8);
+#endif
         l0 = (uint32_t)w0; h0 = (uint32_t)(w0 >> 32); l1 = (uint32_t)w1; h1 = (uint32_t)(w1 >> 32);
     }
     float c000 = (float)(l0 & 0xffu), c100 = (float)((l0 >> 8) & 0xffu);

@@ -87,7 +87,6 @@ struct vpt_renderer {
     float2 *dos_samples; int dos_nsamples;   // DOS: uOcclusionSamples (vpt_renderer_set_occlusion_samples)
     int dos_rect[4]; bool dos_rect_valid;   // DOS: tile rectangle [x0, y0, x1, y1) of the previous integrate call (see dos_tile_rect)
     int dos_cur;                   // DOS: which of the occlusion buffers st[2|3] holds the latest slice (colour: st[0], in place)
-    int mcm_stagger;               // VPT_OPTION_MCM_STAGGER: phase-stagger quantum (10 ns ticks) | pattern << 24; 0 = off
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
@@ -421,7 +420,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->ndc_x = r->ndc_y = nullptr;
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
-    r->mcm_stagger = 0; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -526,8 +525,6 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         a->isovalue = u->isovalue; a->gradient_step = u->gradient_step; a->threshold = u->threshold;
     }
     if (r->kind == VPT_RENDERER_LAO) a->lao = r->lao;
-    a->stagger_ticks = (uint32_t)(r->mcm_stagger & 0xffffff); a->stagger_pattern = (uint32_t)(r->mcm_stagger >> 24) & 1u;
-    a->stagger_blocks = 256u * 7u;                  // the workgroups resident at launch: 256 CUs x 7 (28 waves per CU)
     a->inv_w = (float)(1.0 / (double)r->W);     // gl.uniform2f(uInverseResolution, 1/res, 1/res): MCMRenderer.js:91,155
     a->inv_h = (float)(1.0 / (double)r->H);
     a->frame = r->frame; a->acc = r->acc;
@@ -1114,7 +1111,6 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
     switch (option) {
         case VPT_OPTION_MCS_PERSISTENT: r->mcs_persistent = value != 0; return VPT_OK;
         case VPT_OPTION_MCM_PERSISTENT: r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
-        case VPT_OPTION_MCM_STAGGER: r->mcm_stagger = value < 0 ? 0 : value; return VPT_OK;
         default: return fail(VPT_ERR_INVALID, "unknown option %d", option);
     }
 }

@@ -91,7 +91,6 @@ struct PassArgs {
     f3 light;
     float mix, blur, inv_w, inv_h;
     float isovalue, gradient_step, threshold;   // ISO / Depth (vpt_kernels_iso_depth.h)
-    uint32_t stagger_ticks, stagger_blocks, stagger_pattern;   // MCM phase staggering (k_mcm_integrate), 0 = off
     union {
         LaoParams lao;           // LAO renderer (vpt_kernels_iso_depth.h)
         DosParams dos;           // DOS renderer: one slice (vpt_kernels_iso_depth.h)
@@ -664,6 +663,24 @@ VPT_DEV void reset_photon(uint32_t &state, Photon &ph, float px, float py, const
     ph.position = madd3(from, tnear, ph.direction);
     ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
 }
+// the same with the first two uniforms (the disk sample's) already drawn by the caller
+VPT_DEV void reset_photon_drawn(uint32_t &state, float u1, float u2, Photon &ph, float px, float py, const PassArgs &a, f3 from0) {
+    f3 from = from0, to;
+    if (a.blur != 0.0f) {
+        float radius = sqrt_nr(u1), angle = 6.28318530718f * u2, sn, cs;
+        vpt_sincosf(angle, sn, cs);
+        from = dehomogenize(mat4_mul_point(a.mvp_inv, px + (radius * cs) * a.blur, py + (radius * sn) * a.blur, -1.0f));
+    }
+    float sx = random_uniform(state), sy = random_uniform(state);
+    float ax = fmaf(sx, 2.0f, -1.0f) * a.inv_w;
+    float ay = fmaf(sy, 2.0f, -1.0f) * a.inv_h;
+    to = dehomogenize(mat4_mul_point(a.mvp_inv, px + ax, py + ay, 1.0f));
+    ph.direction = normalize3(sub3(to, from));
+    ph.bounces = 0u;
+    float tnear = vmax(intersect_cube_near(from, ph.direction), 0.0f);
+    ph.position = madd3(from, tnear, ph.direction);
+    ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
+}
 // sampleHenyeyGreensteinAngleCosine: MCMRenderer.glsl:91-95
 VPT_DEV float hg_cos(uint32_t &state, float g) {
     float g2 = g * g;
@@ -680,6 +697,21 @@ VPT_DEV f3 sample_hg(uint32_t &state, float g, f3 dir) {
     c = normalize3(c);
     float s = sqrt_nr(fmaf(-hgcos, hgcos, 1.0f));
     return f3{ fmaf(s, c.x, hgcos * dir.x), fmaf(s, c.y, hgcos * dir.y), fmaf(s, c.z, hgcos * dir.z) };
+}
+VPT_DEV f3 sample_hg_drawn(uint32_t &state, float u1, float u2, float g, f3 dir) {
+    float radius0 = sqrt_nr(u1), angle = 6.28318530718f * u2, sn, cs;
+    vpt_sincosf(angle, sn, cs);
+    f2 d = { radius0 * cs, radius0 * sn };
+    float norm = fmaf(d.y, d.y, d.x * d.x);
+    float radius = 2.0f * sqrt_nr(1.0f - norm);
+    f3 u = { radius * d.x, radius * d.y, fmaf(-2.0f, norm, 1.0f) };
+    if (fabsf(g) < 1e-5f) return u;
+    float hgcos = hg_cos(state, g);
+    float ud = dot3(u, dir);
+    f3 c = { fmaf(-ud, dir.x, u.x), fmaf(-ud, dir.y, u.y), fmaf(-ud, dir.z, u.z) };
+    c = normalize3(c);
+    float sq = sqrt_nr(fmaf(-hgcos, hgcos, 1.0f));
+    return f3{ fmaf(sq, c.x, hgcos * dir.x), fmaf(sq, c.y, hgcos * dir.y), fmaf(sq, c.z, hgcos * dir.z) };
 }
 // radiance += (rad - radiance) / float(samples)   (MCMRenderer.glsl:147-150,154-157), as * (1/n)
 VPT_DEV void photon_deposit(Photon &ph, f3 rad) {
@@ -710,8 +742,12 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
 }
 
 // the `steps` delta-tracking events of one pixel on its persistent photon: MCMRenderer.glsl:128-166
-template <int V>
+#ifndef VPT_X
+#define VPT_X 0            // experiment bits (A/B builds only; the shipped library is built with the default)
+#endif
+template <int V0>
 VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
+    constexpr int V = V0 | ((VPT_X & 4) ? VPT_V_ALIGNED : 0);
     const f3 from0 = unproject_near(px, py, a);
 
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
@@ -726,6 +762,29 @@ VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float
         f3 q = ph.position;
         // any(greaterThan(pos, 1)) || any(lessThan(pos, 0)), NaN components compare false
         bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+#if VPT_X & 2
+        // Both non-null outcomes start by drawing two uniforms (resetPhoton -> unprojectRand's disk sample, scattering ->
+        // the sphere sample's disk): drawn ONCE for the lanes of either outcome, so a wave whose lanes split between the
+        // two pays for two PCG rounds instead of four.  Same draws in the same order per lane: results unchanged.
+        bool fin = oob || wheel < p_abs;
+        bool sct = !fin && wheel < p_abs + p_scat;
+        if (fin || sct) {
+            float u1 = random_uniform(state), u2 = random_uniform(state);
+            if (fin) {
+                f3 rad = { 0.0f, 0.0f, 0.0f };
+                if (oob) {
+                    float4 env = sample_environment(a.env, ph.direction);
+                    rad = f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z };
+                }
+                photon_deposit(ph, rad);
+                reset_photon_drawn(state, u1, u2, ph, px, py, a, from0);
+            } else {
+                ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
+                ph.direction = sample_hg_drawn(state, u1, u2, a.anisotropy, ph.direction);
+                ph.bounces++;
+            }
+        }
+#else
         if (oob || wheel < p_abs) {
             // out of bounds: radiance = transmittance * env; absorption: radiance = 0 — one shared deposit + resetPhoton
             f3 rad = { 0.0f, 0.0f, 0.0f };
@@ -740,6 +799,7 @@ VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float
             ph.direction = sample_hg(state, a.anisotropy, ph.direction);
             ph.bounces++;
         }
+#endif
     }
 }
 VPT_DEV Photon photon_unpack(float4 s0, float4 s1, float4 s2, float4 s3) {   // MCMRenderer.glsl:117-126
@@ -801,40 +861,17 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
 template <bool FUSE_RENDER, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_integrate(PassArgs a) {
-    // Phase staggering.  Every wave of this kernel does load-state -> `steps` events -> store-state and takes the same
-    // time, so the resident waves of the whole chip run in lockstep: all load (HBM saturated, VALU idle), then all
-    // compute (HBM idle); measured frame time = stream time + compute time (42 us + 12 us * steps), no overlap.
-    // Delaying the first-round workgroups by g * quantum (g = 0..3) offsets the phases of four groups of waves; later
-    // workgroups inherit the offset because a slot is refilled when its workgroup retires.  Timing only: results unchanged.
-    if (a.stagger_ticks) {
-        uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin < a.stagger_blocks) {
-            uint32_t g = a.stagger_pattern ? ((lin >> 3) & 3u) : ((lin >> 8) & 3u);
-            uint64_t until = (uint64_t)wall_clock64() + (uint64_t)g * a.stagger_ticks;          // 100 MHz constant clock
-            while ((uint64_t)wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     apply_frame_table(a);
-#if defined(VPT_EXP) && VPT_EXP == 1
-    return;                                               // experiment: launch cost only
-#endif
+    // the photon state (4 x dwordx4 per lane, one contiguous 1 KiB segment per wave and array) does not depend on the LDS
+    // image: its loads are issued first, so they fly while the workgroup stages the tables and hashes its seed
+    Pix p = map_pixel(a.pm);
+    float4 s0, s1, s2, s3;
+    if (p.tile) { s0 = a.st0[p.k]; s1 = a.st1[p.k]; s2 = a.st2[p.k]; s3 = a.st3[p.k]; }
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
-    Pix p = map_pixel(a.pm);
     if (!p.valid) return;
-#if defined(VPT_EXP) && VPT_EXP == 2
-    if (a.steps == 12345u) a.st0[p.k] = make_float4(t.tf[0].x, 0, 0, 0);   // experiment: launch + LDS staging only
-    return;
-#endif
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
-    float4 s0 = a.st0[p.k], s1 = a.st1[p.k], s2 = a.st2[p.k], s3 = a.st3[p.k];
-    Photon ph;
-    ph.position = f3{ s0.x, s0.y, s0.z };
-    ph.direction = f3{ s1.x, s1.y, s1.z };
-    ph.bounces = (uint32_t)(s1.w + 0.5f);
-    ph.transmittance = f3{ s2.x, s2.y, s2.z };
-    ph.radiance = f3{ s3.x, s3.y, s3.z };
-    ph.samples = (uint32_t)(s3.w + 0.5f);
+    Photon ph = photon_unpack(s0, s1, s2, s3);
     mcm_events<V>(a, t, ph, px, py);
     a.st0[p.k] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
     a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
