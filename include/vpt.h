@@ -172,6 +172,12 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * segments (LDS tables staged once per workgroup), 2 = the same with the next segment's photon state prefetched under
  * the current segment's events.  Measured 4-8 % slower than one workgroup per tile (register pressure), kept as options. */
 #define VPT_OPTION_MCM_PERSISTENT 1
+/* VPT_OPTION_FAST_MATH (default 0; MCM renderer): 1 = run the integrate pass with the arithmetic a GPU driver gives GLSL
+ * (v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 / v_log_f32 / v_sin_f32 / v_cos_f32, and algebraically equal shorter forms) instead of
+ * the software routines of the bit-exact contract.  Same integer PCG stream, same decisions except within rounding error;
+ * results are NOT bit-identical to the contract oracle: checked by first-event agreement and converged-image statistics
+ * (tolerance in DESIGN.md section 3).  The persistent-wave option has no fast variant (it takes precedence when set). */
+#define VPT_OPTION_FAST_MATH 2
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
 /* the LAO renderer's own uniforms (gl.uniform* calls of LAORenderer.js:159-169; uStepSize and uExtinction travel in
  * vpt_uniforms); defaults are the reference's property defaults (LAORenderer.js:17-108) */
@@ -301,6 +307,28 @@ VPT_API int vpt_gather_read_frame(vpt_gather *g, void *host_dst, size_t nbytes);
 VPT_API int vpt_probe_math(vpt_context *ctx, int which, const float *in, float *out, size_t n);
 /* samples texture(uVolume, p) -> transfer function at n positions (xyz triples); out = n RGBA float4 */
 VPT_API int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n);
+/* The schedule of frame number `frame` of the gather pipeline as a pure host function (no GPU, no communicator needed): ring
+ * buffer, event edges, render destination, RCCL operation.  vpt_gather_render / _play execute exactly this plan; exported so
+ * that the multi-rank schedule can be checked without more than one GPU (tests/test_gather_schedule.py). */
+#define VPT_GATHER_OP_NONE      0   /* one rank, rooted: nothing to exchange */
+#define VPT_GATHER_OP_ALLGATHER 1   /* root -1: ncclAllGather(send[buffer] -> recv[buffer]) */
+#define VPT_GATHER_OP_SEND      2   /* rooted, this rank is not the root: ncclSend(send[buffer]) to `peer` */
+#define VPT_GATHER_OP_RECV      3   /* rooted, this rank is the root: `npeers` grouped ncclRecv into recv[buffer] (vpt_gather_plan_recv) */
+typedef struct vpt_gather_step {
+    int      ring;             /* buffers in the ring */
+    int      buffer;           /* frame % ring */
+    int      parity;           /* which half of the ring: (frame / (ring / 2)) & 1 */
+    int      wait_gathered;    /* compute stream waits for gathered[parity] before the kernel (the half is re-entered) */
+    int      record_gathered;  /* communication stream records gathered[parity] after this frame's exchange */
+    int      rendered_event;   /* rendered[k]: kernel done -> the communication stream may start */
+    int      in_place;         /* the kernel renders into recv[buffer] + render_offset (root of a rooted gather) instead of send[buffer] */
+    int      op;               /* VPT_GATHER_OP_* */
+    int      peer;             /* SEND: destination rank */
+    int      npeers;           /* RECV: number of receives */
+    uint64_t render_offset;    /* byte offset of the kernel's output inside recv[buffer] when in_place */
+} vpt_gather_step;
+VPT_API int vpt_gather_plan(uint64_t frame, int rank, int world, int root, uint64_t send_bytes, vpt_gather_step *out);
+VPT_API int vpt_gather_plan_recv(const vpt_gather_step *step, int rank, int i, uint64_t send_bytes, int *peer, uint64_t *offset);
 /* the row re-assembly of a gathered frame (k_assemble_rows, used by vpt_gather_read_frame) run on host data:
  * gathered = [world][local_rows][width] RGBA16F as the ranks' send buffers arrive, out = [height][width].  Lets a
  * one-GPU box check the multi-rank assembly against an unsharded frame. */

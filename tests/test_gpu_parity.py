@@ -327,6 +327,15 @@ def test_native_rccl_gather_single_rank(gpu_ctx, oracle):
             assert_same_bits(g.frame(), plain.getTexture(), "gathered frame %d" % k)
     g.synchronize()
     assert_same_bits(shard.read(N.BUFFER_MCM_RADIANCE), plain.read(N.BUFFER_MCM_RADIANCE), "state after gather pipeline")
+    # a captured hipGraph that holds the RCCL exchange stays refused (slower per frame and an abort after ~50
+    # replays on ROCm 7.0 / RCCL 2.26): the call must fail with VPT_ERR_UNSUPPORTED and leave the pipeline usable
+    import ctypes as C
+    u, vars_ = shard._collect_frames(2)
+    plain._collect_frames(2)                          # keep the two renderers' per-frame draws in step
+    rc = N.lib().vpt_gather_play(g._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), 2, N.PLAY_GRAPH)
+    assert rc == N.ERR_UNSUPPORTED
+    g.render(); plain.render()
+    assert_same_bits(g.frame(), plain.getTexture(), "gathered frame after the refused graph request")
     g.destroy(); plain.destroy(); shard.destroy(); sc.gvol.destroy()
 
 

@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libvpt_hip.so")
 OK = 0
 OPTION_MCS_PERSISTENT = 0
 OPTION_MCM_PERSISTENT = 1
+OPTION_FAST_MATH = 2
 PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED = 0, 1, 2
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO, RENDERER_DOS = 0, 1, 2, 3, 4, 5, 6, 7
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
@@ -25,6 +26,7 @@ TONEMAPPER_OPTION_TABLE, TONEMAPPER_TABLE_NEVER, TONEMAPPER_TABLE_ALWAYS, TONEMA
 
 # every symbol include/vpt.h declares (tests check the library exports all of them)
 SYMBOLS = [
+    "vpt_gather_plan", "vpt_gather_plan_recv",
     "vpt_device_count", "vpt_context_create", "vpt_context_create_on_stream", "vpt_context_destroy", "vpt_context_synchronize",
     "vpt_last_error", "vpt_version",
     "vpt_volume_create", "vpt_volume_upload_block", "vpt_volume_upload_block_device", "vpt_volume_finalize",

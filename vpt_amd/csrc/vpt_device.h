@@ -191,7 +191,15 @@ VPT_DEV float vpt_asinf(float x) {
 
 // ---- RNG: mixins/random/hash/pcg.glsl:3-7, squashlinear.glsl:7-9, distribution/*.glsl ---------
 VPT_DEV uint32_t pcg(uint32_t x) {
+#if defined(VPT_X) && (VPT_X & 32)
+    {   // experiment: multiply-add in one instruction (64-bit result, the low dword is x * A + C mod 2^32)
+        uint64_t r, c = 2891336453ull;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(x), "s"(747796405u), "v"(c) : "vcc");
+        x = (uint32_t)r;
+    }
+#else
     x = x * 747796405u + 2891336453u;
+#endif
     x = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
     return (x >> 22u) ^ x;
 }
@@ -338,6 +346,7 @@ VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_
 #define VPT_V_WIDE    1
 #define VPT_V_NEAREST 2
 #define VPT_V_ALIGNED 4   // fetch the two tap windows as dword-aligned 12-byte loads + v_alignbyte (texture-path bound kernels)
+#define VPT_V_FAST    16  // MCM / MCS: hardware rcp / rsq / sqrt / log / sin / cos and shorter algebraic forms (no bit-exact CPU twin; VPT_OPTION_FAST_MATH)
 #define VPT_V_RG      8   // two-channel (RG8) volume: texture(uVolume, p).rg has both channels, the transfer function is looked up in 2-D
 // the eight taps around a cell of one channel's brick and their trilinear blend: taps +0,+1 (y,z) ; +5,+6 (y+1,z) ;
 // +25,+26 (y,z+1) ; +30,+31 (y+1,z+1) = two 8-byte windows of one line.
@@ -345,6 +354,14 @@ VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_
 // of the CU's texture path, a byte-aligned 8-byte one 2x that.  Kernels bound by that path (MIP, EAM: ~60 VALU
 // instructions per sample) fetch 12 aligned bytes per window and realign in registers (v_alignbyte_b32); the
 // VALU-bound MCM / MCS keep the two unaligned 8-byte loads (fewer instructions).
+template <int B> VPT_DEV float cvt_ubyte(uint32_t w) {
+    float r;
+    if (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(w));
+    else if (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(w));
+    else if (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(w));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(w));
+    return r;
+}
 template <int V>
 VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
     uint32_t l0, h0, l1, h1;
@@ -367,14 +384,47 @@ VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
 #endif
         l0 = (uint32_t)w0; h0 = (uint32_t)(w0 >> 32); l1 = (uint32_t)w1; h1 = (uint32_t)(w1 >> 32);
     }
-    float c000 = (float)(l0 & 0xffu), c100 = (float)((l0 >> 8) & 0xffu);
-    float c010 = (float)((h0 >> 8) & 0xffu), c110 = (float)((h0 >> 16) & 0xffu);
-    float c001 = (float)(l1 & 0xffu), c101 = (float)((l1 >> 8) & 0xffu);
-    float c011 = (float)((h1 >> 8) & 0xffu), c111 = (float)((h1 >> 16) & 0xffu);
+    // byte -> float straight out of the loaded dwords (v_cvt_f32_ubyteN: the byte select is free).  Written as opaque
+    // instructions: left to itself the compiler turns (float)b - (float)a into (float)(b - a) and spends 18 integer-class
+    // instructions (shifts, SDWA subtracts, two conversions per pair) where 8 conversions + 4 fp32 subtracts do —
+    // integer-class VALU instructions cost ~4.3 cycles per wave on this chip against ~2.6 for fp32 add/mul/fma
+    // (tools/valu_rates.hip).  Same values, same results.
+    float c000 = cvt_ubyte<0>(l0), c100 = cvt_ubyte<1>(l0);
+    float c010 = cvt_ubyte<1>(h0), c110 = cvt_ubyte<2>(h0);
+    float c001 = cvt_ubyte<0>(l1), c101 = cvt_ubyte<1>(l1);
+    float c011 = cvt_ubyte<1>(h1), c111 = cvt_ubyte<2>(h1);
     float c00 = lerpf(c000, c100, fx), c10 = lerpf(c010, c110, fx);
     float c01 = lerpf(c001, c101, fx), c11 = lerpf(c011, c111, fx);
     float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
     return lerpf(c0, c1, fz) * VPT_INV255;
+}
+// The same sample in two steps — fetch (cell, LDS table look-ups, the two global loads) and blend (conversions + lerps) — so
+// that a caller can put independent work between the loads and their first use (k: mcm_events speculates resetPhoton there).
+struct TapFetch { uint32_t l0, h0, l1, h1; float fx, fy, fz; };
+template <int V>
+VPT_DEV TapFetch fetch_taps(const DevVolume &v, const LdsTables &t, f3 p) {
+    static_assert((V & (VPT_V_NEAREST | VPT_V_ALIGNED | VPT_V_RG)) == 0, "LINEAR one-channel unaligned form only");
+    TapFetch f;
+    uint32_t x, y, z;
+    linear_cell(p.x, v.fnx, v.hx, x, f.fx);
+    linear_cell(p.y, v.fny, v.hy, y, f.fy);
+    linear_cell(p.z, v.fnz, v.hz, z, f.fz);
+    const uint8_t *a = cell_addr<(V & VPT_V_WIDE) != 0>(v, t, x, y, z);
+    uint64_t w0, w1;
+    __builtin_memcpy(&w0, a, 8);
+    __builtin_memcpy(&w1, a + 25, 8);
+    f.l0 = (uint32_t)w0; f.h0 = (uint32_t)(w0 >> 32); f.l1 = (uint32_t)w1; f.h1 = (uint32_t)(w1 >> 32);
+    return f;
+}
+VPT_DEV float blend_taps(const TapFetch &f) {
+    float c000 = cvt_ubyte<0>(f.l0), c100 = cvt_ubyte<1>(f.l0);
+    float c010 = cvt_ubyte<1>(f.h0), c110 = cvt_ubyte<2>(f.h0);
+    float c001 = cvt_ubyte<0>(f.l1), c101 = cvt_ubyte<1>(f.l1);
+    float c011 = cvt_ubyte<1>(f.h1), c111 = cvt_ubyte<2>(f.h1);
+    float c00 = lerpf(c000, c100, f.fx), c10 = lerpf(c010, c110, f.fx);
+    float c01 = lerpf(c001, c101, f.fx), c11 = lerpf(c011, c111, f.fx);
+    float c0 = lerpf(c00, c10, f.fy), c1 = lerpf(c01, c11, f.fy);
+    return lerpf(c0, c1, f.fz) * VPT_INV255;
 }
 // texture(uVolume, p).rg: r always, g only for RG8 volumes (V & VPT_V_RG; an R8 volume has g = 0).  The cell and its
 // brick address are computed once for both channels.

@@ -87,6 +87,7 @@ struct vpt_renderer {
     float2 *dos_samples; int dos_nsamples;   // DOS: uOcclusionSamples (vpt_renderer_set_occlusion_samples)
     int dos_rect[4]; bool dos_rect_valid;   // DOS: tile rectangle [x0, y0, x1, y1) of the previous integrate call (see dos_tile_rect)
     int dos_cur;                   // DOS: which of the occlusion buffers st[2|3] holds the latest slice (colour: st[0], in place)
+    int fast_math;                 // VPT_OPTION_FAST_MATH: MCM events with hardware rcp / rsq / log / sin / cos (k_mcm_integrate<.., V | VPT_V_FAST>)
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
@@ -420,7 +421,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->ndc_x = r->ndc_y = nullptr;
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
-    r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->fast_math = 0; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -592,6 +593,8 @@ static int variant_of(const vpt_renderer *r) {
 #define K_LAO1(V) (k_lao<1, V>)
 #define K_MCM0(V) (k_mcm_integrate<false, V>)
 #define K_MCM1(V) (k_mcm_integrate<true, V>)
+#define K_MCM0F(V) (k_mcm_integrate<false, V | VPT_V_FAST>)
+#define K_MCM1F(V) (k_mcm_integrate<true, V | VPT_V_FAST>)
 
 template <typename K>
 static int launch_mcs_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
@@ -731,7 +734,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_LAO: LAUNCH(k_lao_integrate, r, a, 0); break;
         case VPT_RENDERER_MCM: {
             Timed t(r, true);
-            if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(false, r, a); else LAUNCH_S(K_MCM0, r, a);
+            if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(false, r, a); else if (r->fast_math) LAUNCH_S(K_MCM0F, r, a); else LAUNCH_S(K_MCM0, r, a);
             r->samples_host += r->valid_pixels * (uint64_t)u->steps;   // exactly W*H*steps per pass (MCMRenderer.glsl:129-133)
         } break;
     }
@@ -767,7 +770,7 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
         case VPT_RENDERER_LAO: LAUNCH_S(K_LAO1, r, a); break;
         case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
         case VPT_RENDERER_MCM:
-            if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(true, r, a); else LAUNCH_S(K_MCM1, r, a);
+            if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(true, r, a); else if (r->fast_math) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM1, r, a);
             break;
     }
     return VPT_OK;
@@ -855,16 +858,18 @@ static int launch_multi(K kernel, vpt_renderer *r, const PassArgs &a, uint32_t n
     return VPT_OK;
 }
 static int launch_mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses) {
-    switch (variant_of(r)) {
-        case 0: return launch_multi(k_mcm_multi<0>, r, a, npasses);
-        case 1: return launch_multi(k_mcm_multi<1>, r, a, npasses);
-        case 2: return launch_multi(k_mcm_multi<2>, r, a, npasses);
-        case 3: return launch_multi(k_mcm_multi<3>, r, a, npasses);
-        case 8: return launch_multi(k_mcm_multi<8>, r, a, npasses);
-        case 9: return launch_multi(k_mcm_multi<9>, r, a, npasses);
-        case 10: return launch_multi(k_mcm_multi<10>, r, a, npasses);
-        default: return launch_multi(k_mcm_multi<11>, r, a, npasses);
-    }
+#define MULTI_CASES(F) switch (variant_of(r)) { \
+        case 0: return launch_multi(k_mcm_multi<0 | F>, r, a, npasses); \
+        case 1: return launch_multi(k_mcm_multi<1 | F>, r, a, npasses); \
+        case 2: return launch_multi(k_mcm_multi<2 | F>, r, a, npasses); \
+        case 3: return launch_multi(k_mcm_multi<3 | F>, r, a, npasses); \
+        case 8: return launch_multi(k_mcm_multi<8 | F>, r, a, npasses); \
+        case 9: return launch_multi(k_mcm_multi<9 | F>, r, a, npasses); \
+        case 10: return launch_multi(k_mcm_multi<10 | F>, r, a, npasses); \
+        default: return launch_multi(k_mcm_multi<11 | F>, r, a, npasses); }
+    if (r->fast_math) MULTI_CASES(VPT_V_FAST)
+    MULTI_CASES(0)
+#undef MULTI_CASES
 }
 static bool play_key_equal(const PassArgs &x, const PassArgs &y) { return memcmp(&x, &y, sizeof(PassArgs)) == 0; }
 
@@ -1111,6 +1116,9 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
     switch (option) {
         case VPT_OPTION_MCS_PERSISTENT: r->mcs_persistent = value != 0; return VPT_OK;
         case VPT_OPTION_MCM_PERSISTENT: r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
+        case VPT_OPTION_FAST_MATH:
+            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_FAST_MATH: only the MCM renderer has a fast-arithmetic variant");
+            r->fast_math = value != 0; return VPT_OK;
         default: return fail(VPT_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -1612,6 +1620,49 @@ static void profile_events(vpt_renderer *r, hipEvent_t *t0, hipEvent_t *t1) {
     *t0 = r->events[r->events_used].first; *t1 = r->events[r->events_used].second;
     r->event_launches[r->events_used] = 1; r->events_used++;
 }
+// The schedule of one frame of the gather pipeline as a PURE function of (frame index, rank, world, root): which ring buffer,
+// which event edges, where the kernel renders, which RCCL operations.  gather_enqueue_frame executes exactly this plan, and
+// tests/test_gather_schedule.py checks it on the CPU for world 2..8 (matching send / receive pairs, disjoint receive slots
+// that cover the frame, no ring buffer rewritten before its gather was waited for) — the `world > 1` operations cannot be
+// exercised on a one-GPU box.
+extern "C" int vpt_gather_plan(uint64_t frame, int rank, int world, int root, uint64_t send_bytes, vpt_gather_step *out) {
+    if (!out) return fail(VPT_ERR_INVALID, "null argument");
+    if (world < 1 || rank < 0 || rank >= world || root < -1 || root >= world) return fail(VPT_ERR_INVALID, "bad rank / world / root");
+    static_assert(VPT_GATHER_RING >= 2 && VPT_GATHER_RING % 2 == 0, "the ring is split into two halves");
+    const uint64_t half = VPT_GATHER_RING / 2;
+    memset(out, 0, sizeof(*out));
+    out->ring = VPT_GATHER_RING;
+    out->buffer = (int)(frame % VPT_GATHER_RING);
+    out->parity = (int)((frame / half) & 1);
+    // entering a half of the ring again: the gathers that used these buffers a ring ago must have drained
+    out->wait_gathered = (frame % half == 0 && frame >= VPT_GATHER_RING) ? 1 : 0;
+    // this half's last gather publishes "buffers of this half are free again"
+    out->record_gathered = ((frame + 1) % half == 0) ? 1 : 0;
+    out->rendered_event = out->buffer & 1;
+    // the receiving rank of a rooted gather renders straight into its own slot of the receive buffer
+    out->in_place = (root == rank) ? 1 : 0;
+    out->render_offset = out->in_place ? (uint64_t)rank * send_bytes : 0;
+    if (root < 0) {
+        out->op = VPT_GATHER_OP_ALLGATHER;
+    } else if (world == 1) {
+        out->op = VPT_GATHER_OP_NONE;
+    } else if (out->in_place) {
+        out->op = VPT_GATHER_OP_RECV;                 // one grouped receive per peer, slot p of the receive buffer
+        out->npeers = world - 1;
+    } else {
+        out->op = VPT_GATHER_OP_SEND;
+        out->peer = root;
+    }
+    return VPT_OK;
+}
+// the i-th receive of a VPT_GATHER_OP_RECV step: peer rank and byte offset of its slot in the receive buffer
+extern "C" int vpt_gather_plan_recv(const vpt_gather_step *st, int rank, int i, uint64_t send_bytes, int *peer, uint64_t *offset) {
+    if (!st || !peer || !offset) return fail(VPT_ERR_INVALID, "null argument");
+    if (st->op != VPT_GATHER_OP_RECV || i < 0 || i >= st->npeers) return fail(VPT_ERR_INVALID, "not a receive of this step");
+    int p = i < rank ? i : i + 1;                     // every rank but this one, ascending
+    *peer = p; *offset = (uint64_t)p * send_bytes;
+    return VPT_OK;
+}
 static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0, hipEvent_t t1, uint32_t fused_passes);
 extern "C" int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u) {
     if (!g || !u) return fail(VPT_ERR_INVALID, "null argument");
@@ -1632,17 +1683,13 @@ extern "C" int vpt_gather_render(vpt_gather *g, const vpt_uniforms *u) {
 static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, uint32_t fused_passes = 0) {
     vpt_renderer *r = g->r;
     hipStream_t cs = r->ctx->stream;
-    static_assert(VPT_GATHER_RING >= 2 && VPT_GATHER_RING % 2 == 0, "the ring is split into two halves");
     if ((size_t)r->W * r->local_h * 8 != g->send_bytes || r->G != g->world || r->g != g->rank)
         return fail(VPT_ERR_INVALID, "the renderer was resized or re-sharded after the gather was created: destroy and re-create the gather");
-    const uint64_t half = VPT_GATHER_RING / 2;
-    int b = (int)(g->frames % VPT_GATHER_RING);
-    int parity = (int)((g->frames / half) & 1);
-    // entering a half of the ring again: the gathers that used these buffers a ring ago must have drained
-    if (g->frames % half == 0 && g->frames >= VPT_GATHER_RING) HIP_TRY(hipStreamWaitEvent(cs, g->gathered[parity], 0));
-    // the receiving rank of a rooted gather renders straight into its own slot of the receive buffer
-    bool in_place = g->root == g->rank;
-    a.render = in_place ? (uint2 *)((char *)g->recv[b] + (size_t)g->rank * g->send_bytes) : (uint2 *)g->send[b];
+    vpt_gather_step st;
+    VPT_TRY(vpt_gather_plan(g->frames, g->rank, g->world, g->root, g->send_bytes, &st));
+    const int b = st.buffer;
+    if (st.wait_gathered) HIP_TRY(hipStreamWaitEvent(cs, g->gathered[st.parity], 0));
+    a.render = st.in_place ? (uint2 *)((char *)g->recv[b] + st.render_offset) : (uint2 *)g->send[b];
     r->render_target = a.render;                                             // vpt_renderer_read(RENDER) returns the last frame's rows
     if (t0) HIP_TRY(hipEventRecord(t0, cs));
     if (fused_passes) {
@@ -1652,25 +1699,28 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
         VPT_TRY(launch_fused(r, a));
     }
     if (t1) HIP_TRY(hipEventRecord(t1, cs));
-    HIP_TRY(hipEventRecord(g->rendered[b & 1], cs));
-    HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[b & 1], 0));
-    if (g->root < 0) {
+    HIP_TRY(hipEventRecord(g->rendered[st.rendered_event], cs));
+    HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[st.rendered_event], 0));
+    if (st.op == VPT_GATHER_OP_ALLGATHER) {
         RCCL_TRY(g_rccl.AllGather(g->send[b], g->recv[b], g->send_bytes, /*ncclUint8*/ 1, g->comm, g->comm_stream));
-    } else if (g->world > 1) {
+    } else if (st.op != VPT_GATHER_OP_NONE) {
         // gather to the display rank: its 7 peers send over 7 distinct xGMI links at once
         RCCL_TRY(g_rccl.GroupStart());
         int ne = 0;
-        if (in_place) {
-            for (int p = 0; p < g->world && ne == 0; p++)
-                if (p != g->rank) ne = g_rccl.Recv((char *)g->recv[b] + (size_t)p * g->send_bytes, g->send_bytes, /*ncclUint8*/ 1, p, g->comm, g->comm_stream);
+        if (st.op == VPT_GATHER_OP_RECV) {
+            for (int i = 0; i < st.npeers && ne == 0; i++) {
+                int p; uint64_t off;
+                VPT_TRY(vpt_gather_plan_recv(&st, g->rank, i, g->send_bytes, &p, &off));
+                ne = g_rccl.Recv((char *)g->recv[b] + off, g->send_bytes, /*ncclUint8*/ 1, p, g->comm, g->comm_stream);
+            }
         } else {
-            ne = g_rccl.Send(g->send[b], g->send_bytes, /*ncclUint8*/ 1, g->root, g->comm, g->comm_stream);
+            ne = g_rccl.Send(g->send[b], g->send_bytes, /*ncclUint8*/ 1, st.peer, g->comm, g->comm_stream);
         }
         int ge = g_rccl.GroupEnd();
         if (ne != 0) return fail(VPT_ERR_HIP, "ncclSend/ncclRecv failed: %s", g_rccl.GetErrorString(ne));
         if (ge != 0) return fail(VPT_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(ge));
     }
-    if ((g->frames + 1) % half == 0) HIP_TRY(hipEventRecord(g->gathered[parity], g->comm_stream));   // this half's last gather
+    if (st.record_gathered) HIP_TRY(hipEventRecord(g->gathered[st.parity], g->comm_stream));   // this half's last gather
     g->frames++;
     return VPT_OK;
 }

@@ -754,7 +754,27 @@ VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float
     for (uint32_t s = 0u; s < a.steps; s++) {
         float dist = random_exponential(state, a.inv_extinction);
         ph.position = madd3(ph.position, dist, ph.direction);
+#if VPT_X & 64
+        // TIMING HACK (results wrong): what would one aligned dword gather from a small table cost for the out-of-cube samples?
+        float4 vs;
+        {
+            f3 q0 = ph.position;
+            bool oob0 = (vmax(vmax(q0.x, q0.y), q0.z) > 1.0f) || (vmin(vmin(q0.x, q0.y), q0.z) < 0.0f);
+            if (oob0) {
+                uint32_t iy, iz; float fy, fz;
+                linear_cell(q0.y, a.vol.fny, a.vol.hy, iy, fy);
+                linear_cell(q0.z, a.vol.fnz, a.vol.hz, iz, fz);
+                uint32_t w = *(const uint32_t *)(a.vol.bricks + (((iy * 512u + iz) & 0x3ffffu) << 2));
+                float c00 = cvt_ubyte<0>(w), c10 = cvt_ubyte<1>(w), c01 = cvt_ubyte<2>(w), c11 = cvt_ubyte<3>(w);
+                float r = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz) * VPT_INV255;
+                vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
+            } else {
+                vs = sample_volume_color<V>(a, t, ph.position);
+            }
+        }
+#else
         float4 vs = sample_volume_color<V>(a, t, ph.position);
+#endif
         float p_null = 1.0f - vs.w;
         float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
         float p_abs = 1.0f - p_null - p_scat;
@@ -800,6 +820,145 @@ VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float
             ph.bounces++;
         }
 #endif
+    }
+}
+// The same events with resetPhoton run SPECULATIVELY between the sample's loads and their first use.  A wave's event is a
+// dependent chain  draw -> position -> LDS tables -> brick line (global, ~1-2 us under load) -> blend -> transfer function ->
+// decision -> resetPhoton ; measured (rocprofv3 PMC, r02): VALU busy 84 %, yet a variant with a third fewer VALU instructions
+// is only 3 % faster — the pass is bound by the latency of that chain times the seven waves a SIMD holds, not by issue.
+// resetPhoton (MCMRenderer.glsl:70-78) needs the random stream only, not the sampled value, and 93 % of the events of the
+// benchmark scene end in it: computed on copies while the loads fly and committed by the decision, it leaves the chain.
+// Same operations on the same values, so every buffer stays bit-identical (tests/test_gpu_parity.py).
+template <int V>
+VPT_DEV void mcm_events_spec(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
+    const f3 from0 = unproject_near(px, py, a);
+    uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    for (uint32_t s = 0u; s < a.steps; s++) {
+        float dist = random_exponential(state, a.inv_extinction);
+        ph.position = madd3(ph.position, dist, ph.direction);
+        TapFetch taps = fetch_taps<V>(a.vol, t, ph.position);                 // loads in flight from here
+        float wheel = random_uniform(state);
+        f3 q = ph.position;
+        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+        uint32_t st2 = state;
+        Photon sp = ph;
+        reset_photon(st2, sp, px, py, a, from0);                              // speculative: commits below
+        float4 vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, blend_taps(taps));     // first use of the loads
+        float p_null = 1.0f - vs.w;
+        float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
+        float p_abs = 1.0f - p_null - p_scat;
+        if (oob || wheel < p_abs) {
+            f3 rad = { 0.0f, 0.0f, 0.0f };
+            if (oob) {
+                float4 env = sample_environment(a.env, ph.direction);
+                rad = f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z };
+            }
+            photon_deposit(ph, rad);
+            state = st2;
+            ph.position = sp.position; ph.direction = sp.direction;
+            ph.bounces = 0u; ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
+        } else if (wheel < p_abs + p_scat) {
+            ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
+            ph.direction = sample_hg(state, a.anisotropy, ph.direction);
+            ph.bounces++;
+        }
+    }
+}
+// ---- fast-arithmetic variant of the MCM events (VPT_OPTION_FAST_MATH, kernel variant bit VPT_V_FAST) ---------------------
+// The same shader (MCMRenderer.glsl:128-166, resetPhoton :70-78, HG :91-106) with the arithmetic a GPU driver gives GLSL:
+// v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 / v_log_f32 / v_sin_f32 / v_cos_f32 (1 ulp class, GLSL ES 3.00 §4.5.1 allows 2.5 ulp for a/b and
+// leaves log / sin / cos implementation-defined) instead of the contract's software routines, and algebraically equal forms
+// that need fewer instructions:
+//   * -log(u)/rate = log2(u) * (-ln 2 / rate);
+//   * (random_square * 2 - 1) * inverseResolution = k * (2^-31 / W) - 1 / W with k the PCG state as a float;
+//   * inverseMvp * (p + jitter, 1, 1) = inverseMvp * (p, 1, 1) + jitter.x * column0 + jitter.y * column1 (the first term is a
+//     pixel constant);
+//   * normalize(to.xyz / to.w - from) = sign(to.w) * normalize(to.xyz - to.w * from): no division by w.
+// The integer PCG stream is identical, so the two variants take the same decisions except where a comparison falls
+// within rounding error; there is NO bit-exact CPU twin of this variant — it is checked against the contract oracle by
+// first-event agreement and converged-image statistics (tests/test_gpu_fast_math.py, tolerance in DESIGN.md §3).
+VPT_DEV float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }        // 1/(+-0) = +-inf, as the slab test needs
+VPT_DEV float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+VPT_DEV float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+VPT_DEV float hw_log2(float x) { return __builtin_amdgcn_logf(x); }       // log2(0) = -inf
+VPT_DEV float pcg_float(uint32_t &state) { state = pcg(state); return (float)state; }
+// sampleHenyeyGreenstein with hardware sqrt / sin / cos; v_sin_f32 / v_cos_f32 take their argument in revolutions:
+// sin(TWOPI * u) = v_sin_f32(u)
+VPT_DEV f3 sample_hg_fast(uint32_t &state, float g, f3 dir) {
+    float u1 = pcg_float(state) * 0x1p-32f, u2 = pcg_float(state) * 0x1p-32f;
+    float r0 = hw_sqrt(u1);
+    f2 d = { r0 * __builtin_amdgcn_cosf(u2), r0 * __builtin_amdgcn_sinf(u2) };
+    float norm = fmaf(d.y, d.y, d.x * d.x);
+    float radius = 2.0f * hw_sqrt(1.0f - norm);
+    f3 u = { radius * d.x, radius * d.y, fmaf(-2.0f, norm, 1.0f) };
+    if (fabsf(g) < 1e-5f) return u;
+    float g2 = g * g;
+    float c = (1.0f - g2) * hw_rcp(fmaf(2.0f * g, pcg_float(state) * 0x1p-32f, 1.0f - g));
+    float hgcos = fmaf(-c, c, 1.0f + g2) * hw_rcp(2.0f * g);
+    float ud = dot3(u, dir);
+    f3 cc = { fmaf(-ud, dir.x, u.x), fmaf(-ud, dir.y, u.y), fmaf(-ud, dir.z, u.z) };
+    float sq = hw_sqrt(fmaf(-hgcos, hgcos, 1.0f)) * hw_rsq(dot3(cc, cc));
+    return f3{ fmaf(sq, cc.x, hgcos * dir.x), fmaf(sq, cc.y, hgcos * dir.y), fmaf(sq, cc.z, hgcos * dir.z) };
+}
+template <int V>
+VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
+    const float *m = a.mvp_inv.m;
+    // pixel constants of resetPhoton with blur == 0: the near-plane point and the far-plane base point (homogeneous)
+    const float4 nb = mat4_mul_point(a.mvp_inv, px, py, -1.0f);
+    const float inw = hw_rcp(nb.w);
+    const f3 from0 = { nb.x * inw, nb.y * inw, nb.z * inw };
+    const float4 fb = mat4_mul_point(a.mvp_inv, px, py, 1.0f);
+    const float jx = 0x1p-31f * a.inv_w, jy = 0x1p-31f * a.inv_h;
+    const float ld = -0.6931471805599453f * a.inv_extinction;
+
+    uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    for (uint32_t s = 0u; s < a.steps; s++) {
+        float dist = hw_log2(pcg_float(state) * 0x1p-32f) * ld;
+        ph.position = madd3(ph.position, dist, ph.direction);
+        float4 vs = sample_volume_color<V>(a, t, ph.position);
+        float p_null = 1.0f - vs.w;
+        float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
+        float p_abs = 1.0f - p_null - p_scat;
+        float wheel = pcg_float(state) * 0x1p-32f;
+        f3 q = ph.position;
+        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+        if (oob || wheel < p_abs) {
+            f3 rad = { 0.0f, 0.0f, 0.0f };
+            if (oob) {
+                float4 env = sample_environment(a.env, ph.direction);
+                rad = f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z };
+            }
+            ph.samples++;
+            float inv_n = hw_rcp((float)ph.samples);
+            ph.radiance.x = fmaf(rad.x - ph.radiance.x, inv_n, ph.radiance.x);
+            ph.radiance.y = fmaf(rad.y - ph.radiance.y, inv_n, ph.radiance.y);
+            ph.radiance.z = fmaf(rad.z - ph.radiance.z, inv_n, ph.radiance.z);
+            if (a.blur == 0.0f) {
+                state = pcg(pcg(state));                          // the disk sample's two draws (multiplied by blur = 0)
+                float ax = fmaf(pcg_float(state), jx, -a.inv_w);
+                float ay = fmaf(pcg_float(state), jy, -a.inv_h);
+                float4 th = { fmaf(m[4], ay, fmaf(m[0], ax, fb.x)), fmaf(m[5], ay, fmaf(m[1], ax, fb.y)),
+                              fmaf(m[6], ay, fmaf(m[2], ax, fb.z)), fmaf(m[7], ay, fmaf(m[3], ax, fb.w)) };
+                f3 d = { fmaf(-th.w, from0.x, th.x), fmaf(-th.w, from0.y, th.y), fmaf(-th.w, from0.z, th.z) };
+                float inv = __builtin_copysignf(hw_rsq(dot3(d, d)), th.w);
+                f3 dir = { d.x * inv, d.y * inv, d.z * inv };
+                f3 iv = { hw_rcp(dir.x), hw_rcp(dir.y), hw_rcp(dir.z) };
+                float tx = vmin((0.0f - from0.x) * iv.x, (1.0f - from0.x) * iv.x);
+                float ty = vmin((0.0f - from0.y) * iv.y, (1.0f - from0.y) * iv.y);
+                float tz = vmin((0.0f - from0.z) * iv.z, (1.0f - from0.z) * iv.z);
+                float tnear = vmax(vmax(vmax(tx, ty), tz), 0.0f);
+                ph.direction = dir;
+                ph.position = madd3(from0, tnear, dir);
+                ph.bounces = 0u;
+                ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
+            } else {
+                reset_photon(state, ph, px, py, a, from0);        // depth-of-field runs: the contract's general path
+            }
+        } else if (wheel < p_abs + p_scat) {
+            ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
+            ph.direction = sample_hg_fast(state, a.anisotropy, ph.direction);
+            ph.bounces++;
+        }
     }
 }
 VPT_DEV Photon photon_unpack(float4 s0, float4 s1, float4 s2, float4 s3) {   // MCMRenderer.glsl:117-126
@@ -872,7 +1031,9 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     if (!p.valid) return;
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     Photon ph = photon_unpack(s0, s1, s2, s3);
-    mcm_events<V>(a, t, ph, px, py);
+    if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
+    else if ((VPT_X & 128) && !(V & (VPT_V_NEAREST | VPT_V_RG))) mcm_events_spec<V & ~(VPT_V_NEAREST | VPT_V_RG)>(a, t, ph, px, py);
+    else mcm_events<V>(a, t, ph, px, py);
     a.st0[p.k] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
     a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
     a.st2[p.k] = make_float4(ph.transmittance.x, ph.transmittance.y, ph.transmittance.z, 0.0f);
@@ -903,7 +1064,9 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     uint32_t base = *a.frame_counter;
     for (uint32_t f = 0; f < npasses; f++) {
         a.seed = a.frame_table[(base + f) & a.frame_mask].seed;
-        mcm_events<V>(a, t, ph, px, py);
+        if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
+        else if ((VPT_X & 128) && !(V & (VPT_V_NEAREST | VPT_V_RG))) mcm_events_spec<V & ~(VPT_V_NEAREST | VPT_V_RG)>(a, t, ph, px, py);
+    else mcm_events<V>(a, t, ph, px, py);
         // the unfused sequence stores the counters as floats between passes and re-reads them with uint(w + 0.5):
         // identical for every count below 2^24
     }
