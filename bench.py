@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--fast-math", type=int, default=0,
                     help="MCM: 1 = the fast-arithmetic kernel variant (VPT_OPTION_FAST_MATH: hardware rcp / rsq / log / sin / cos; "
                          "checked against the contract by tolerance, not bit for bit)")
+    ap.add_argument("--boundary-atlas", type=int, default=1,
+                    help="MCM: 0 = out-of-cube samples from the bricks as well (VPT_OPTION_BOUNDARY_ATLAS off; results identical)")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
     return ap.parse_args()
 
@@ -290,6 +292,8 @@ def main():
             r.set_option(N.OPTION_MCM_PERSISTENT, args.mcm_persistent)
         if args.fast_math:
             r.set_option(N.OPTION_FAST_MATH, 1)
+        if not args.boundary_atlas and args.renderer == "mcm":
+            r.set_option(N.OPTION_BOUNDARY_ATLAS, 0)
         if args.mcs_persistent >= 0:
             r.set_option(N.OPTION_MCS_PERSISTENT, args.mcs_persistent)
         assert r.local_rows() == gather.rows
@@ -364,6 +368,7 @@ def main():
                            "arithmetic": ("fast-math variant (VPT_OPTION_FAST_MATH: hardware rcp/rsq/sqrt/log/sin/cos; tolerance-checked against the "
                                           "contract oracle, tests/test_gpu_fast_math.py)" if args.fast_math else
                                           "bit-exact contract (every buffer identical to oracle/vpt_oracle.c)"),
+                           "boundary_atlas": bool(args.boundary_atlas),
                            "repeats": args.repeats, "block_ms_min": min(res["blocks_ms"]), "block_ms_max": max(res["blocks_ms"]),
                            "block_ms_median": res["dt"] * 1e3, "timed_block": "median of `repeats` blocks of `steps` steps"},
                 # `frac` prices the kernel against the HBM roofline by ALGORITHMIC bytes, as the metric is defined; what actually

@@ -48,6 +48,9 @@ extern "C" {
 
 /* Volume formats (RAWReader.js:36-38: format RED, internalFormat R8, type UNSIGNED_BYTE) */
 #define VPT_FORMAT_R8 0
+#define VPT_FORMAT_R32F 2        /* format RED, internalFormat R32F (or R16F: widened exactly on upload), type FLOAT / HALF_FLOAT: the texel value
+                                  * itself (not normalised), LINEAR-filtered like the byte formats (OES_texture_float_linear, RenderingContext.js:78);
+                                  * blocks are uploaded as float32 */
 #define VPT_FORMAT_RG8 1         /* format RG, internalFormat RG8, type UNSIGNED_BYTE: two interleaved channels, texture(uVolume, p).rg
                                   * has both and the transfer function is looked up in 2-D (MIPRenderer.glsl:45-49) */
 
@@ -178,6 +181,12 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * results are NOT bit-identical to the contract oracle: checked by first-event agreement and converged-image statistics
  * (tolerance in DESIGN.md section 3).  The persistent-wave option has no fast variant (it takes precedence when set). */
 #define VPT_OPTION_FAST_MATH 2
+/* VPT_OPTION_BOUNDARY_ATLAS (default 1; MCM renderer, LINEAR filter, one-channel volumes): the sample of an event whose position
+ * lies outside the cube — taken at the clamped position and discarded by the shader (MCMRenderer.glsl:132-142) — is fetched from
+ * the volume's boundary atlas (the six outer voxel planes, one dword per 2 x 2 footprint) instead of the bricks: the same
+ * value bit for bit (a clamped cell has weight 0 along the clamped axis), one aligned 4-byte gather instead of two unaligned
+ * 8-byte ones.  0 = always the bricks. */
+#define VPT_OPTION_BOUNDARY_ATLAS 3
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
 /* the LAO renderer's own uniforms (gl.uniform* calls of LAORenderer.js:159-169; uStepSize and uExtinction travel in
  * vpt_uniforms); defaults are the reference's property defaults (LAORenderer.js:17-108) */

@@ -446,11 +446,11 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("gatherUniqueId", GatherUniqueId); EXPORT("gatherCreate", GatherCreate); EXPORT("gatherDestroy", GatherDestroy);
     EXPORT("gatherSetRoot", GatherSetRoot); EXPORT("gatherRender", GatherRender); EXPORT("gatherPlay", GatherPlay); EXPORT("gatherSynchronize", GatherSynchronize);
     EXPORT("gatherReadFrame", GatherReadFrame);
-    CONST(VPT_OPTION_MCS_PERSISTENT); CONST(VPT_OPTION_MCM_PERSISTENT); CONST(VPT_OPTION_FAST_MATH);
+    CONST(VPT_OPTION_MCS_PERSISTENT); CONST(VPT_OPTION_MCM_PERSISTENT); CONST(VPT_OPTION_FAST_MATH); CONST(VPT_OPTION_BOUNDARY_ATLAS);
     CONST(VPT_PLAY_EAGER); CONST(VPT_PLAY_GRAPH); CONST(VPT_PLAY_FUSED);
     CONST(VPT_RENDERER_MIP); CONST(VPT_RENDERER_EAM); CONST(VPT_RENDERER_MCS); CONST(VPT_RENDERER_MCM);
     CONST(VPT_RENDERER_ISO); CONST(VPT_RENDERER_DEPTH); CONST(VPT_RENDERER_LAO); CONST(VPT_RENDERER_DOS); CONST(VPT_BUFFER_DOS_OCCLUSION);
-    CONST(VPT_FILTER_NEAREST); CONST(VPT_FILTER_LINEAR); CONST(VPT_FORMAT_R8); CONST(VPT_FORMAT_RG8);
+    CONST(VPT_FILTER_NEAREST); CONST(VPT_FILTER_LINEAR); CONST(VPT_FORMAT_R8); CONST(VPT_FORMAT_RG8); CONST(VPT_FORMAT_R32F);
     CONST(VPT_BUFFER_RENDER); CONST(VPT_BUFFER_FRAME); CONST(VPT_BUFFER_ACCUM);
     CONST(VPT_BUFFER_MCM_POSITION); CONST(VPT_BUFFER_MCM_DIRECTION); CONST(VPT_BUFFER_MCM_TRANSMITTANCE); CONST(VPT_BUFFER_MCM_RADIANCE);
     napi_set_named_property(env, exports, "UNIFORMS_BYTES", number(env, (double)sizeof(vpt_uniforms)));

@@ -5,6 +5,8 @@ const { AbstractLoader, BlobLoader } = require('../loaders/loaders.js');
 
 const GL_RED = 6403, GL_R8 = 33321, GL_UNSIGNED_BYTE = 5121;
 const GL_RG = 33319, GL_RG8 = 33323;                  // two-channel volumes of BVP manifests
+const GL_RGB = 6407, GL_RGB8 = 32849, GL_RGBA = 6408, GL_RGBA8 = 32856;   // byte manifests with more channels (the shaders read .rg)
+const GL_FLOAT = 5126, GL_HALF_FLOAT = 5131, GL_R32F = 33326, GL_R16F = 33325;   // float volumes (Volume.js:84-105)
 
 class AbstractReader {                                          // AbstractReader.js:1-15
     constructor(loader) { this._loader = loader; }
@@ -124,4 +126,5 @@ function ReaderFactory(which) {                                 // ReaderFactory
     }
 }
 
-module.exports = { AbstractReader, RAWReader, ZIPReader, BVPReader, ReaderFactory, GL_RED, GL_R8, GL_RG, GL_RG8, GL_UNSIGNED_BYTE };
+module.exports = { AbstractReader, RAWReader, ZIPReader, BVPReader, ReaderFactory, GL_RED, GL_R8, GL_RG, GL_RG8, GL_UNSIGNED_BYTE,
+    GL_RGB, GL_RGB8, GL_RGBA, GL_RGBA8, GL_FLOAT, GL_HALF_FLOAT, GL_R32F, GL_R16F };

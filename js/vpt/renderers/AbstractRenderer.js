@@ -14,6 +14,20 @@ const { native } = require('../native.js');
 const U = { MVP: 0, SEED: 64, OFFSET: 68, STEP: 72, EXTINCTION: 76, ANISOTROPY: 80, BOUNCES: 84, STEPS: 88, LIGHT: 92, MIX: 104, BLUR: 108,
             ISOVALUE: 112, GRADIENT_STEP: 116, THRESHOLD: 120, SIZE: 128 };
 
+const GL = { NEAREST: 9728, CLAMP_TO_EDGE: 33071, RED: 6403, RG: 33319, RGBA: 6408, R8: 33321, R32F: 33326, RG32F: 33328,
+    RGBA16F: 34842, RGBA32F: 34836, UNSIGNED_BYTE: 5121, FLOAT: 5126 };
+const KIND_NAMES = ['mip', 'eam', 'mcs', 'mcm', 'iso', 'depth', 'lao', 'dos'];      // VPT_RENDERER_* (include/vpt.h)
+const U8 = ['RGBA', 'RGBA', 'UNSIGNED_BYTE'], F4 = ['RGBA', 'RGBA32F', 'FLOAT'];
+const BUFFER_FORMATS = {            // renderer name -> [frame attachments, accumulation attachments] as [format, iformat, type]
+    mip: [[['RED', 'R8', 'UNSIGNED_BYTE']], [['RED', 'R8', 'UNSIGNED_BYTE']]],              // MIPRenderer.js:133-157
+    eam: [[U8], [U8]], lao: [[U8], [U8]],                                                   // EAMRenderer.js:155-179
+    mcs: [[F4], [F4]],                                                                      // MCSRenderer.js:156-180
+    mcm: [[F4], [F4, F4, F4, F4]],                                                          // MCMRenderer.js:201-263
+    iso: [[['RGBA', 'RGBA16F', 'FLOAT']], [['RGBA', 'RGBA16F', 'FLOAT']]],
+    depth: [[['RED', 'R32F', 'FLOAT']], [['RED', 'R32F', 'FLOAT']]],
+    dos: [[F4], [F4, ['RED', 'R32F', 'FLOAT']]],                                            // DOSRenderer.js:277-305
+};
+
 class AbstractRenderer extends PropertyBag {
 
 constructor(gl, volume, camera, environmentTexture, options) {
@@ -131,6 +145,21 @@ _resetFrame() {}
 _generateFrame() {}
 _integrateFrame() {}
 _renderFrame() {}
+
+// Buffer specs (AbstractRenderer.js:134-155 and the subclasses' _get*BufferSpec).  In the reference these lists drive the allocation of
+// the WebGL attachments (_rebuildBuffers, :78-92); here the native renderer owns the HIP buffers and the hooks DESCRIBE them with the
+// reference's GL enums, one object per attachment in attachment order.
+_spec(fmt) {
+    const size = this._size();
+    return { width: size[0], height: size[1], min: GL.NEAREST, mag: GL.NEAREST, format: GL[fmt[0]], iformat: GL[fmt[1]], type: GL[fmt[2]] };
+}
+_getFrameBufferSpec() { return BUFFER_FORMATS[KIND_NAMES[this.constructor.KIND()]][0].map(f => this._spec(f)); }
+_getAccumulationBufferSpec() { return BUFFER_FORMATS[KIND_NAMES[this.constructor.KIND()]][1].map(f => this._spec(f)); }
+_getRenderBufferSpec() {                                                                     // AbstractRenderer.js:142-155
+    const d = this._spec(['RGBA', 'RGBA16F', 'FLOAT']);
+    d.wrapS = d.wrapT = GL.CLAMP_TO_EDGE;
+    return [d];
+}
 // the uniforms of one whole render() pass, with the per-frame draws taken in hook order (subclasses)
 _prepareFused() { return null; }
 _renderFused() { this._bindVolume(); native().rendererRender(this._h, this._prepareFused()); }

@@ -26,7 +26,7 @@ class Scene(C.Structure):
         ("filter", C.c_int32),
         ("tf_rgba", C.c_void_p), ("tf_w", C.c_int32), ("tf_h", C.c_int32),
         ("env_rgba", C.c_void_p), ("env_w", C.c_int32), ("env_h", C.c_int32),
-        ("channels", C.c_int32),
+        ("channels", C.c_int32), ("dtype", C.c_int32),
     ]
 
 
@@ -172,8 +172,10 @@ class OracleScene:
     """Holds numpy arrays alive and exposes the ctypes Scene."""
 
     def __init__(self, volume, filter="linear", tf=None, env=None):
-        volume = np.ascontiguousarray(volume, dtype=np.uint8)
-        assert volume.ndim == 3 or (volume.ndim == 4 and volume.shape[3] == 2), "volume is [z][y][x] uint8 (R8) or [z][y][x][2] (RG8)"
+        volume = np.asarray(volume)
+        f32 = volume.dtype.kind == "f"                 # FLOAT / HALF_FLOAT texels: half widens to float exactly
+        volume = np.ascontiguousarray(volume, dtype=np.float32 if f32 else np.uint8)
+        assert volume.ndim == 3 or (volume.ndim == 4 and volume.shape[3] == 2), "volume is [z][y][x] (R8 / R32F) or [z][y][x][2] (RG8)"
         self.volume = volume
         self.tf = np.ascontiguousarray(DEFAULT_TF if tf is None else tf, dtype=np.uint8)
         self.env = np.ascontiguousarray(DEFAULT_ENV if env is None else env, dtype=np.uint8)
@@ -183,6 +185,7 @@ class OracleScene:
         s.volume = _ptr(self.volume)
         s.nz, s.ny, s.nx = volume.shape[:3]
         s.channels = 2 if volume.ndim == 4 else 1
+        s.dtype = 1 if f32 else 0
         s.filter = 1 if filter == "linear" else 0
         s.tf_rgba = _ptr(self.tf); s.tf_h, s.tf_w = self.tf.shape[:2]
         s.env_rgba = _ptr(self.env); s.env_h, s.env_w = self.env.shape[:2]

@@ -51,6 +51,8 @@ typedef struct {
     const uint8_t *env_rgba;    /* RGBA8 environment map, LINEAR/CLAMP (RenderingContext.js:90-101) */
     int32_t env_w, env_h;
     int32_t channels;           /* 1 = R8 (RAWReader.js:36-38), 2 = RG8 interleaved: texture(uVolume, p).rg has both (0 means 1) */
+    int32_t dtype;              /* 0 = UNSIGNED_BYTE texels, normalised v/255; 1 = FLOAT texels (R32F / R16F widened exactly): the value itself,
+                                 * LINEAR-filtered the same way (OES_texture_float_linear, RenderingContext.js:78); `volume` then points at floats */
 } vpo_scene;
 
 typedef struct {
@@ -360,24 +362,29 @@ static inline float lerpf(float a, float b, float f) { return fmaf(f, b - a, a);
  * texel values (x, then y, then z) and normalises once by * fl32(1/255). */
 static float sample_volume_channel(const vpo_scene *sc, v3 p, int channel) {
     size_t nch = sc->channels == 2 ? 2 : 1;
-    const uint8_t *v = sc->volume + channel;
     size_t sx = nch, sy = nch * (size_t)sc->nx, sz = nch * (size_t)sc->nx * (size_t)sc->ny;
+    const int f32 = sc->dtype == 1;
+    const uint8_t *v = sc->volume + channel;
+    const float *vf = (const float *)sc->volume + channel;
+#define TEXEL(ix, iy, iz) (f32 ? vf[(ix) * sx + (iy) * sy + (iz) * sz] : (float)v[(ix) * sx + (iy) * sy + (iz) * sz])
+    const float norm = f32 ? 1.0f : VPO_INV255;          /* float texels are not normalised (x * 1.0f is exact) */
     if (sc->filter == 0) {
         int32_t x = nearest_coord(p.x, sc->nx), y = nearest_coord(p.y, sc->ny), z = nearest_coord(p.z, sc->nz);
-        return (float)v[x * sx + y * sy + z * sz] * VPO_INV255;
+        return TEXEL(x, y, z) * norm;
     }
     int32_t x0, x1, y0, y1, z0, z1; float fx, fy, fz;
     linear_coord(p.x, sc->nx, &x0, &x1, &fx);
     linear_coord(p.y, sc->ny, &y0, &y1, &fy);
     linear_coord(p.z, sc->nz, &z0, &z1, &fz);
-    float c000 = v[x0 * sx + y0 * sy + z0 * sz], c100 = v[x1 * sx + y0 * sy + z0 * sz];
-    float c010 = v[x0 * sx + y1 * sy + z0 * sz], c110 = v[x1 * sx + y1 * sy + z0 * sz];
-    float c001 = v[x0 * sx + y0 * sy + z1 * sz], c101 = v[x1 * sx + y0 * sy + z1 * sz];
-    float c011 = v[x0 * sx + y1 * sy + z1 * sz], c111 = v[x1 * sx + y1 * sy + z1 * sz];
+    float c000 = TEXEL(x0, y0, z0), c100 = TEXEL(x1, y0, z0);
+    float c010 = TEXEL(x0, y1, z0), c110 = TEXEL(x1, y1, z0);
+    float c001 = TEXEL(x0, y0, z1), c101 = TEXEL(x1, y0, z1);
+    float c011 = TEXEL(x0, y1, z1), c111 = TEXEL(x1, y1, z1);
+#undef TEXEL
     float c00 = lerpf(c000, c100, fx), c10 = lerpf(c010, c110, fx);
     float c01 = lerpf(c001, c101, fx), c11 = lerpf(c011, c111, fx);
     float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
-    return lerpf(c0, c1, fz) * VPO_INV255;
+    return lerpf(c0, c1, fz) * norm;
 }
 static inline float sample_volume(const vpo_scene *sc, v3 p) { return sample_volume_channel(sc, p, 0); }
 

@@ -69,6 +69,11 @@ def random_case(seed):
     if seed % 3 == 1:                                  # a two-channel (RG8) volume: the transfer function is looked up in 2-D
         second = rng.integers(0, 256, size=dims, dtype=np.uint8) if rng.uniform() < 0.7 else (255 - vol)
         vol = np.ascontiguousarray(np.stack([vol, second], axis=-1))
+    elif seed % 5 == 2:                                # FLOAT texels (R32F, or an R16F file widened): the value itself, also outside [0, 1]
+        frng = np.random.default_rng(77 + seed)        # (own generator: the other cases keep their draws)
+        vol = (vol.astype(np.float32) / np.float32(255.0) * np.float32(frng.uniform(0.5, 1.6)) + np.float32(frng.uniform(-0.3, 0.2))).astype(np.float32)
+        if frng.uniform() < 0.5:
+            vol = vol.astype(np.float16).astype(np.float32)
     w, h = int(rng.integers(1, 200)), int(rng.integers(1, 140))
     tf_w, tf_h = int(rng.choice([1, 2, 3, 7, 64, 256])), int(rng.choice([1, 1, 3, 16]))
     tf = rng.integers(0, 256, size=(tf_h, tf_w, 4), dtype=np.uint8)

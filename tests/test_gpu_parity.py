@@ -349,6 +349,33 @@ def test_errors_are_loud(gpu_ctx):
     r.destroy()
 
 
+@pytest.mark.parametrize("dims,cam", [((20, 24, 17), (0.6, -0.35, 1.7)), ((1, 9, 33), (2.2, 0.4, 1.2)), ((40, 40, 40), (0.3, 0.2, 0.35))])
+def test_mcm_boundary_atlas_is_bit_identical_to_the_bricks(gpu_ctx, oracle, dims, cam):
+    """VPT_OPTION_BOUNDARY_ATLAS: out-of-cube samples from the six face images vs from the bricks — every state buffer identical
+    to each other and to the oracle (non-cubic volumes, a one-voxel-thick axis, a camera INSIDE the volume)"""
+    sc = Scene(gpu_ctx, oracle, 24, 88, 56, tf=colour_tf(32, 1), camera=orbit_camera(88 / 56, *cam), dims=dims)
+    outs = []
+    for atlas in (1, 0):
+        r = sc.renderer('mcm')
+        r.set_option(N.OPTION_BOUNDARY_ATLAS, atlas)
+        r.extinction = 5; r.steps = 7
+        r.reset()
+        us = []
+        for _ in range(4):
+            r.render(); us.append(r._u)
+        outs.append([r.read(b) for b in MCM_BUFFERS] + [r.getTexture()])
+        r.destroy()
+    for x, y in zip(*outs):
+        assert_same_bits(x, y, "atlas on vs off")
+    o = oracle.OracleRenderer('mcm', sc.osc, sc.w, sc.h)
+    o.reset(oracle.make_frame(sc.w, sc.h, sc.m, seed=np.float32(GoldenRatioRng()())))
+    for u in us:
+        o.render(to_frame(oracle, sc, u))
+    for b, s_ in zip(outs[0][:4], o.state):
+        assert_same_bits(b, s_.reshape(sc.h, sc.w, 4), "atlas path vs oracle")
+    sc.gvol.destroy()
+
+
 @pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "mcm"])
 def test_wide_offset_tables_variant(gpu_ctx, oracle, kind):
     """the 64-bit brick-offset-table kernels (used above 4 GiB of bricked data, e.g. 2048^3) forced on a small volume"""

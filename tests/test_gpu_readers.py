@@ -140,3 +140,76 @@ def test_rg8_volume_through_bvp(gpu_ctx, oracle, tmp_path):
                 o.render(oracle.make_frame(W, H, m, offset=off, steps=64, extinction=100, mix=np.float32(1.0 / (k + 1))))
         assert (outs[0].view(np.uint16).reshape(-1) == o.out).all(), "%s vs oracle" % kind
     v.destroy(); whole.destroy()
+
+
+def make_bvp_typed(arr, fmt, ifmt, gltype, cuts):
+    """arr [z][y][x] or [z][y][x][c] of any dtype -> stored-zip BVP with the given GL format / internalFormat / type"""
+    d, h, w = arr.shape[:3]
+    xs, ys, zs = ([0] + list(c) + [n] for c, n in zip(cuts, (w, h, d)))
+    blocks, placements = [], []
+    bio = io.BytesIO()
+    with zipfile.ZipFile(bio, "w", compression=zipfile.ZIP_STORED) as z:
+        for zi in range(len(zs) - 1):
+            for yi in range(len(ys) - 1):
+                for xi in range(len(xs) - 1):
+                    x0, x1, y0, y1, z0, z1 = xs[xi], xs[xi + 1], ys[yi], ys[yi + 1], zs[zi], zs[zi + 1]
+                    name = "blocks/%d_%d_%d.raw" % (xi, yi, zi)
+                    z.writestr(name, np.ascontiguousarray(arr[z0:z1, y0:y1, x0:x1]).tobytes())
+                    placements.append({"index": len(blocks), "position": {"x": x0, "y": y0, "z": z0}})
+                    blocks.append({"url": name, "format": "raw", "dimensions": {"width": x1 - x0, "height": y1 - y0, "depth": z1 - z0}})
+        manifest = {"meta": {"version": 1},
+                    "modalities": [{"name": "default", "dimensions": {"width": w, "height": h, "depth": d},
+                                    "transform": {"matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]},
+                                    "format": fmt, "internalFormat": ifmt, "type": gltype, "placements": placements}],
+                    "blocks": blocks}
+        z.writestr("manifest.json", json.dumps(manifest))
+    return bio.getvalue()
+
+
+@pytest.mark.parametrize("case", ["r32f", "r16f", "rgba8", "rgb8"])
+def test_float_and_multichannel_manifests(gpu_ctx, oracle, case):
+    """Volume.js:58-60 allocates whatever internalFormat the manifest names, :84-105 maps the GL type: R32F / R16F volumes
+    (FLOAT / HALF_FLOAT, filtered LINEAR) and RGBA8 / RGB8 (the shaders read .rg) through a BVP with partial blocks must render
+    exactly like the same texels uploaded as one array — and like the oracle"""
+    from vpt_amd.readers import GL_RED, GL_R32F, GL_R16F, GL_FLOAT, GL_HALF_FLOAT, GL_RGBA, GL_RGBA8, GL_RGB, GL_RGB8, GL_UNSIGNED_BYTE
+    rng = np.random.default_rng(11)
+    base = sphere_volume(0, noise=35.0, dims=(19, 26, 23))
+    if case in ("r32f", "r16f"):
+        f = (base.astype(np.float32) / np.float32(255) * np.float32(1.4) - np.float32(0.2)).astype(np.float32)
+        if case == "r16f":
+            stored = f.astype(np.float16); texels = stored.astype(np.float32)
+            archive = make_bvp_typed(stored, GL_RED, GL_R16F, GL_HALF_FLOAT, ((9,), (11, 20), (7,)))
+        else:
+            stored = texels = f
+            archive = make_bvp_typed(stored, GL_RED, GL_R32F, GL_FLOAT, ((9,), (11, 20), (7,)))
+    else:
+        nch = 4 if case == "rgba8" else 3
+        stored = rng.integers(0, 256, size=base.shape + (nch,), dtype=np.uint8)
+        stored[..., 0] = base
+        texels = np.ascontiguousarray(stored[..., :2])
+        archive = make_bvp_typed(stored, GL_RGBA if nch == 4 else GL_RGB, GL_RGBA8 if nch == 4 else GL_RGB8, GL_UNSIGNED_BYTE, ((9,), (11, 20), (7,)))
+    v1 = vpt_amd.Volume(gpu_ctx, BVPReader(BlobLoader(archive))); v1.load(); v1.setFilter('linear')
+    v2 = vpt_amd.Volume.from_array(gpu_ctx, texels, 'linear')
+    a, ta = render_mip(gpu_ctx, v1); b, tb = render_mip(gpu_ctx, v2)
+    assert (a == b).all() and (ta.view(np.uint16) == tb.view(np.uint16)).all() and a.max() > 0
+    # against the oracle's linear-layout sampler (same seeds as render_mip)
+    w, h = 120, 90
+    from vpt_amd.scene import mvp_inverse_matrix
+    m = mvp_inverse_matrix(default_camera(w / h), Transform(Node()))
+    o = oracle.OracleRenderer('mip', oracle.OracleScene(texels, 'linear'), w, h)
+    o.reset(oracle.make_frame(w, h, m))
+    g = GoldenRatioRng()
+    for _ in range(2):
+        o.render(oracle.make_frame(w, h, m, steps=50, offset=np.float32(g())))
+    assert (a.reshape(-1) == o.acc).all()
+    v1.destroy(); v2.destroy()
+
+
+def test_unsupported_gl_types_raise_the_reference_error(gpu_ctx):
+    from vpt_amd.readers import GL_RED
+    vol = np.zeros((4, 4, 4), np.uint16)
+    for gltype in (5123, 5125, 5120, 5122):            # UNSIGNED_SHORT, UNSIGNED_INT, BYTE, SHORT: not filterable through sampler3D
+        archive = make_bvp_typed(vol, GL_RED, 33322, gltype, ((), (), ()))
+        v = vpt_amd.Volume(gpu_ctx, BVPReader(BlobLoader(archive)))
+        with pytest.raises(RuntimeError, match="Unknown volume datatype"):
+            v.load()

@@ -84,3 +84,23 @@ def test_golden_ratio_rng_is_deterministic():
     va = [a() for _ in range(5)]
     assert va == [b() for _ in range(5)] and all(0 <= v < 1 for v in va)
     assert abs(va[0] - 0.61803398875) < 1e-12
+
+
+def test_buffer_spec_hooks_describe_the_reference_attachments():
+    """AbstractRenderer.js:134-155 + the subclasses' _get*BufferSpec: one dict per attachment, the reference's GL enums (checked
+    here against the enum values and attachment counts read from the reference's renderer classes)"""
+    from vpt_amd import renderers as R
+    from vpt_amd import _native as N
+    GL = R.AbstractRenderer._GL
+    want = {N.RENDERER_MIP: (1, 1, GL['R8']), N.RENDERER_EAM: (1, 1, GL['RGBA']), N.RENDERER_MCS: (1, 1, GL['RGBA32F']),
+            N.RENDERER_MCM: (1, 4, GL['RGBA32F']), N.RENDERER_ISO: (1, 1, GL['RGBA16F']), N.RENDERER_DEPTH: (1, 1, GL['R32F']),
+            N.RENDERER_LAO: (1, 1, GL['RGBA']), N.RENDERER_DOS: (1, 2, GL['RGBA32F'])}
+    for cls in (R.MIPRenderer, R.EAMRenderer, R.MCSRenderer, R.MCMRenderer, R.ISORenderer, R.DepthRenderer, R.LAORenderer, R.DOSRenderer):
+        r = cls.__new__(cls)
+        r._resolution = (40, 30)
+        nf, na, iformat = want[cls._KIND]
+        fs, acc, ren = r._getFrameBufferSpec(), r._getAccumulationBufferSpec(), r._getRenderBufferSpec()
+        assert len(fs) == nf and len(acc) == na and len(ren) == 1
+        assert acc[0]['iformat'] == iformat and acc[0]['width'] == 40 and acc[0]['height'] == 30 and acc[0]['min'] == GL['NEAREST']
+        assert ren[0]['iformat'] == GL['RGBA16F'] and ren[0]['type'] == GL['FLOAT'] and ren[0]['wrapS'] == GL['CLAMP_TO_EDGE']
+    assert R.DOSRenderer.__new__(R.DOSRenderer)._BUFFER_FORMATS[N.RENDERER_DOS][1][1] == ('RED', 'R32F', 'FLOAT')

@@ -1,0 +1,38 @@
+"""CPU: compiles the HIP source to assembly for gfx950 (hipcc cross-compiles without a GPU) and checks the register / scratch
+budget of the headline kernels from the compiler's own resource report.  Guards against a class of silent 5x regressions: an
+lvalue conditional on kernel-argument members (`c ? a.ny : a.nx`) makes the whole argument block live in scratch memory —
+results stay bit-exact, only the speed collapses (r02: 137 us -> 672 us per frame)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
+def test_mcm_kernels_use_no_scratch_and_fit_seven_waves():
+    res = subprocess.run(["make", "-C", os.path.join(ROOT, "vpt_amd", "csrc"), "asm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert res.returncode == 0, res.stdout.decode()[-2000:]
+    text = res.stdout.decode()
+    usage = {}
+    cur = None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1); usage[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            usage[cur][m.group(1).strip()] = int(m.group(2))
+    # LINEAR filter, one channel: bit-exact and fast-math, 32-bit and brick-code (> 4 GiB) tables, hooks and fused render
+    hot = {k: v for k, v in usage.items() if re.match(r"_Z15k_mcm_integrateILb[01]ELi(0|1|16|17)EE", k) or k.startswith("_Z11k_mcm_multiILi0E") or k.startswith("_Z11k_mcm_multiILi16E")}
+    assert len(hot) == 10, sorted(hot)
+    for name, u in hot.items():
+        multi = "k_mcm_multi" in name                         # the fused-pass kernels may spill a few registers around their pass loop
+        assert u.get("ScratchSize", 0) <= (64 if multi else 0), (name, u)
+        assert u.get("VGPRs Spill", 0) <= (16 if multi else 0), (name, u)
+        assert u.get("VGPRs", 999) <= 72, (name, u)          # 7 waves per SIMD
+        assert u.get("Occupancy", 0) >= 7, (name, u)

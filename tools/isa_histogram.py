@@ -6,10 +6,13 @@
 Splits the kernel into basic blocks, marks the blocks of the innermost loop that holds the most VALU instructions (the
 MCM event loop), classifies every VALU instruction by issue-cost class (tools/valu_rates.hip, MI355X, >= 4 waves per SIMD):
 
-  fp32   v_fma / v_fmac / v_fmaak / v_fmamk / v_mul_f32 / v_add_f32 / v_sub_f32      ~2.6 cycles per wave64 instruction
-  pk     v_pk_{fma,mul,add}_f32 (two fp32 operations)                                 ~4.4
-  trans  v_rcp / v_rsq / v_sqrt / v_log / v_exp / v_sin / v_cos                       ~8.4
-  int    everything else: integer, shift, logic, convert, min/max/med3, fract, compare, select, move   ~4.3 (3.8 logic)
+  full   v_fma / v_fmac / v_fmaak / v_fmamk / v_mul_f32 / v_add_f32 / v_sub_f32, integer add / sub, shifts, and / or / xor,
+         v_mov, v_cndmask                                                             2 cycles per wave64 instruction
+  half   v_mul_lo_u32, v_mul_u32_u24, conversions, min / max / med3 / min3 / max3, fract, rndne, three-operand integer
+         (add3, lshl_add, lshl_or, and_or, bfe, perm), compares, v_pk_{fma,mul,add}_f32 (two fp32 operations)   4
+  trans  v_rcp / v_rsq / v_sqrt / v_log / v_exp / v_sin / v_cos                       8   (v_mad_u64_u32: 6)
+(r02 measurement at 7-8 waves per SIMD: 2.37 / 4.2 / 8.25 "cycles at 2.4 GHz", i.e. 2 / 4 / 8 cycles at the ~2.0 GHz the chip
+holds under this load; one dependent chain per wave reaches the same rates from 2 waves per SIMD on)
 
 and attributes the event loop's instructions to phases by signature: a PCG round = the 9 instructions around each
 `>> 28` shift; the rest is reported per basic block (the blocks of the deposit + resetPhoton path, the scattering path and the
@@ -19,17 +22,19 @@ import json
 import re
 import sys
 
-COST = {"fp32": 2.6, "pk": 4.4, "trans": 8.4, "int": 4.3}
+COST = {"full": 2.0, "half": 4.0, "trans": 8.0}
 
 
 def classify(op):
-    if op.startswith("v_pk_") and op.endswith("_f32"):
-        return "pk"
-    if re.match(r"v_(fma|fmac|fmaak|fmamk|mul|add|sub|subrev|mac|mad)_f32", op):
-        return "fp32"
-    if re.match(r"v_(rcp|rsq|sqrt|log|exp|sin|cos)_f32", op):
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    if re.match(r"v_(rcp|rsq|sqrt|log|exp|sin|cos)_f32", base):
         return "trans"
-    return "int"
+    if re.match(r"v_(fma|fmac|fmaak|fmamk|mul|add|sub|subrev|mac|mad)_f32$", base):
+        return "full"
+    if re.match(r"v_(add|sub|subrev)_(u32|i32|co_u32)$", base) or re.match(r"v_(lshrrev|lshlrev|ashrrev)_b32$", base) or \
+            re.match(r"v_(and|or|xor|not)_b32$", base) or re.match(r"v_(mov_b32|mov_b64|cndmask_b32|accvgpr)", base):
+        return "full"
+    return "half"
 
 
 def main():
@@ -65,7 +70,7 @@ def main():
     hot = max(per_loop, key=per_loop.get)
 
     def hist(bl):
-        h = {"fp32": 0, "pk": 0, "trans": 0, "int": 0}
+        h = {"full": 0, "half": 0, "trans": 0}
         other = {"salu": 0, "vmem": 0, "lds": 0}
         ops = {}
         for b in bl:

@@ -191,15 +191,7 @@ VPT_DEV float vpt_asinf(float x) {
 
 // ---- RNG: mixins/random/hash/pcg.glsl:3-7, squashlinear.glsl:7-9, distribution/*.glsl ---------
 VPT_DEV uint32_t pcg(uint32_t x) {
-#if defined(VPT_X) && (VPT_X & 32)
-    {   // experiment: multiply-add in one instruction (64-bit result, the low dword is x * A + C mod 2^32)
-        uint64_t r, c = 2891336453ull;
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(x), "s"(747796405u), "v"(c) : "vcc");
-        x = (uint32_t)r;
-    }
-#else
     x = x * 747796405u + 2891336453u;
-#endif
     x = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
     return (x >> 22u) ^ x;
 }
@@ -306,6 +298,9 @@ struct DevVolume {
     int filter;              // VPT_FILTER_*
     int channels;            // 1 = R8, 2 = RG8: the G brick follows the R brick in a 256-byte slot (R at +0, G at +128)
     uint32_t slot_shift;     // log2 of the slot size: 7 (R8) or 8 (RG8)
+    uint32_t elem_shift;     // log2 of the bytes per texel channel: 0 (UNSIGNED_BYTE) or 2 (FLOAT)
+    const uint32_t *atlas;   // boundary atlas (one-channel volumes; null: not built or switched off) — see sample_volume_boundary
+    uint32_t atlas_face, atlas_shift;   // dwords per face image, log2 of its row pitch
 };
 // LDS image of the per-workgroup tables: [tf pairs][TX][TY][TZ]
 struct LdsTables {
@@ -336,7 +331,7 @@ VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_
         // entries: 24 KB of LDS for 2048^3 where 64-bit byte offsets took 48 KB and halved the occupancy); the in-brick
         // offset costs five VALU instructions instead of riding along in the table
         uint32_t code = t.tx[x] + t.ty[y] + t.tz[z];
-        uint32_t intra = (x & 3u) + (y & 3u) * 5u + (z & 3u) * 25u;
+        uint32_t intra = ((x & 3u) + (y & 3u) * 5u + (z & 3u) * 25u) << v.elem_shift;
         return v.bricks + (((uint64_t)code << v.slot_shift) + intra);
     }
     return v.bricks + (uint32_t)(t.tx[x] + t.ty[y] + t.tz[z]);
@@ -347,6 +342,7 @@ VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_
 #define VPT_V_NEAREST 2
 #define VPT_V_ALIGNED 4   // fetch the two tap windows as dword-aligned 12-byte loads + v_alignbyte (texture-path bound kernels)
 #define VPT_V_FAST    16  // MCM / MCS: hardware rcp / rsq / sqrt / log / sin / cos and shorter algebraic forms (no bit-exact CPU twin; VPT_OPTION_FAST_MATH)
+#define VPT_V_F32     32  // FLOAT texels (R32F; R16F widened on upload): 5^3 floats in a 512-byte slot, no normalisation
 #define VPT_V_RG      8   // two-channel (RG8) volume: texture(uVolume, p).rg has both channels, the transfer function is looked up in 2-D
 // the eight taps around a cell of one channel's brick and their trilinear blend: taps +0,+1 (y,z) ; +5,+6 (y+1,z) ;
 // +25,+26 (y,z+1) ; +30,+31 (y+1,z+1) = two 8-byte windows of one line.
@@ -374,14 +370,8 @@ VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
         l1 = __builtin_amdgcn_alignbyte(q1.b, q1.a, s1); h1 = __builtin_amdgcn_alignbyte(q1.c, q1.b, s1);
     } else {
         uint64_t w0, w1;
-#if defined(VPT_X) && (VPT_X & 8)
-        typedef uint64_t u64_any __attribute__((aligned(1)));
-        w0 = __builtin_nontemporal_load((const u64_any *)a);
-        w1 = __builtin_nontemporal_load((const u64_any *)(a + 25));
-#else
         __builtin_memcpy(&w0, a, 8);
         __builtin_memcpy(&w1, a + 25, 8);
-#endif
         l0 = (uint32_t)w0; h0 = (uint32_t)(w0 >> 32); l1 = (uint32_t)w1; h1 = (uint32_t)(w1 >> 32);
     }
     // byte -> float straight out of the loaded dwords (v_cvt_f32_ubyteN: the byte select is free).  Written as opaque
@@ -398,33 +388,50 @@ VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
     float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
     return lerpf(c0, c1, fz) * VPT_INV255;
 }
-// The same sample in two steps — fetch (cell, LDS table look-ups, the two global loads) and blend (conversions + lerps) — so
-// that a caller can put independent work between the loads and their first use (k: mcm_events speculates resetPhoton there).
-struct TapFetch { uint32_t l0, h0, l1, h1; float fx, fy, fz; };
-template <int V>
-VPT_DEV TapFetch fetch_taps(const DevVolume &v, const LdsTables &t, f3 p) {
-    static_assert((V & (VPT_V_NEAREST | VPT_V_ALIGNED | VPT_V_RG)) == 0, "LINEAR one-channel unaligned form only");
-    TapFetch f;
-    uint32_t x, y, z;
-    linear_cell(p.x, v.fnx, v.hx, x, f.fx);
-    linear_cell(p.y, v.fny, v.hy, y, f.fy);
-    linear_cell(p.z, v.fnz, v.hz, z, f.fz);
-    const uint8_t *a = cell_addr<(V & VPT_V_WIDE) != 0>(v, t, x, y, z);
-    uint64_t w0, w1;
-    __builtin_memcpy(&w0, a, 8);
-    __builtin_memcpy(&w1, a + 25, 8);
-    f.l0 = (uint32_t)w0; f.h0 = (uint32_t)(w0 >> 32); f.l1 = (uint32_t)w1; f.h1 = (uint32_t)(w1 >> 32);
-    return f;
-}
-VPT_DEV float blend_taps(const TapFetch &f) {
-    float c000 = cvt_ubyte<0>(f.l0), c100 = cvt_ubyte<1>(f.l0);
-    float c010 = cvt_ubyte<1>(f.h0), c110 = cvt_ubyte<2>(f.h0);
-    float c001 = cvt_ubyte<0>(f.l1), c101 = cvt_ubyte<1>(f.l1);
-    float c011 = cvt_ubyte<1>(f.h1), c111 = cvt_ubyte<2>(f.h1);
-    float c00 = lerpf(c000, c100, f.fx), c10 = lerpf(c010, c110, f.fx);
-    float c01 = lerpf(c001, c101, f.fx), c11 = lerpf(c011, c111, f.fx);
-    float c0 = lerpf(c00, c10, f.fy), c1 = lerpf(c01, c11, f.fy);
-    return lerpf(c0, c1, f.fz) * VPT_INV255;
+// ---- boundary atlas ---------------------------------------------------------------------------------------------------
+// For a position with a coordinate outside [0, 1] (MCM samples before its bounds test, MCMRenderer.glsl:132-142) the clamped
+// filter cell of that axis k is u_k = 0 or N_k - 1 exactly: i_k is the first or last voxel plane and f_k = 0, so
+// lerp(a, b, 0) = fma(0, b - a, a) = a EXACTLY and the trilinear blend above equals the bilinear blend of four taps on that
+// plane, in the same x -> y -> z order of the remaining two axes.  The six boundary planes are kept a second time as "face
+// images" with the 2 x 2 footprint of every cell in ONE dword — [t(a,b), t(a+1,b), t(a,b+1), t(a+1,b+1)], indices clamped like
+// the bricks' apron — so such a sample costs one aligned 4-byte gather from a small table (6 MiB for 512^3; L2-resident)
+// instead of two unaligned 8-byte gathers from the bricks.  Face f = 2 * axis + side (side 1 = plane N_k - 1) starts at dword
+// f * atlas_face; cell (a, b) of a face sits at (b << atlas_shift) + a with (a, b) = (y, z), (x, z), (x, y) for axis x, y, z.
+// Precondition: some coordinate of p is > 1 or < 0 (not NaN) — the caller's bounds test.
+VPT_DEV float sample_volume_boundary(const DevVolume &v, f3 p) {
+    // (members copied into locals first: `c ? v.fny : v.fnx` on struct members is an lvalue conditional — a select of ADDRESSES
+    // into the kernel argument block, which then has to live in scratch memory: measured 5x slower)
+    const float fnx = v.fnx, fny = v.fny, fnz = v.fnz, hx = v.hx, hy = v.hy, hz = v.hz;
+    const uint32_t face = v.atlas_face, sh = v.atlas_shift;
+    const bool ox = (p.x > 1.0f) || (p.x < 0.0f);
+    const bool oy = (p.y > 1.0f) || (p.y < 0.0f);
+    // The face is the first out-of-range axis k; its side follows from the coordinate itself (p_k > 1: plane N_k - 1, p_k < 0:
+    // plane 0), so the clamped axis needs no filter cell at all.  The photons of a wave mostly leave through the same face
+    // (8 x 8 neighbouring pixels): the three wave-uniform cases are separate straight-line paths without per-lane selects,
+    // and only a wave whose lanes disagree takes the generic one.
+    const unsigned long long act = __ballot(1), bx = __ballot(ox), by = __ballot(oy);
+    uint32_t a, b, idx; float fa, fb;
+    if (bx == act) {
+        linear_cell(p.y, fny, hy, a, fa); linear_cell(p.z, fnz, hz, b, fb);
+        idx = (p.x > 1.0f ? face : 0u) + ((b << sh) + a);
+    } else if (bx == 0ull && by == act) {
+        linear_cell(p.x, fnx, hx, a, fa); linear_cell(p.z, fnz, hz, b, fb);
+        idx = (p.y > 1.0f ? 3u * face : 2u * face) + ((b << sh) + a);
+    } else if (bx == 0ull && by == 0ull) {
+        linear_cell(p.x, fnx, hx, a, fa); linear_cell(p.y, fny, hy, b, fb);
+        idx = (p.z > 1.0f ? 5u * face : 4u * face) + ((b << sh) + a);
+    } else {
+        const bool oxy = ox || oy;
+        const float pa = ox ? p.y : p.x, pb = oxy ? p.z : p.y;
+        linear_cell(pa, ox ? fny : fnx, ox ? hy : hx, a, fa);
+        linear_cell(pb, oxy ? fnz : fny, oxy ? hz : hy, b, fb);
+        const float pk = ox ? p.x : (oy ? p.y : p.z);
+        const uint32_t f = (ox ? 0u : (oy ? 2u : 4u)) + (pk > 1.0f ? 1u : 0u);
+        idx = f * face + ((b << sh) + a);
+    }
+    const uint32_t w = v.atlas[idx];
+    float c00 = cvt_ubyte<0>(w), c10 = cvt_ubyte<1>(w), c01 = cvt_ubyte<2>(w), c11 = cvt_ubyte<3>(w);
+    return lerpf(lerpf(c00, c10, fa), lerpf(c01, c11, fa), fb) * VPT_INV255;
 }
 // texture(uVolume, p).rg: r always, g only for RG8 volumes (V & VPT_V_RG; an R8 volume has g = 0).  The cell and its
 // brick address are computed once for both channels.
@@ -432,6 +439,24 @@ template <int V>
 VPT_DEV f2 sample_volume_rg(const DevVolume &v, const LdsTables &t, f3 p) {
     constexpr bool WIDE = (V & VPT_V_WIDE) != 0;
     constexpr bool RG = (V & VPT_V_RG) != 0;
+    if (V & VPT_V_F32) {
+        // FLOAT texels (Volume.js:84-105 `FLOAT` / `HALF_FLOAT`; LINEAR filtering of float textures: OES_texture_float_linear,
+        // RenderingContext.js:78): the brick holds 5^3 floats, a row's two taps are one dword-aligned 8-byte load; same
+        // x -> y -> z lerps, the value is used as it is (no normalisation)
+        if (V & VPT_V_NEAREST) {
+            uint32_t x = nearest_cell(p.x, v.fnx, v.hx), y = nearest_cell(p.y, v.fny, v.hy), z = nearest_cell(p.z, v.fnz, v.hz);
+            return f2{ *(const float *)cell_addr<WIDE>(v, t, x, y, z), 0.0f };
+        }
+        uint32_t x, y, z; float fx, fy, fz;
+        linear_cell(p.x, v.fnx, v.hx, x, fx);
+        linear_cell(p.y, v.fny, v.hy, y, fy);
+        linear_cell(p.z, v.fnz, v.hz, z, fz);
+        const float *b = (const float *)cell_addr<WIDE>(v, t, x, y, z);
+        float2 r00 = *(const float2 *)b, r10 = *(const float2 *)(b + 5), r01 = *(const float2 *)(b + 25), r11 = *(const float2 *)(b + 30);
+        float c00 = lerpf(r00.x, r00.y, fx), c10 = lerpf(r10.x, r10.y, fx);
+        float c01 = lerpf(r01.x, r01.y, fx), c11 = lerpf(r11.x, r11.y, fx);
+        return f2{ lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz), 0.0f };
+    }
     if (V & VPT_V_NEAREST) {
         uint32_t x = nearest_cell(p.x, v.fnx, v.hx), y = nearest_cell(p.y, v.fny, v.hy), z = nearest_cell(p.z, v.fnz, v.hz);
         const uint8_t *a = cell_addr<WIDE>(v, t, x, y, z);

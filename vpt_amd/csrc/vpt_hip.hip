@@ -47,7 +47,9 @@ struct vpt_context {
 struct vpt_volume {
     vpt_context *ctx;
     int nx, ny, nz;
-    int channels;          // 1 = R8, 2 = RG8 (interleaved)
+    int channels;          // 1 = R8 / R32F, 2 = RG8 (interleaved)
+    bool f32;              // FLOAT texels (VPT_FORMAT_R32F): 4 bytes per voxel, 512-byte brick slots
+    int vox_bytes;         // bytes per voxel of the linear storage: channels * (f32 ? 4 : 1)
     int filter;
     uint8_t *linear;       // nx*ny*nz*channels, the "texture storage" blocks are uploaded into
     uint8_t *bricks;       // apron bricks, Morton order
@@ -58,6 +60,9 @@ struct vpt_volume {
     bool dirty;            // blocks uploaded since the last brickify
     bool any_upload;
     uint8_t *staging; size_t staging_bytes;
+    uint32_t *atlas;       // boundary atlas: the six outer voxel planes as 2 x 2-footprint dwords (vpt_device.h sample_volume_boundary); one-channel volumes
+    size_t atlas_dwords;
+    uint32_t atlas_face, atlas_shift;   // dwords per face image (row pitch x rows), log2 of the row pitch
 };
 
 struct vpt_renderer {
@@ -87,6 +92,7 @@ struct vpt_renderer {
     float2 *dos_samples; int dos_nsamples;   // DOS: uOcclusionSamples (vpt_renderer_set_occlusion_samples)
     int dos_rect[4]; bool dos_rect_valid;   // DOS: tile rectangle [x0, y0, x1, y1) of the previous integrate call (see dos_tile_rect)
     int dos_cur;                   // DOS: which of the occlusion buffers st[2|3] holds the latest slice (colour: st[0], in place)
+    int boundary_atlas;            // VPT_OPTION_BOUNDARY_ATLAS (default 1): MCM takes out-of-cube samples from the volume's boundary atlas
     int fast_math;                 // VPT_OPTION_FAST_MATH: MCM events with hardware rcp / rsq / log / sin / cos (k_mcm_integrate<.., V | VPT_V_FAST>)
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
@@ -172,7 +178,7 @@ extern "C" int vpt_context_synchronize(vpt_context *c) {
 // ---------------------------------------------------------------------------------------------
 extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format, vpt_volume **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
-    if (format != VPT_FORMAT_R8 && format != VPT_FORMAT_RG8) return fail(VPT_ERR_UNSUPPORTED, "Unknown volume datatype: %d", format);  // Volume.js:103
+    if (format != VPT_FORMAT_R8 && format != VPT_FORMAT_RG8 && format != VPT_FORMAT_R32F) return fail(VPT_ERR_UNSUPPORTED, "Unknown volume datatype: %d", format);  // Volume.js:103
     if (w < 1 || h < 1 || d < 1 || w > 4096 || h > 4096 || d > 4096)
         return fail(VPT_ERR_INVALID, "volume dimensions %dx%dx%d out of range [1,4096]", w, h, d);
     HIP_TRY(hipSetDevice(c->device));
@@ -180,7 +186,10 @@ extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format
     memset(v, 0, sizeof(*v));
     v->ctx = c; v->nx = w; v->ny = h; v->nz = d;
     v->channels = format == VPT_FORMAT_RG8 ? 2 : 1;
-    const int slot_shift = v->channels == 2 ? 8 : 7;     // RG8: 256-byte slots, the R brick at +0 and the G brick at +128
+    v->f32 = format == VPT_FORMAT_R32F;
+    v->vox_bytes = v->channels * (v->f32 ? 4 : 1);
+    const int slot_shift = v->f32 ? 9 : (v->channels == 2 ? 8 : 7);   // RG8: 256-byte slots (R brick at +0, G brick at +128); R32F: 512-byte slots
+    const uint64_t eb = v->f32 ? 4 : 1;                  // bytes per texel channel
     v->filter = VPT_FILTER_LINEAR;                       // Volume.js:53-54
     int nbx = (w + 3) / 4, nby = (h + 3) / 4, nbz = (d + 3) / 4;
     // Z-order over the bricks with exactly as many bits per axis as the axis needs: the low bits of x, y, z interleave
@@ -194,20 +203,32 @@ extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format
     auto axis_code = [&](int ax, uint32_t b) { uint64_t c = 0; for (int k = 0; k < nbits[ax]; k++) c |= (uint64_t)((b >> k) & 1u) << bitpos[ax][k]; return c; };
     size_t max_slot = (size_t)(axis_code(0, (uint32_t)nbx - 1) | axis_code(1, (uint32_t)nby - 1) | axis_code(2, (uint32_t)nbz - 1));
     v->brick_bytes = (max_slot + 1) << slot_shift;
-    hipError_t e = hipMalloc(&v->linear, (size_t)w * h * d * v->channels);
+    hipError_t e = hipMalloc(&v->linear, (size_t)w * h * d * v->vox_bytes);
     if (e == hipSuccess) e = hipMalloc(&v->bricks, v->brick_bytes + 64);   // +64: the 8-byte tap windows end <= byte 125+7
+    if (e == hipSuccess && v->channels == 1 && !v->f32) {
+        // boundary atlas: six face images (axis x: ny x nz cells, y: nx x nz, z: nx x ny; low side, high side) with one common
+        // power-of-two row pitch and one common size, one dword per cell
+        int pitch = 1, shift = 0;
+        while (pitch < std::max(w, h)) { pitch <<= 1; shift++; }
+        v->atlas_shift = (uint32_t)shift;
+        v->atlas_face = (uint32_t)pitch * (uint32_t)std::max(h, d);
+        v->atlas_dwords = 6 * (size_t)v->atlas_face;
+        e = hipMalloc(&v->atlas, v->atlas_dwords * 4);
+    }
     if (e != hipSuccess) {
+        if (v->atlas) hipFree(v->atlas);
+        if (v->bricks) hipFree(v->bricks);
         if (v->linear) hipFree(v->linear);
         delete v;
         return fail(VPT_ERR_HIP, "hipMalloc volume %dx%dx%d: %s", w, h, d, hipGetErrorString(e));
     }
-    HIP_TRY(hipMemsetAsync(v->linear, 0, (size_t)w * h * d * v->channels, c->stream));   // texStorage3D zero-initialises
+    HIP_TRY(hipMemsetAsync(v->linear, 0, (size_t)w * h * d * v->vox_bytes, c->stream));   // texStorage3D zero-initialises
     {   // offset tables: off(x,y,z) = TX[x] + TY[y] + TZ[z]
         std::vector<uint64_t> t64((size_t)w + h + d);
         std::vector<uint32_t> t32(t64.size());
-        for (int i = 0; i < w; i++) t64[i] = (axis_code(0, (uint32_t)i >> 2) << slot_shift) + (uint64_t)(i & 3);
-        for (int i = 0; i < h; i++) t64[(size_t)w + i] = (axis_code(1, (uint32_t)i >> 2) << slot_shift) + (uint64_t)(i & 3) * 5;
-        for (int i = 0; i < d; i++) t64[(size_t)w + h + i] = (axis_code(2, (uint32_t)i >> 2) << slot_shift) + (uint64_t)(i & 3) * 25;
+        for (int i = 0; i < w; i++) t64[i] = (axis_code(0, (uint32_t)i >> 2) << slot_shift) + (uint64_t)(i & 3) * eb;
+        for (int i = 0; i < h; i++) t64[(size_t)w + i] = (axis_code(1, (uint32_t)i >> 2) << slot_shift) + (uint64_t)(i & 3) * 5 * eb;
+        for (int i = 0; i < d; i++) t64[(size_t)w + h + i] = (axis_code(2, (uint32_t)i >> 2) << slot_shift) + (uint64_t)(i & 3) * 25 * eb;
         for (size_t i = 0; i < t64.size(); i++) t32[i] = (uint32_t)t64[i];
         for (size_t i = 0; i < t64.size(); i++) t64[i] >>= slot_shift;     // the brick's Morton code alone (WIDE variant)
         std::vector<uint32_t> tc(t64.size());
@@ -226,13 +247,13 @@ static int volume_upload(vpt_volume *v, int x, int y, int z, int w, int h, int d
     if (!v || !data) return fail(VPT_ERR_INVALID, "null argument");
     if (w < 1 || h < 1 || d < 1 || x < 0 || y < 0 || z < 0 || x + w > v->nx || y + h > v->ny || z + d > v->nz)
         return fail(VPT_ERR_INVALID, "block (%d,%d,%d)+(%d,%d,%d) outside volume %dx%dx%d", x, y, z, w, h, d, v->nx, v->ny, v->nz);
-    size_t need = (size_t)w * h * d * v->channels;
+    size_t need = (size_t)w * h * d * v->vox_bytes;
     if (nbytes < need) return fail(VPT_ERR_INVALID, "block data too short: %zu < %zu", nbytes, need);
     vpt_context *c = v->ctx;
     HIP_TRY(hipSetDevice(c->device));
     bool full_xy = (x == 0 && y == 0 && w == v->nx && h == v->ny);
     if (full_xy) {   // contiguous run of z-slices (RAWReader.js:47-63 produces exactly these)
-        uint8_t *dst = v->linear + (size_t)z * v->nx * v->ny * v->channels;
+        uint8_t *dst = v->linear + (size_t)z * v->nx * v->ny * v->vox_bytes;
         HIP_TRY(hipMemcpyAsync(dst, data, need, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     } else {
         const uint8_t *src = (const uint8_t *)data;
@@ -245,8 +266,8 @@ static int volume_upload(vpt_volume *v, int x, int y, int z, int w, int h, int d
             HIP_TRY(hipMemcpyAsync(v->staging, data, need, hipMemcpyHostToDevice, c->stream));
             src = v->staging;
         }
-        int grid = (int)((need / v->channels + 255) / 256); if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(k_blit_block, dim3(grid), dim3(256), 0, c->stream, v->linear, v->nx, v->ny, src, x, y, z, w, h, d, v->channels);
+        int grid = (int)((need / v->vox_bytes + 255) / 256); if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(k_blit_block, dim3(grid), dim3(256), 0, c->stream, v->linear, v->nx, v->ny, src, x, y, z, w, h, d, v->vox_bytes);
         HIP_TRY(hipGetLastError());
     }
     if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));   // host buffer may be released by the caller
@@ -269,10 +290,18 @@ extern "C" int vpt_volume_finalize(vpt_volume *v) {
     const int strips = (nbx + VPT_BRICKIFY_RUN - 1) / VPT_BRICKIFY_RUN;
     // one-channel volumes with dword-aligned rows go through the LDS-staged kernel (dword loads and stores)
     int fast = (v->channels == 1 && v->nx % 4 == 0) ? strips : 0;
-    if (fast > 0)
+    if (v->f32) {
+        hipLaunchKernelGGL(k_brickify_f32, dim3((unsigned)strips, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, (const float *)v->linear, (float *)v->bricks, v->nx, v->ny, v->nz, v->tabc);
+        fast = strips;                                    // nothing left for the byte kernels
+    } else if (fast > 0)
         hipLaunchKernelGGL(k_brickify_strip, dim3((unsigned)fast, (unsigned)((nby + VPT_BRICKIFY_ROWS - 1) / VPT_BRICKIFY_ROWS), (unsigned)nbz), dim3(256), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->tabc);
     if (fast < strips)
         hipLaunchKernelGGL(k_brickify, dim3((unsigned)(strips - fast), (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->channels, v->tabc, fast * VPT_BRICKIFY_RUN);
+    if (v->atlas) {
+        size_t cells = (size_t)v->ny * v->nz + (size_t)v->nx * v->nz + (size_t)v->nx * v->ny;
+        hipLaunchKernelGGL(k_build_atlas, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, v->linear, v->atlas, v->nx, v->ny, v->nz,
+                           v->atlas_face, v->atlas_shift);
+    }
     HIP_TRY(hipGetLastError());
     v->dirty = false;
     return VPT_OK;
@@ -301,6 +330,7 @@ extern "C" int vpt_volume_destroy(vpt_volume *v) {
     renderers_unbind(v->ctx, v);              // a renderer still bound to it reports "no ready volume" instead of reading freed memory
     if (v->linear) hipFree(v->linear);
     if (v->bricks) hipFree(v->bricks);
+    if (v->atlas) hipFree(v->atlas);
     if (v->staging) hipFree(v->staging);
     if (v->tab32) hipFree(v->tab32);
     if (v->tabc) hipFree(v->tabc);
@@ -421,7 +451,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->ndc_x = r->ndc_y = nullptr;
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
-    r->fast_math = 0; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->fast_math = 0; r->boundary_atlas = 1; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -511,7 +541,10 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         a->vol.hx = (float)(v->nx - 1); a->vol.hy = (float)(v->ny - 1); a->vol.hz = (float)(v->nz - 1);
         a->vol.tab32 = v->tab32; a->vol.tabc = v->tabc;
         a->vol.filter = v->filter;
-        a->vol.channels = v->channels; a->vol.slot_shift = v->channels == 2 ? 8u : 7u;
+        a->vol.channels = v->channels; a->vol.slot_shift = v->f32 ? 9u : (v->channels == 2 ? 8u : 7u);
+        a->vol.elem_shift = v->f32 ? 2u : 0u;
+        a->vol.atlas = r->boundary_atlas ? v->atlas : nullptr;
+        a->vol.atlas_face = v->atlas_face; a->vol.atlas_shift = v->atlas_shift;
     }
     a->env.texels = r->env; a->env.w = r->env_w; a->env.h = r->env_h; a->env.constant = r->env_const;
     a->tf = r->tf; a->tf_w = r->tf_w; a->tf_h = r->tf_h; a->tf_fw = (float)r->tf_w; a->tf_hi = (float)(r->tf_w - 1);
@@ -564,7 +597,8 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
 }
 // the instantiation for (addressing, filter, channels): V = VPT_V_WIDE | VPT_V_NEAREST | VPT_V_RG bits
 static int variant_of(const vpt_renderer *r) {
-    return (r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0) | (r->vol->channels == 2 ? VPT_V_RG : 0);
+    return (r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0) | (r->vol->channels == 2 ? VPT_V_RG : 0) |
+           (r->vol->f32 ? VPT_V_F32 : 0);
 }
 #define LAUNCH_S(KT, r, a) do { \
     unsigned g_ = (unsigned)(r)->ntiles; \
@@ -576,7 +610,11 @@ static int variant_of(const vpt_renderer *r) {
         case 8: VPT_TRY(launch_sampling(KT(8), (r), (a), g_)); break; \
         case 9: VPT_TRY(launch_sampling(KT(9), (r), (a), g_)); break; \
         case 10: VPT_TRY(launch_sampling(KT(10), (r), (a), g_)); break; \
-        default: VPT_TRY(launch_sampling(KT(11), (r), (a), g_)); break; \
+        case 11: VPT_TRY(launch_sampling(KT(11), (r), (a), g_)); break; \
+        case 32: VPT_TRY(launch_sampling(KT(32), (r), (a), g_)); break; \
+        case 33: VPT_TRY(launch_sampling(KT(33), (r), (a), g_)); break; \
+        case 34: VPT_TRY(launch_sampling(KT(34), (r), (a), g_)); break; \
+        default: VPT_TRY(launch_sampling(KT(35), (r), (a), g_)); break; \
     } } while (0)
 #define K_MIP0(V) (k_mip<0, V | VPT_V_ALIGNED>)
 #define K_MIP1(V) (k_mip<1, V | VPT_V_ALIGNED>)
@@ -713,7 +751,7 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
             case VPT_RENDERER_ISO: LAUNCH_S(K_ISO0, r, a); break;
             case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH0, r, a); break;
             case VPT_RENDERER_LAO: LAUNCH_S(K_LAO0, r, a); break;
-            case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1) LAUNCH_MCS_PERSIST(0, r, a); else LAUNCH_S(K_MCS0, r, a); break;
+            case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCS_PERSIST(0, r, a); else LAUNCH_S(K_MCS0, r, a); break;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -734,7 +772,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_LAO: LAUNCH(k_lao_integrate, r, a, 0); break;
         case VPT_RENDERER_MCM: {
             Timed t(r, true);
-            if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(false, r, a); else if (r->fast_math) LAUNCH_S(K_MCM0F, r, a); else LAUNCH_S(K_MCM0, r, a);
+            if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCM_PERSIST(false, r, a); else if (r->fast_math) LAUNCH_S(K_MCM0F, r, a); else LAUNCH_S(K_MCM0, r, a);
             r->samples_host += r->valid_pixels * (uint64_t)u->steps;   // exactly W*H*steps per pass (MCMRenderer.glsl:129-133)
         } break;
     }
@@ -768,9 +806,9 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
         case VPT_RENDERER_ISO: LAUNCH_S(K_ISO1, r, a); break;
         case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH1, r, a); break;
         case VPT_RENDERER_LAO: LAUNCH_S(K_LAO1, r, a); break;
-        case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
+        case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
         case VPT_RENDERER_MCM:
-            if (r->mcm_persistent && r->vol->channels == 1) LAUNCH_MCM_PERSIST(true, r, a); else if (r->fast_math) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM1, r, a);
+            if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCM_PERSIST(true, r, a); else if (r->fast_math) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM1, r, a);
             break;
     }
     return VPT_OK;
@@ -866,7 +904,11 @@ static int launch_mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses
         case 8: return launch_multi(k_mcm_multi<8 | F>, r, a, npasses); \
         case 9: return launch_multi(k_mcm_multi<9 | F>, r, a, npasses); \
         case 10: return launch_multi(k_mcm_multi<10 | F>, r, a, npasses); \
-        default: return launch_multi(k_mcm_multi<11 | F>, r, a, npasses); }
+        case 11: return launch_multi(k_mcm_multi<11 | F>, r, a, npasses); \
+        case 32: return launch_multi(k_mcm_multi<32 | F>, r, a, npasses); \
+        case 33: return launch_multi(k_mcm_multi<33 | F>, r, a, npasses); \
+        case 34: return launch_multi(k_mcm_multi<34 | F>, r, a, npasses); \
+        default: return launch_multi(k_mcm_multi<35 | F>, r, a, npasses); }
     if (r->fast_math) MULTI_CASES(VPT_V_FAST)
     MULTI_CASES(0)
 #undef MULTI_CASES
@@ -1069,7 +1111,11 @@ static int launch_dos(vpt_renderer *r, PassArgs &a, const int rect[4]) {
         case 8: return launch_dos_slice(k_dos_slice<8>, r, a, rect);
         case 9: return launch_dos_slice(k_dos_slice<9>, r, a, rect);
         case 10: return launch_dos_slice(k_dos_slice<10>, r, a, rect);
-        default: return launch_dos_slice(k_dos_slice<11>, r, a, rect);
+        case 11: return launch_dos_slice(k_dos_slice<11>, r, a, rect);
+        case 32: return launch_dos_slice(k_dos_slice<32>, r, a, rect);
+        case 33: return launch_dos_slice(k_dos_slice<33>, r, a, rect);
+        case 34: return launch_dos_slice(k_dos_slice<34>, r, a, rect);
+        default: return launch_dos_slice(k_dos_slice<35>, r, a, rect);
     }
 }
 // _integrateFrame of the DOS renderer (DOSRenderer.js:199-259): `count` full-screen passes, pass s with
@@ -1116,6 +1162,7 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
     switch (option) {
         case VPT_OPTION_MCS_PERSISTENT: r->mcs_persistent = value != 0; return VPT_OK;
         case VPT_OPTION_MCM_PERSISTENT: r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
+        case VPT_OPTION_BOUNDARY_ATLAS: r->boundary_atlas = value != 0; return VPT_OK;
         case VPT_OPTION_FAST_MATH:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_FAST_MATH: only the MCM renderer has a fast-arithmetic variant");
             r->fast_math = value != 0; return VPT_OK;
@@ -1212,7 +1259,11 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
             case 8: hipLaunchKernelGGL(k_probe_sample<8>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
             case 9: hipLaunchKernelGGL(k_probe_sample<9>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
             case 10: hipLaunchKernelGGL(k_probe_sample<10>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            default: hipLaunchKernelGGL(k_probe_sample<11>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 11: hipLaunchKernelGGL(k_probe_sample<11>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 32: hipLaunchKernelGGL(k_probe_sample<32>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 33: hipLaunchKernelGGL(k_probe_sample<33>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 34: hipLaunchKernelGGL(k_probe_sample<34>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            default: hipLaunchKernelGGL(k_probe_sample<35>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
         }
         e = hipGetLastError();
     }

@@ -663,24 +663,6 @@ VPT_DEV void reset_photon(uint32_t &state, Photon &ph, float px, float py, const
     ph.position = madd3(from, tnear, ph.direction);
     ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
 }
-// the same with the first two uniforms (the disk sample's) already drawn by the caller
-VPT_DEV void reset_photon_drawn(uint32_t &state, float u1, float u2, Photon &ph, float px, float py, const PassArgs &a, f3 from0) {
-    f3 from = from0, to;
-    if (a.blur != 0.0f) {
-        float radius = sqrt_nr(u1), angle = 6.28318530718f * u2, sn, cs;
-        vpt_sincosf(angle, sn, cs);
-        from = dehomogenize(mat4_mul_point(a.mvp_inv, px + (radius * cs) * a.blur, py + (radius * sn) * a.blur, -1.0f));
-    }
-    float sx = random_uniform(state), sy = random_uniform(state);
-    float ax = fmaf(sx, 2.0f, -1.0f) * a.inv_w;
-    float ay = fmaf(sy, 2.0f, -1.0f) * a.inv_h;
-    to = dehomogenize(mat4_mul_point(a.mvp_inv, px + ax, py + ay, 1.0f));
-    ph.direction = normalize3(sub3(to, from));
-    ph.bounces = 0u;
-    float tnear = vmax(intersect_cube_near(from, ph.direction), 0.0f);
-    ph.position = madd3(from, tnear, ph.direction);
-    ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
-}
 // sampleHenyeyGreensteinAngleCosine: MCMRenderer.glsl:91-95
 VPT_DEV float hg_cos(uint32_t &state, float g) {
     float g2 = g * g;
@@ -697,21 +679,6 @@ VPT_DEV f3 sample_hg(uint32_t &state, float g, f3 dir) {
     c = normalize3(c);
     float s = sqrt_nr(fmaf(-hgcos, hgcos, 1.0f));
     return f3{ fmaf(s, c.x, hgcos * dir.x), fmaf(s, c.y, hgcos * dir.y), fmaf(s, c.z, hgcos * dir.z) };
-}
-VPT_DEV f3 sample_hg_drawn(uint32_t &state, float u1, float u2, float g, f3 dir) {
-    float radius0 = sqrt_nr(u1), angle = 6.28318530718f * u2, sn, cs;
-    vpt_sincosf(angle, sn, cs);
-    f2 d = { radius0 * cs, radius0 * sn };
-    float norm = fmaf(d.y, d.y, d.x * d.x);
-    float radius = 2.0f * sqrt_nr(1.0f - norm);
-    f3 u = { radius * d.x, radius * d.y, fmaf(-2.0f, norm, 1.0f) };
-    if (fabsf(g) < 1e-5f) return u;
-    float hgcos = hg_cos(state, g);
-    float ud = dot3(u, dir);
-    f3 c = { fmaf(-ud, dir.x, u.x), fmaf(-ud, dir.y, u.y), fmaf(-ud, dir.z, u.z) };
-    c = normalize3(c);
-    float sq = sqrt_nr(fmaf(-hgcos, hgcos, 1.0f));
-    return f3{ fmaf(sq, c.x, hgcos * dir.x), fmaf(sq, c.y, hgcos * dir.y), fmaf(sq, c.z, hgcos * dir.z) };
 }
 // radiance += (rad - radiance) / float(samples)   (MCMRenderer.glsl:147-150,154-157), as * (1/n)
 VPT_DEV void photon_deposit(Photon &ph, f3 rad) {
@@ -742,69 +709,37 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
 }
 
 // the `steps` delta-tracking events of one pixel on its persistent photon: MCMRenderer.glsl:128-166
-#ifndef VPT_X
-#define VPT_X 0            // experiment bits (A/B builds only; the shipped library is built with the default)
-#endif
-template <int V0>
+// sampleVolumeColor of an event.  The reference samples BEFORE its bounds test (MCMRenderer.glsl:132-142), so the sample of an
+// event that leaves the cube is taken at the clamped position (CLAMP_TO_EDGE) and then discarded.  It is executed here too, for
+// every lane (the empty asm keeps the compiler from proving it dead on the out-of-bounds path): an out-of-cube position has at
+// least one coordinate clamped onto the first or last voxel plane of its axis with weight 0 there, so its eight-tap footprint
+// degenerates to four taps on a face of the volume — fetched from the boundary atlas (vpt_device.h, sample_volume_boundary:
+// one aligned dword instead of two unaligned 8-byte gathers; bit-identical value).  At the benchmark camera 93 % of the events
+// end outside the cube (80 % of the pixels never meet it), and the pass was bound by the texture path's gather rate.
+template <int V>
+VPT_DEV float4 mcm_sample(const PassArgs &a, const LdsTables &t, f3 p, bool oob) {
+    float4 vs;
+    if (!(V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32)) && a.vol.atlas != nullptr && oob) vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, sample_volume_boundary(a.vol, p));
+    else vs = sample_volume_color<V>(a, t, p);
+    asm volatile("" : "+v"(vs.w));
+    return vs;
+}
+template <int V>
 VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
-    constexpr int V = V0 | ((VPT_X & 4) ? VPT_V_ALIGNED : 0);
     const f3 from0 = unproject_near(px, py, a);
 
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
     for (uint32_t s = 0u; s < a.steps; s++) {
         float dist = random_exponential(state, a.inv_extinction);
         ph.position = madd3(ph.position, dist, ph.direction);
-#if VPT_X & 64
-        // TIMING HACK (results wrong): what would one aligned dword gather from a small table cost for the out-of-cube samples?
-        float4 vs;
-        {
-            f3 q0 = ph.position;
-            bool oob0 = (vmax(vmax(q0.x, q0.y), q0.z) > 1.0f) || (vmin(vmin(q0.x, q0.y), q0.z) < 0.0f);
-            if (oob0) {
-                uint32_t iy, iz; float fy, fz;
-                linear_cell(q0.y, a.vol.fny, a.vol.hy, iy, fy);
-                linear_cell(q0.z, a.vol.fnz, a.vol.hz, iz, fz);
-                uint32_t w = *(const uint32_t *)(a.vol.bricks + (((iy * 512u + iz) & 0x3ffffu) << 2));
-                float c00 = cvt_ubyte<0>(w), c10 = cvt_ubyte<1>(w), c01 = cvt_ubyte<2>(w), c11 = cvt_ubyte<3>(w);
-                float r = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz) * VPT_INV255;
-                vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
-            } else {
-                vs = sample_volume_color<V>(a, t, ph.position);
-            }
-        }
-#else
-        float4 vs = sample_volume_color<V>(a, t, ph.position);
-#endif
+        f3 q = ph.position;
+        // any(greaterThan(pos, 1)) || any(lessThan(pos, 0)), NaN components compare false
+        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+        float4 vs = mcm_sample<V>(a, t, q, oob);
         float p_null = 1.0f - vs.w;
         float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
         float p_abs = 1.0f - p_null - p_scat;
         float wheel = random_uniform(state);
-        f3 q = ph.position;
-        // any(greaterThan(pos, 1)) || any(lessThan(pos, 0)), NaN components compare false
-        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
-#if VPT_X & 2
-        // Both non-null outcomes start by drawing two uniforms (resetPhoton -> unprojectRand's disk sample, scattering ->
-        // the sphere sample's disk): drawn ONCE for the lanes of either outcome, so a wave whose lanes split between the
-        // two pays for two PCG rounds instead of four.  Same draws in the same order per lane: results unchanged.
-        bool fin = oob || wheel < p_abs;
-        bool sct = !fin && wheel < p_abs + p_scat;
-        if (fin || sct) {
-            float u1 = random_uniform(state), u2 = random_uniform(state);
-            if (fin) {
-                f3 rad = { 0.0f, 0.0f, 0.0f };
-                if (oob) {
-                    float4 env = sample_environment(a.env, ph.direction);
-                    rad = f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z };
-                }
-                photon_deposit(ph, rad);
-                reset_photon_drawn(state, u1, u2, ph, px, py, a, from0);
-            } else {
-                ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
-                ph.direction = sample_hg_drawn(state, u1, u2, a.anisotropy, ph.direction);
-                ph.bounces++;
-            }
-        }
-#else
         if (oob || wheel < p_abs) {
             // out of bounds: radiance = transmittance * env; absorption: radiance = 0 — one shared deposit + resetPhoton
             f3 rad = { 0.0f, 0.0f, 0.0f };
@@ -814,49 +749,6 @@ VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float
             }
             photon_deposit(ph, rad);
             reset_photon(state, ph, px, py, a, from0);
-        } else if (wheel < p_abs + p_scat) {
-            ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
-            ph.direction = sample_hg(state, a.anisotropy, ph.direction);
-            ph.bounces++;
-        }
-#endif
-    }
-}
-// The same events with resetPhoton run SPECULATIVELY between the sample's loads and their first use.  A wave's event is a
-// dependent chain  draw -> position -> LDS tables -> brick line (global, ~1-2 us under load) -> blend -> transfer function ->
-// decision -> resetPhoton ; measured (rocprofv3 PMC, r02): VALU busy 84 %, yet a variant with a third fewer VALU instructions
-// is only 3 % faster — the pass is bound by the latency of that chain times the seven waves a SIMD holds, not by issue.
-// resetPhoton (MCMRenderer.glsl:70-78) needs the random stream only, not the sampled value, and 93 % of the events of the
-// benchmark scene end in it: computed on copies while the loads fly and committed by the decision, it leaves the chain.
-// Same operations on the same values, so every buffer stays bit-identical (tests/test_gpu_parity.py).
-template <int V>
-VPT_DEV void mcm_events_spec(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
-    const f3 from0 = unproject_near(px, py, a);
-    uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
-    for (uint32_t s = 0u; s < a.steps; s++) {
-        float dist = random_exponential(state, a.inv_extinction);
-        ph.position = madd3(ph.position, dist, ph.direction);
-        TapFetch taps = fetch_taps<V>(a.vol, t, ph.position);                 // loads in flight from here
-        float wheel = random_uniform(state);
-        f3 q = ph.position;
-        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
-        uint32_t st2 = state;
-        Photon sp = ph;
-        reset_photon(st2, sp, px, py, a, from0);                              // speculative: commits below
-        float4 vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, blend_taps(taps));     // first use of the loads
-        float p_null = 1.0f - vs.w;
-        float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
-        float p_abs = 1.0f - p_null - p_scat;
-        if (oob || wheel < p_abs) {
-            f3 rad = { 0.0f, 0.0f, 0.0f };
-            if (oob) {
-                float4 env = sample_environment(a.env, ph.direction);
-                rad = f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z };
-            }
-            photon_deposit(ph, rad);
-            state = st2;
-            ph.position = sp.position; ph.direction = sp.direction;
-            ph.bounces = 0u; ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
         } else if (wheel < p_abs + p_scat) {
             ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
             ph.direction = sample_hg(state, a.anisotropy, ph.direction);
@@ -915,13 +807,13 @@ VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, 
     for (uint32_t s = 0u; s < a.steps; s++) {
         float dist = hw_log2(pcg_float(state) * 0x1p-32f) * ld;
         ph.position = madd3(ph.position, dist, ph.direction);
-        float4 vs = sample_volume_color<V>(a, t, ph.position);
+        f3 q = ph.position;
+        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+        float4 vs = mcm_sample<V>(a, t, q, oob);
         float p_null = 1.0f - vs.w;
         float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
         float p_abs = 1.0f - p_null - p_scat;
         float wheel = pcg_float(state) * 0x1p-32f;
-        f3 q = ph.position;
-        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
         if (oob || wheel < p_abs) {
             f3 rad = { 0.0f, 0.0f, 0.0f };
             if (oob) {
@@ -1032,7 +924,6 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     Photon ph = photon_unpack(s0, s1, s2, s3);
     if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
-    else if ((VPT_X & 128) && !(V & (VPT_V_NEAREST | VPT_V_RG))) mcm_events_spec<V & ~(VPT_V_NEAREST | VPT_V_RG)>(a, t, ph, px, py);
     else mcm_events<V>(a, t, ph, px, py);
     a.st0[p.k] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
     a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
@@ -1065,8 +956,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     for (uint32_t f = 0; f < npasses; f++) {
         a.seed = a.frame_table[(base + f) & a.frame_mask].seed;
         if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
-        else if ((VPT_X & 128) && !(V & (VPT_V_NEAREST | VPT_V_RG))) mcm_events_spec<V & ~(VPT_V_NEAREST | VPT_V_RG)>(a, t, ph, px, py);
-    else mcm_events<V>(a, t, ph, px, py);
+        else mcm_events<V>(a, t, ph, px, py);
         // the unfused sequence stores the counters as floats between passes and re-reads them with uint(w + 0.5):
         // identical for every count below 2^24
     }
@@ -1175,6 +1065,48 @@ __global__ void __launch_bounds__(256) k_brickify_strip(const uint8_t *lin, uint
         }
         size_t slot = (size_t)(codes[x0 + 4 * ux] + codes[nx + 4 * (by0 + uy)] + cz) << 7;
         *(uint32_t *)(bricks + slot + 4 * w) = out;
+    }
+}
+
+// FLOAT volumes: linear floats -> 5^3-float apron bricks in 512-byte slots (slot = brick code << 9); VPT_BRICKIFY_RUN bricks of a
+// brick row per workgroup, thread t < 125 carries local voxel t of each
+__global__ void __launch_bounds__(128) k_brickify_f32(const float *lin, float *bricks, int nx, int ny, int nz, const uint32_t *codes) {
+    const int by = (int)blockIdx.y, bz = (int)blockIdx.z, t = (int)threadIdx.x;
+    if (t >= 125) return;
+    const int nbx = (nx + VPT_BRICK - 1) / VPT_BRICK;
+    const int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
+    const int y = min(by * VPT_BRICK + ly, ny - 1), z = min(bz * VPT_BRICK + lz, nz - 1);
+    const size_t row = ((size_t)z * ny + y) * nx;
+    const uint32_t cyz = codes[nx + 4 * by] + codes[nx + ny + 4 * bz];
+    for (int u = 0; u < VPT_BRICKIFY_RUN; u++) {
+        int bx = (int)blockIdx.x * VPT_BRICKIFY_RUN + u;
+        if (bx >= nbx) break;
+        int x = min(bx * VPT_BRICK + lx, nx - 1);
+        bricks[((size_t)(codes[4 * bx] + cyz) << 7) + t] = lin[row + x];       // 128 floats per slot
+    }
+}
+
+// boundary atlas (vpt_device.h sample_volume_boundary): thread c of [0, cx + cy + cz) builds cell c of the low-side AND the
+// high-side face of its axis from the linear volume.  Face x: cells (a, b) = (y, z); y: (x, z); z: (x, y); face f = 2 * axis +
+// side at dword f * face, cell (a, b) at (b << shift) + a.
+__global__ void __launch_bounds__(256) k_build_atlas(const uint8_t *lin, uint32_t *atlas, int nx, int ny, int nz, uint32_t face, uint32_t shift) {
+    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t cx = (size_t)ny * nz, cy = (size_t)nx * nz, cz = (size_t)nx * ny;
+    int axis, na, nb;
+    if (c < cx) { axis = 0; na = ny; nb = nz; }
+    else if (c < cx + cy) { axis = 1; c -= cx; na = nx; nb = nz; }
+    else if (c < cx + cy + cz) { axis = 2; c -= cx + cy; na = nx; nb = ny; }
+    else return;
+    const int a = (int)(c % (size_t)na), b = (int)(c / (size_t)na);
+    const int a1 = min(a + 1, na - 1), b1 = min(b + 1, nb - 1);
+    const int nk = axis == 0 ? nx : (axis == 1 ? ny : nz);
+    for (int side = 0; side < 2; side++) {
+        const int k = side ? nk - 1 : 0;
+        auto vox = [&](int p, int q) -> uint32_t {
+            int x = axis == 0 ? k : p, y = axis == 0 ? p : (axis == 1 ? k : q), z = axis == 2 ? k : q;
+            return lin[((size_t)z * ny + y) * nx + x];
+        };
+        atlas[(size_t)(2 * axis + side) * face + ((size_t)b << shift) + a] = vox(a, b) | (vox(a1, b) << 8) | (vox(a, b1) << 16) | (vox(a1, b1) << 24);
     }
 }
 

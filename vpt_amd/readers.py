@@ -14,6 +14,8 @@ from .loaders import AbstractLoader, BlobLoader
 # WebGL2 enums carried by reader metadata (RAWReader.js:36-38)
 GL_RED, GL_R8, GL_UNSIGNED_BYTE = 6403, 33321, 5121
 GL_RG, GL_RG8 = 33319, 33323              # two-channel volumes (value + e.g. gradient magnitude) of BVP manifests
+GL_RGB, GL_RGB8, GL_RGBA, GL_RGBA8 = 6407, 32849, 6408, 32856      # byte manifests with more channels: texture(uVolume, p).rg reads the first two
+GL_FLOAT, GL_HALF_FLOAT, GL_R32F, GL_R16F = 5126, 5131, 33326, 33325   # float volumes (Volume.js:84-105 maps FLOAT -> Float32Array, HALF_FLOAT -> Uint16Array)
 
 
 class AbstractReader:

@@ -157,6 +157,41 @@ class AbstractRenderer(PropertyBag):
     def _renderFrame(self): pass
     def _renderFused(self): pass
 
+    # ---- buffer specs (AbstractRenderer.js:134-155 and the subclasses' _get*BufferSpec) --------------------
+    # In the reference these lists drive the allocation of the WebGL attachments (_rebuildBuffers, :78-92); here the native
+    # renderer owns the HIP buffers and the hooks DESCRIBE them with the reference's GL enums: one dict per attachment, in
+    # attachment order (what vpt_renderer_read returns for BUFFER_FRAME / BUFFER_ACCUM / BUFFER_MCM_* / BUFFER_RENDER).
+    _GL = {'NEAREST': 9728, 'CLAMP_TO_EDGE': 33071, 'RED': 6403, 'RG': 33319, 'RGBA': 6408, 'R8': 33321, 'R32F': 33326, 'RG32F': 33328,
+           'RGBA16F': 34842, 'RGBA32F': 34836, 'UNSIGNED_BYTE': 5121, 'FLOAT': 5126}
+    _BUFFER_FORMATS = {          # kind -> (frame attachments, accumulation attachments) as (format, iformat, type)
+        N.RENDERER_MIP: ([('RED', 'R8', 'UNSIGNED_BYTE')], [('RED', 'R8', 'UNSIGNED_BYTE')]),                     # MIPRenderer.js:133-157
+        N.RENDERER_EAM: ([('RGBA', 'RGBA', 'UNSIGNED_BYTE')], [('RGBA', 'RGBA', 'UNSIGNED_BYTE')]),                # EAMRenderer.js:155-179
+        N.RENDERER_LAO: ([('RGBA', 'RGBA', 'UNSIGNED_BYTE')], [('RGBA', 'RGBA', 'UNSIGNED_BYTE')]),                # LAORenderer.js
+        N.RENDERER_MCS: ([('RGBA', 'RGBA32F', 'FLOAT')], [('RGBA', 'RGBA32F', 'FLOAT')]),                          # MCSRenderer.js:156-180
+        N.RENDERER_MCM: ([('RGBA', 'RGBA32F', 'FLOAT')], [('RGBA', 'RGBA32F', 'FLOAT')] * 4),                      # MCMRenderer.js:201-263
+        N.RENDERER_ISO: ([('RGBA', 'RGBA16F', 'FLOAT')], [('RGBA', 'RGBA16F', 'FLOAT')]),                          # ISORenderer.js
+        N.RENDERER_DEPTH: ([('RED', 'R32F', 'FLOAT')], [('RED', 'R32F', 'FLOAT')]),                                # DepthRenderer.js
+        N.RENDERER_DOS: ([('RGBA', 'RGBA32F', 'FLOAT')], [('RGBA', 'RGBA32F', 'FLOAT'), ('RED', 'R32F', 'FLOAT')]),   # DOSRenderer.js:277-305
+    }
+
+    def _spec(self, fmt):
+        g = self._GL
+        w, h = self._size()
+        return {'width': w, 'height': h, 'min': g['NEAREST'], 'mag': g['NEAREST'],
+                'format': g[fmt[0]], 'iformat': g[fmt[1]] if fmt[1] in g else g['RGBA'], 'type': g[fmt[2]]}
+
+    def _getFrameBufferSpec(self):
+        return [self._spec(f) for f in self._BUFFER_FORMATS[self._KIND][0]]
+
+    def _getAccumulationBufferSpec(self):
+        return [self._spec(f) for f in self._BUFFER_FORMATS[self._KIND][1]]
+
+    def _getRenderBufferSpec(self):                                # AbstractRenderer.js:142-155
+        g = self._GL
+        d = self._spec(('RGBA', 'RGBA16F', 'FLOAT'))
+        d['wrapS'] = d['wrapT'] = g['CLAMP_TO_EDGE']
+        return [d]
+
     # ---- extensions: read-back and counters -----------------------------------------------------
     def local_rows(self):
         n = C.c_int(0)

@@ -7,7 +7,23 @@ import numpy as np
 from . import _native as N
 from .property_bag import EventTarget, CustomEvent
 
-from .readers import RAWReader, GL_RED, GL_R8, GL_RG, GL_RG8, GL_UNSIGNED_BYTE      # noqa: F401  (re-exported: the in-memory RAW form lives in readers.py)
+from .readers import (RAWReader, GL_RED, GL_R8, GL_RG, GL_RG8, GL_UNSIGNED_BYTE, GL_RGB, GL_RGB8, GL_RGBA, GL_RGBA8,      # noqa: F401  (re-exported)
+                      GL_FLOAT, GL_HALF_FLOAT, GL_R32F, GL_R16F)
+
+
+def device_format(modality):
+    """(native format, channels in the file, numpy dtype of a block) for a manifest's (format, type) — Volume.js:58-60 allocates whatever
+    internalFormat the manifest names and :84-105 `_typize` maps the GL type to a typed array.  What a WebGL2 sampler3D can
+    filter is what is taken here: UNSIGNED_BYTE with 1-4 channels (the shaders read .rg: channels past the second are
+    dropped on upload) and FLOAT / HALF_FLOAT with one channel (R32F / R16F; half widens to float exactly).  Integer and
+    16-bit normalised types cannot be sampled through a float sampler in WebGL2 and raise the reference's error."""
+    t, f = modality['type'], modality['format']
+    if t == GL_UNSIGNED_BYTE and f in (GL_RED, GL_RG, GL_RGB, GL_RGBA):
+        n = {GL_RED: 1, GL_RG: 2, GL_RGB: 3, GL_RGBA: 4}[f]
+        return (N.FORMAT_R8 if n == 1 else N.FORMAT_RG8), n, np.uint8
+    if t in (GL_FLOAT, GL_HALF_FLOAT) and f == GL_RED:
+        return N.FORMAT_R32F, 1, (np.float32 if t == GL_FLOAT else np.float16)
+    raise RuntimeError('Unknown volume datatype: %s' % t)                   # Volume.js:103
 
 
 class Volume(EventTarget):
@@ -47,20 +63,24 @@ class Volume(EventTarget):
             L.vpt_volume_destroy(self.texture)
             self.texture = None
         dims = modality['dimensions']
-        if modality['type'] != GL_UNSIGNED_BYTE or modality['format'] not in (GL_RED, GL_RG):
-            raise RuntimeError('Unknown volume datatype: %s' % modality['type'])    # Volume.js:103
-        fmt, channels = (N.FORMAT_RG8, 2) if modality['format'] == GL_RG else (N.FORMAT_R8, 1)
+        fmt, nch, dtype = device_format(modality)
         h = C.c_void_p()
         N.check(L.vpt_volume_create(self._gl._h, dims['width'], dims['height'], dims['depth'], fmt, C.byref(h)))
         self.texture = h
         placements = modality['placements']
         for placement in placements:
             index, position = placement['index'], placement['position']
-            data = np.ascontiguousarray(self._reader.readBlock(index), dtype=np.uint8)
+            raw = self._reader.readBlock(index)
             bd = self.metadata['blocks'][index]['dimensions']
+            data = np.frombuffer(raw, dtype=dtype) if isinstance(raw, (bytes, bytearray, memoryview)) else np.asarray(raw).view(dtype).reshape(-1)
+            if nch > 2:                                   # RGB8 / RGBA8: texture(uVolume, p).rg reads the first two channels
+                data = data.reshape(-1, nch)[:, :2]
+            if dtype is not np.uint8:
+                data = data.astype(np.float32)            # HALF_FLOAT widens exactly
+            data = np.ascontiguousarray(data)
             N.check(L.vpt_volume_upload_block(self.texture, position['x'], position['y'], position['z'],
                                               bd['width'], bd['height'], bd['depth'],
-                                              data.ctypes.data_as(C.c_void_p), data.size))
+                                              data.ctypes.data_as(C.c_void_p), data.nbytes))
             progress = (index + 1) / len(placements)
             self.dispatchEvent(CustomEvent('progress', {'detail': progress}))
         N.check(L.vpt_volume_finalize(self.texture))
@@ -80,29 +100,35 @@ class Volume(EventTarget):
     # ---- extension: whole-array upload (one block) for synthetic volumes ----
     @classmethod
     def from_array(cls, gl, array, filter='linear'):
-        """Upload a [depth][height][width] (R8) or [depth][height][width][2] (RG8) uint8 array (host -> HBM once)."""
-        array = np.ascontiguousarray(array, dtype=np.uint8)
-        if array.ndim == 4 and array.shape[3] != 2:
-            raise ValueError('a two-channel volume is [depth][height][width][2]')
+        """Upload a [depth][height][width] (R8; float16 / float32: R32F) or [depth][height][width][2] (RG8) array (host -> HBM once)."""
+        array = np.asarray(array)
+        f32 = array.dtype.kind == 'f'
+        array = np.ascontiguousarray(array, dtype=np.float32 if f32 else np.uint8)
+        if array.ndim == 4 and (array.shape[3] != 2 or f32):
+            raise ValueError('a two-channel volume is [depth][height][width][2] uint8')
         d, h, w = array.shape[:3]
         channels = 2 if array.ndim == 4 else 1
-        vol = cls(gl, RAWReader(array, {'width': w * channels, 'height': h, 'depth': d}))      # slices of w * channels bytes
+        vox = channels * (4 if f32 else 1)
+        vol = cls(gl, RAWReader(array.view(np.uint8), {'width': w * vox, 'height': h, 'depth': d}))      # slices of w * vox bytes
         L = N.lib()
         hnd = C.c_void_p()
-        N.check(L.vpt_volume_create(gl._h, w, h, d, N.FORMAT_RG8 if channels == 2 else N.FORMAT_R8, C.byref(hnd)))
+        N.check(L.vpt_volume_create(gl._h, w, h, d, N.FORMAT_R32F if f32 else (N.FORMAT_RG8 if channels == 2 else N.FORMAT_R8), C.byref(hnd)))
         vol.texture = hnd
         # chunk along z so one call stays < 2 GiB
-        zs = max(1, (1 << 30) // (w * h * channels))
+        zs = max(1, (1 << 30) // (w * h * vox))
         for z0 in range(0, d, zs):
             z1 = min(d, z0 + zs)
             chunk = array[z0:z1]
-            N.check(L.vpt_volume_upload_block(hnd, 0, 0, z0, w, h, z1 - z0, chunk.ctypes.data_as(C.c_void_p), chunk.size))
+            N.check(L.vpt_volume_upload_block(hnd, 0, 0, z0, w, h, z1 - z0, chunk.ctypes.data_as(C.c_void_p), chunk.nbytes))
         N.check(L.vpt_volume_finalize(hnd))
         vol.metadata = vol._reader.readMetadata()
         vol.modality = vol.metadata['modalities'][0]
-        if channels == 2:                                   # the slices were handed over as w * 2 bytes wide: restore the description
+        if vox > 1:                                         # the slices were handed over as w * vox bytes wide: restore the description
             vol.modality['dimensions']['width'] = w
-            vol.modality['format'], vol.modality['internalFormat'] = GL_RG, GL_RG8
+            if f32:
+                vol.modality['format'], vol.modality['internalFormat'], vol.modality['type'] = GL_RED, GL_R32F, GL_FLOAT
+            else:
+                vol.modality['format'], vol.modality['internalFormat'] = GL_RG, GL_RG8
             for b in vol.metadata['blocks']:
                 b['dimensions']['width'] = w
         vol.ready = True
