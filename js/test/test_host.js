@@ -91,6 +91,18 @@ assert.strictEqual(vpt.RendererFactory('dos'), vpt.DOSRenderer);
 assert.strictEqual(vpt.RendererFactory('lao'), vpt.LAORenderer);
 assert.strictEqual(vpt.RendererFactory('iso'), vpt.ISORenderer); assert.strictEqual(vpt.RendererFactory('depth'), vpt.DepthRenderer);
 assert.strictEqual(vpt.RendererFactory('mcm'), vpt.MCMRenderer);
+// buffer spec hooks (AbstractRenderer.js:134-155): attachment counts and GL enums, without creating a native renderer
+{
+    const mk = (cls, size) => { const o = Object.create(cls.prototype); o._size = () => size; return o; };
+    const m = mk(vpt.MCMRenderer, [40, 30]);
+    assert.strictEqual(m._getAccumulationBufferSpec().length, 4);
+    assert.strictEqual(m._getAccumulationBufferSpec()[3].iformat, 34836);          // RGBA32F
+    assert.strictEqual(m._getFrameBufferSpec()[0].width, 40);
+    assert.strictEqual(m._getRenderBufferSpec()[0].iformat, 34842);                // RGBA16F
+    assert.strictEqual(mk(vpt.MIPRenderer, [8, 8])._getFrameBufferSpec()[0].iformat, 33321);   // R8
+    assert.strictEqual(mk(vpt.DOSRenderer, [8, 8])._getAccumulationBufferSpec().length, 2);
+    assert.strictEqual(mk(vpt.DepthRenderer, [8, 8])._getAccumulationBufferSpec()[0].iformat, 33326);   // R32F
+}
 // the addon loads and reports the struct size the JS side packs
 const { native } = require('../vpt/native.js');
 assert.strictEqual(native().UNIFORMS_BYTES, vpt.U.SIZE);

@@ -376,6 +376,42 @@ def test_mcm_boundary_atlas_is_bit_identical_to_the_bricks(gpu_ctx, oracle, dims
     sc.gvol.destroy()
 
 
+@pytest.mark.parametrize("fast", [0, 1])
+def test_mcm_split_streams_give_identical_buffers(gpu_ctx, oracle, fast):
+    """VPT_OPTION_SPLIT_STREAMS = 2: every pass as two tile-row ranges on two HIP streams — with reads, a reset, a transfer
+    function change and a tone mapper in between (each joins the side stream), every buffer equals the one-stream run's"""
+    sc = Scene(gpu_ctx, oracle, 32, 176, 150, tf=colour_tf(64, 1), camera=orbit_camera(176 / 150))
+
+    def run(split):
+        r = sc.renderer('mcm')
+        r.set_option(N.OPTION_FAST_MATH, fast)
+        r.set_option(N.OPTION_SPLIT_STREAMS, split)
+        r.extinction = 5; r.steps = 6
+        r.reset()
+        outs = []
+        for k in range(7):
+            r.render()
+            if k in (0, 4):
+                outs.append(r.read(N.BUFFER_MCM_RADIANCE).copy())      # a join in the middle of a sequence
+        tm = vpt_amd.ToneMapperFactory('artistic')(gpu_ctx, r, {'resolution': (sc.w, sc.h)})
+        tm.render(); outs.append(tm.getTexture().copy()); tm.destroy()
+        r.setTransferFunction(ramp_tf(32))
+        r.reset()                                                        # reset kernel on the context's stream, then split passes again
+        for k in range(3):
+            r.render()
+        outs += [r.read(b).copy() for b in MCM_BUFFERS] + [r.getTexture().copy()]
+        assert r.sample_count() == sc.w * sc.h * 6 * 10
+        gpu_ctx.synchronize()
+        r.destroy()
+        return outs
+
+    a, b = run(1), run(2)
+    assert len(a) == len(b)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert_same_bits(y, x, "split streams, output %d" % k)
+    sc.gvol.destroy()
+
+
 @pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "mcm"])
 def test_wide_offset_tables_variant(gpu_ctx, oracle, kind):
     """the 64-bit brick-offset-table kernels (used above 4 GiB of bricked data, e.g. 2048^3) forced on a small volume"""

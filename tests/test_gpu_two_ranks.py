@@ -1,0 +1,40 @@
+"""GPU (needs TWO GPUs in the box; skipped on the one-GPU boxes of the pool): the native RCCL gather pipeline with a real
+two-rank communicator — the rooted grouped ncclSend / ncclRecv path, the in-place render into the root's receive slot, the
+all_gather path and the ring's reverse edge, none of which a one-rank communicator executes (vpt_hip.hip gather_enqueue_frame).
+Two fresh child processes are started before anything in them touches a GPU (tests/two_rank_worker.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()                     # does not initialise the GPU
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs (the pool's boxes have one): run on the multi-GPU node")
+def test_native_gather_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("two-rank gather did not finish in 300 s (a hung collective?)")
+        outs.append(out.decode())
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)

@@ -11,6 +11,7 @@ OPTION_MCS_PERSISTENT = 0
 OPTION_MCM_PERSISTENT = 1
 OPTION_FAST_MATH = 2
 OPTION_BOUNDARY_ATLAS = 3
+OPTION_SPLIT_STREAMS = 4
 PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED = 0, 1, 2
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO, RENDERER_DOS = 0, 1, 2, 3, 4, 5, 6, 7
 FILTER_NEAREST, FILTER_LINEAR = 0, 1

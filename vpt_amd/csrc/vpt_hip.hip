@@ -92,6 +92,10 @@ struct vpt_renderer {
     float2 *dos_samples; int dos_nsamples;   // DOS: uOcclusionSamples (vpt_renderer_set_occlusion_samples)
     int dos_rect[4]; bool dos_rect_valid;   // DOS: tile rectangle [x0, y0, x1, y1) of the previous integrate call (see dos_tile_rect)
     int dos_cur;                   // DOS: which of the occlusion buffers st[2|3] holds the latest slice (colour: st[0], in place)
+    // VPT_OPTION_SPLIT_STREAMS: the MCM pass is launched as two tile-row ranges, the second on a private side stream.  A pixel's pass
+    // depends on its own previous pass only, so the two ranges never wait for each other: the launch gap, ramp and tail of one
+    // overlap the body of the other.  Every other entry point joins the side stream into the context's stream first.
+    int split; hipStream_t side; hipEvent_t ev_fork, ev_join; bool side_busy, main_dirty;
     int boundary_atlas;            // VPT_OPTION_BOUNDARY_ATLAS (default 1): MCM takes out-of-cube samples from the volume's boundary atlas
     int fast_math;                 // VPT_OPTION_FAST_MATH: MCM events with hardware rcp / rsq / log / sin / cos (k_mcm_integrate<.., V | VPT_V_FAST>)
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
@@ -166,9 +170,11 @@ extern "C" int vpt_context_destroy(vpt_context *c) {
     delete c;
     return VPT_OK;
 }
+static int join_side(struct vpt_renderer *r);
 extern "C" int vpt_context_synchronize(vpt_context *c) {
     if (!c) return fail(VPT_ERR_INVALID, "context is null");
     HIP_TRY(hipSetDevice(c->device));
+    for (vpt_renderer *r : c->renderers) VPT_TRY(join_side(r));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VPT_OK;
 }
@@ -251,6 +257,7 @@ static int volume_upload(vpt_volume *v, int x, int y, int z, int w, int h, int d
     if (nbytes < need) return fail(VPT_ERR_INVALID, "block data too short: %zu < %zu", nbytes, need);
     vpt_context *c = v->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    for (vpt_renderer *r : c->renderers) if (r->vol == v) VPT_TRY(join_side(r));
     bool full_xy = (x == 0 && y == 0 && w == v->nx && h == v->ny);
     if (full_xy) {   // contiguous run of z-slices (RAWReader.js:47-63 produces exactly these)
         uint8_t *dst = v->linear + (size_t)z * v->nx * v->ny * v->vox_bytes;
@@ -326,6 +333,7 @@ static void renderers_unbind(vpt_context *c, vpt_volume *v);
 extern "C" int vpt_volume_destroy(vpt_volume *v) {
     if (!v) return VPT_OK;
     hipSetDevice(v->ctx->device);
+    for (vpt_renderer *r : v->ctx->renderers) if (r->vol == v) join_side(r);
     hipStreamSynchronize(v->ctx->stream);
     renderers_unbind(v->ctx, v);              // a renderer still bound to it reports "no ready volume" instead of reading freed memory
     if (v->linear) hipFree(v->linear);
@@ -414,6 +422,7 @@ static int upload_table(vpt_context *c, float4 **dst, const std::vector<float4> 
 }
 extern "C" int vpt_renderer_set_transfer_function(vpt_renderer *r, const uint8_t *rgba, int w, int h) {
     if (!r || !rgba) return fail(VPT_ERR_INVALID, "null argument");
+    VPT_TRY(join_side(r));
     if (w < 1 || h < 1 || w > 2048 || h > 4096) return fail(VPT_ERR_INVALID, "transfer function size %dx%d out of range", w, h);
     // SRGB8_ALPHA8: rgb decoded before filtering, alpha linear (AbstractRenderer.js:36,99-104)
     std::vector<float4> t((size_t)w * h);
@@ -426,6 +435,7 @@ extern "C" int vpt_renderer_set_transfer_function(vpt_renderer *r, const uint8_t
 }
 extern "C" int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba, int w, int h) {
     if (!r || !rgba) return fail(VPT_ERR_INVALID, "null argument");
+    VPT_TRY(join_side(r));
     if (w < 1 || h < 1 || w > 16384 || h > 16384) return fail(VPT_ERR_INVALID, "environment size %dx%d out of range", w, h);
     std::vector<float4> t((size_t)w * h);
     for (size_t i = 0; i < t.size(); i++)
@@ -451,7 +461,8 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->ndc_x = r->ndc_y = nullptr;
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
-    r->fast_math = 0; r->boundary_atlas = 1; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->fast_math = 0; r->boundary_atlas = 1;
+    r->split = 1; r->side = nullptr; r->ev_fork = r->ev_join = nullptr; r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -471,6 +482,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
 static void tonemappers_unbind(vpt_context *c, vpt_renderer *r);
 extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (!r) return VPT_OK;
+    join_side(r);
     hipSetDevice(r->ctx->device);
     hipStreamSynchronize(r->ctx->stream);
     tonemappers_unbind(r->ctx, r);            // a tone mapper still bound to this renderer falls back to the white placeholder
@@ -485,6 +497,7 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (r->frame_table) hipFree(r->frame_table);
     if (r->frame_staging) hipHostFree(r->frame_staging);
     if (r->frame_counter) hipFree(r->frame_counter);
+    if (r->side) { hipStreamDestroy(r->side); hipEventDestroy(r->ev_fork); hipEventDestroy(r->ev_join); }
     if (r->play_graph) play_graph_free(r->play_graph);
     for (auto &ev : r->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete r;
@@ -492,6 +505,7 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
 }
 extern "C" int vpt_renderer_set_shard(vpt_renderer *r, int rank, int world, int rows_per_block) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    VPT_TRY(join_side(r));
     if (world < 1 || rank < 0 || rank >= world || rows_per_block < 1) return fail(VPT_ERR_INVALID, "bad shard %d/%d rows %d", rank, world, rows_per_block);
     if (r->kind == VPT_RENDERER_DOS && world > 1)
         return fail(VPT_ERR_UNSUPPORTED, "the DOS renderer does not shard: every slice reads its neighbours' occlusion across rows");
@@ -512,6 +526,7 @@ extern "C" int vpt_renderer_global_row(vpt_renderer *r, int l, int *j) {
 }
 extern "C" int vpt_renderer_resize(vpt_renderer *r, int width, int height) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    VPT_TRY(join_side(r));
     if (width < 1 || height < 1 || width > 32768 || height > 32768) return fail(VPT_ERR_INVALID, "resolution %dx%d out of range", width, height);
     if (width == r->W && height == r->H) return VPT_OK;   // AbstractRenderer.js:107
     r->W = width; r->H = height;
@@ -519,6 +534,7 @@ extern "C" int vpt_renderer_resize(vpt_renderer *r, int width, int height) {
 }
 extern "C" int vpt_renderer_set_volume(vpt_renderer *r, vpt_volume *v) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    VPT_TRY(join_side(r));
     if (v && v->ctx != r->ctx) return fail(VPT_ERR_INVALID, "volume belongs to another context");
     r->vol = v;
     return VPT_OK;
@@ -530,6 +546,7 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
     a->pm.tiles_x = r->tiles_x; a->pm.ntiles = r->ntiles;
     a->pm.G = r->G; a->pm.g = r->g; a->pm.R = r->R;
     a->pm.rshift = -1;
+    a->pm.ty0 = 0;
     for (int sft = 0; sft < 16; sft++) if ((1 << sft) == r->R) a->pm.rshift = sft;
     a->pm.ndc_x = r->ndc_x; a->pm.ndc_y = r->ndc_y;
     if (need_volume) {
@@ -582,6 +599,14 @@ static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)(r->tiles_x
 static bool wave_blocks(const vpt_renderer *r) {
     return r->kind != VPT_RENDERER_MCM && r->kind != VPT_RENDERER_DOS && lds_bytes(r) * 28 <= 150 * 1024;
 }
+// the side stream's work happens-before everything enqueued on the context's stream from here on
+static int join_side(vpt_renderer *r) {
+    if (!r || !r->side_busy) return VPT_OK;
+    HIP_TRY(hipEventRecord(r->ev_join, r->side));
+    HIP_TRY(hipStreamWaitEvent(r->ctx->stream, r->ev_join, 0));
+    r->side_busy = false; r->main_dirty = true;
+    return VPT_OK;
+}
 template <typename K>
 static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigned) {
     size_t lds = lds_bytes(r);
@@ -590,6 +615,19 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     if (wave_blocks(r)) {
         dim3 g = tile_grid(r);
         hipLaunchKernelGGL(kernel, dim3(g.x * 4u, g.y), dim3(64), lds, r->ctx->stream, a);
+    } else if (r->split == 2 && r->kind == VPT_RENDERER_MCM && r->tiles_y >= 2) {
+        dim3 g = tile_grid(r);
+        const unsigned h1 = g.y / 2u;
+        PassArgs lo = a, hi = a;
+        lo.pm.ty0 = 0; hi.pm.ty0 = (int)h1;
+        if (r->main_dirty) {      // whatever the context's stream did to the renderer's buffers since the last join comes first
+            HIP_TRY(hipEventRecord(r->ev_fork, r->ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(r->side, r->ev_fork, 0));
+            r->main_dirty = false;
+        }
+        hipLaunchKernelGGL(kernel, dim3(g.x, h1), dim3(VPT_BLOCK), lds, r->ctx->stream, lo);
+        hipLaunchKernelGGL(kernel, dim3(g.x, g.y - h1), dim3(VPT_BLOCK), lds, r->side, hi);
+        r->side_busy = true;
     } else {
         hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a);
     }
@@ -716,6 +754,7 @@ struct Timed {   // HIP events around the dominant kernel (or around one graph r
 
 extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    VPT_TRY(join_side(r));
     if (r->kind == VPT_RENDERER_MCM && !u) return fail(VPT_ERR_INVALID, "MCM reset needs uniforms (uMvpInverseMatrix, uRandSeed)");
     HIP_TRY(hipSetDevice(r->ctx->device));
     PassArgs a;
@@ -735,6 +774,7 @@ extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
 }
 extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r) return fail(VPT_ERR_INVALID, "null argument");
+    VPT_TRY(join_side(r));
     if (r->kind == VPT_RENDERER_DOS) return VPT_OK;                 // DOSRenderer.js has no _generateFrame (AbstractRenderer.js:122-124: empty)
     if (!u) return fail(VPT_ERR_INVALID, "null argument");
     if (r->kind == VPT_RENDERER_MCM) return VPT_OK;                 // MCMRenderer.js:118-119: empty
@@ -781,6 +821,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
 }
 extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    VPT_TRY(join_side(r));
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind == VPT_RENDERER_ISO && !u) return fail(VPT_ERR_INVALID, "ISO renderFrame needs uniforms (uLight, uGradientStep)");
     PassArgs a;
@@ -917,6 +958,7 @@ static bool play_key_equal(const PassArgs &x, const PassArgs &y) { return memcmp
 
 extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int use_graph) {
     if (!r || !base || !frame_vars) return fail(VPT_ERR_INVALID, "null argument");
+    VPT_TRY(join_side(r));
     if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "frame sequences are not defined for the DOS renderer: drive it slice by slice");
     vpt_context *c = r->ctx;
     HIP_TRY(hipSetDevice(c->device));
@@ -985,6 +1027,7 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
 // ---------------------------------------------------------------------------------------------
 extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t nbytes) {
     if (!r || !dst) return fail(VPT_ERR_INVALID, "null argument");
+    VPT_TRY(join_side(r));
     vpt_context *c = r->ctx;
     HIP_TRY(hipSetDevice(c->device));
     size_t npix = (size_t)r->W * r->local_h;
@@ -1030,11 +1073,13 @@ extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t 
 }
 extern "C" int vpt_renderer_render_buffer_device(vpt_renderer *r, void **ptr, size_t *nbytes) {
     if (!r || !ptr || !nbytes) return fail(VPT_ERR_INVALID, "null argument");
+    VPT_TRY(join_side(r));
     *ptr = r->render_target ? r->render_target : r->render; *nbytes = (size_t)r->W * r->local_h * 8;
     return VPT_OK;
 }
 extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t nbytes) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    VPT_TRY(join_side(r));
     size_t need = (size_t)r->W * r->local_h * 8;
     if (ptr && nbytes < need) return fail(VPT_ERR_INVALID, "render target too small: %zu < %zu", nbytes, need);
     r->render_target = (uint2 *)ptr;
@@ -1163,6 +1208,17 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
         case VPT_OPTION_MCS_PERSISTENT: r->mcs_persistent = value != 0; return VPT_OK;
         case VPT_OPTION_MCM_PERSISTENT: r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
         case VPT_OPTION_BOUNDARY_ATLAS: r->boundary_atlas = value != 0; return VPT_OK;
+        case VPT_OPTION_SPLIT_STREAMS:
+            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_SPLIT_STREAMS: MCM renderer only");
+            if (value != 1 && value != 2) return fail(VPT_ERR_INVALID, "VPT_OPTION_SPLIT_STREAMS: 1 or 2");
+            VPT_TRY(join_side(r));
+            HIP_TRY(hipSetDevice(r->ctx->device));
+            if (value == 2 && !r->side) {
+                HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
+            }
+            r->split = value; return VPT_OK;
         case VPT_OPTION_FAST_MATH:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_FAST_MATH: only the MCM renderer has a fast-arithmetic variant");
             r->fast_math = value != 0; return VPT_OK;
@@ -1182,6 +1238,7 @@ extern "C" int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count) {
 }
 extern "C" int vpt_renderer_clear_sample_count(vpt_renderer *r) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    VPT_TRY(join_side(r));
     HIP_TRY(hipSetDevice(r->ctx->device));
     HIP_TRY(hipMemsetAsync(r->samples, 0, COUNTER_BYTES, r->ctx->stream));
     r->samples_host = 0;
@@ -1396,6 +1453,7 @@ __global__ void k_fill_u32(uint32_t *dst, size_t n, uint32_t v) {
 }
 extern "C" int vpt_tonemapper_render(vpt_tonemapper *t, const struct vpt_tonemap_params *params) {
     if (!t || !params) return fail(VPT_ERR_INVALID, "null argument");
+    VPT_TRY(join_side(t->source));
     vpt_context *c = t->ctx;
     HIP_TRY(hipSetDevice(c->device));
     static_assert(sizeof(TonemapParams) == sizeof(vpt_tonemap_params), "parameter block layout");
@@ -1750,6 +1808,7 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
         VPT_TRY(launch_fused(r, a));
     }
     if (t1) HIP_TRY(hipEventRecord(t1, cs));
+    VPT_TRY(join_side(r));                                                   // a split pass: both row ranges are in the frame
     HIP_TRY(hipEventRecord(g->rendered[st.rendered_event], cs));
     HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[st.rendered_event], 0));
     if (st.op == VPT_GATHER_OP_ALLGATHER) {

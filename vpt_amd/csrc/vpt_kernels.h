@@ -25,6 +25,7 @@ struct PixMap {
     int tiles_x, ntiles;
     int G, g, R;       // shard: world, rank, rows per block
     int rshift;        // log2(R) when R is a power of two, else -1
+    int ty0;           // first tile row of this launch (a pass split over two streams launches two row ranges; else 0)
     const float *ndc_x, *ndc_y;   // pixel-centre NDC per column / global row: fl(fl((2i+1)/W) - 1), W resp. H entries
 };
 struct Pix { int i, j, l, k; bool valid, tile; };   // tile: the workgroup maps to a tile of the buffers (valid or padding pixel)
@@ -45,7 +46,7 @@ VPT_DEV int global_row(const PixMap &m, int l) {
 // gridDim.x is a multiple of 8, so blockIdx.x & 7 labels the XCD.  Within a group of 8 adjacent tiles of a row the
 // tile of XCD x is the one with (tx + ty) % 8 == x; groups past tiles_x fail the p.i < W test.
 VPT_DEV Pix map_pixel(const PixMap &m) {
-    int xcd = (int)blockIdx.x & 7, ty = (int)blockIdx.y;
+    int xcd = (int)blockIdx.x & 7, ty = (int)blockIdx.y + m.ty0;
     int tx, w, lane = (int)threadIdx.x & 63;
     if (blockDim.x == 64) {
         // one-wave workgroups (the ray marchers when their LDS image is small): blockIdx.x = (group * 4 + wave) * 8 + xcd.
@@ -908,10 +909,13 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+#ifndef VPT_MCM_WAVES
+#define VPT_MCM_WAVES 7          // waves per SIMD the integrate kernel is compiled for (72 VGPRs; 8 needs 64: A/B in DESIGN.md section 5)
+#endif
 // integrate/fragment main(): MCMRenderer.glsl:116-172.  FUSE_RENDER additionally performs
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
 template <bool FUSE_RENDER, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_integrate(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(VPT_MCM_WAVES, 8))) k_mcm_integrate(PassArgs a) {
     apply_frame_table(a);
     // the photon state (4 x dwordx4 per lane, one contiguous 1 KiB segment per wave and array) does not depend on the LDS
     // image: its loads are issued first, so they fly while the workgroup stages the tables and hashes its seed
