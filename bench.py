@@ -296,6 +296,8 @@ def main():
             r.extinction = args.extinction
         if args.mcm_persistent >= 0:
             r.set_option(N.OPTION_MCM_PERSISTENT, args.mcm_persistent)
+        if args.renderer != "mcm":
+            args.fast_math, args.split_streams = 0, 1       # MCM options
         if args.fast_math:
             r.set_option(N.OPTION_FAST_MATH, 1)
         if world > 1:

@@ -264,6 +264,45 @@ async function main() {
         assert.throws(() => r.render(), /no ready volume/);
         r.destroy();
     }
+    // ---- manifests beyond R8 (Volume.js:58-60,84-105): an R32F and an R16F volume with the same texels, and an RGBA8 volume against
+    //      its first two channels as RG8, must render identically; integer types throw the reference's error
+    {
+        const GL = require('../vpt/readers/readers.js');
+        const f32 = new Float32Array(n * n * n), f16 = new Uint16Array(n * n * n), rgba = new Uint8Array(4 * n * n * n), rg = new Uint8Array(2 * n * n * n);
+        const toHalf = v => { const f = new Float32Array([v]), u = new Uint32Array(f.buffer)[0]; const e = ((u >> 23) & 255) - 112, m = (u >> 13) & 1023;
+            return e <= 0 ? 0 : ((u >> 16) & 0x8000) | (e << 10) | m; };     // truncating: only used to MAKE a half file
+        const halfVal = h => { const e = (h >> 10) & 31, m = h & 1023; return e === 0 ? m * Math.pow(2, -24) : (1 + m / 1024) * Math.pow(2, e - 15); };
+        for (let i = 0; i < vol.length; i++) {
+            f16[i] = toHalf(vol[i] / 255 * 1.3); f32[i] = halfVal(f16[i]);
+            rgba[4 * i] = vol[i]; rgba[4 * i + 1] = 255 - vol[i]; rgba[4 * i + 2] = 7; rgba[4 * i + 3] = 200;
+            rg[2 * i] = vol[i]; rg[2 * i + 1] = 255 - vol[i];
+        }
+        const mk = (bytes, format, internalFormat, type) => {
+            const rd = new vpt.RAWReader(new Uint8Array(bytes.buffer), { width: n, height: n, depth: n });
+            const base = rd.readMetadata.bind(rd), bpv = bytes.byteLength / (n * n * n);
+            rd.readMetadata = async () => { const m = await base(); m.modalities[0].format = format; m.modalities[0].internalFormat = internalFormat; m.modalities[0].type = type; return m; };
+            rd.readBlock = i => new Uint8Array(bytes.buffer, i * n * n * bpv, n * n * bpv);
+            return new vpt.Volume(ctx, rd);
+        };
+        const render = async v => {
+            await v.load(); v.setFilter('linear');
+            const r = new (vpt.RendererFactory('eam'))(ctx, v, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });
+            r.reset(); r.render(); r.render();
+            const out = r.read(N.VPT_BUFFER_ACCUM, new Uint8Array(4 * W * H));
+            r.destroy(); v.destroy();
+            return out;
+        };
+        const a = await render(mk(f32, GL.GL_RED, GL.GL_R32F, GL.GL_FLOAT));
+        const b = await render(mk(f16, GL.GL_RED, GL.GL_R16F, GL.GL_HALF_FLOAT));
+        assert.deepStrictEqual(Array.from(b), Array.from(a), 'R16F and R32F volumes with the same texels');
+        assert.ok(a.some(x => x > 0 && x < 255));
+        const c = await render(mk(rgba, GL.GL_RGBA, GL.GL_RGBA8, GL.GL_UNSIGNED_BYTE));
+        const d = await render(mk(rg, GL.GL_RG, GL.GL_RG8, GL.GL_UNSIGNED_BYTE));
+        assert.deepStrictEqual(Array.from(c), Array.from(d), 'RGBA8 keeps the two channels the shaders read');
+        let threw = false;
+        try { await mk(new Uint16Array(n * n * n), GL.GL_RED, 33322, 5123).load(); } catch (e) { threw = /Unknown volume datatype/.test(e.message); }
+        assert.ok(threw, 'UNSIGNED_SHORT volumes raise the reference error');
+    }
     volume.destroy();
     ctx.destroy();
     console.log('js gpu ok');
