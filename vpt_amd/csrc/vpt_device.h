@@ -398,7 +398,7 @@ VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
 // instead of two unaligned 8-byte gathers from the bricks.  Face f = 2 * axis + side (side 1 = plane N_k - 1) starts at dword
 // f * atlas_face; cell (a, b) of a face sits at (b << atlas_shift) + a with (a, b) = (y, z), (x, z), (x, y) for axis x, y, z.
 // Precondition: some coordinate of p is > 1 or < 0 (not NaN) — the caller's bounds test.
-VPT_DEV float sample_volume_boundary(const DevVolume &v, f3 p) {
+VPT_DEV uint32_t boundary_cell(const DevVolume &v, f3 p, float &out_fa, float &out_fb) {
     // (members copied into locals first: `c ? v.fny : v.fnx` on struct members is an lvalue conditional — a select of ADDRESSES
     // into the kernel argument block, which then has to live in scratch memory: measured 5x slower)
     const float fnx = v.fnx, fny = v.fny, fnz = v.fnz, hx = v.hx, hy = v.hy, hz = v.hz;
@@ -429,9 +429,17 @@ VPT_DEV float sample_volume_boundary(const DevVolume &v, f3 p) {
         const uint32_t f = (ox ? 0u : (oy ? 2u : 4u)) + (pk > 1.0f ? 1u : 0u);
         idx = f * face + ((b << sh) + a);
     }
-    const uint32_t w = v.atlas[idx];
+    out_fa = fa; out_fb = fb;
+    return idx;
+}
+VPT_DEV float boundary_blend(uint32_t w, float fa, float fb) {
     float c00 = cvt_ubyte<0>(w), c10 = cvt_ubyte<1>(w), c01 = cvt_ubyte<2>(w), c11 = cvt_ubyte<3>(w);
     return lerpf(lerpf(c00, c10, fa), lerpf(c01, c11, fa), fb) * VPT_INV255;
+}
+VPT_DEV float sample_volume_boundary(const DevVolume &v, f3 p) {
+    float fa, fb;
+    const uint32_t idx = boundary_cell(v, p, fa, fb);
+    return boundary_blend(v.atlas[idx], fa, fb);
 }
 // texture(uVolume, p).rg: r always, g only for RG8 volumes (V & VPT_V_RG; an R8 volume has g = 0).  The cell and its
 // brick address are computed once for both channels.

@@ -394,8 +394,11 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
         HIP_TRY(hipMemsetAsync(r->acc, 0, r->npix_padded * fe, c->stream));
     } else {
         for (int i = 0; i < 4; i++) {
-            HIP_TRY(hipMalloc(&r->st[i], r->npix_padded * sizeof(float4)));
-            HIP_TRY(hipMemsetAsync(r->st[i], 0, r->npix_padded * sizeof(float4), c->stream));
+            // MCM: position (0) and transmittance (2) are 12-byte texels — their fourth float is a constant 0 in the reference's
+            // attachments (MCMRenderer.glsl:168,170) and is not stored; DOS keeps float4 / float arrays in the same slots
+            size_t texel = (r->kind == VPT_RENDERER_MCM && (i == 0 || i == 2)) ? 3 * sizeof(float) : sizeof(float4);
+            HIP_TRY(hipMalloc(&r->st[i], r->npix_padded * texel));
+            HIP_TRY(hipMemsetAsync(r->st[i], 0, r->npix_padded * texel, c->stream));
         }
     }
     {   // pixel-centre NDC: fl(fl((2i+1)/W) - 1), the exact per-pixel expression of the contract
@@ -1065,6 +1068,9 @@ extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t 
     }
     PassArgs a;
     VPT_TRY(make_args(r, nullptr, false, &a));
+    if (r->kind == VPT_RENDERER_MCM && (buffer == VPT_BUFFER_MCM_POSITION || buffer == VPT_BUFFER_MCM_TRANSMITTANCE))
+        hipLaunchKernelGGL(k_detile_mcm3, tile_grid(r), dim3(VPT_BLOCK), 0, c->stream, a.pm, (const f3 *)src, (float4 *)r->scratch);
+    else
     hipLaunchKernelGGL(k_detile, tile_grid(r), dim3(VPT_BLOCK), 0, c->stream, a.pm, (const uint8_t *)src, (uint8_t *)r->scratch, (int)elem);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(dst, r->scratch, npix * elem, hipMemcpyDeviceToHost, c->stream));

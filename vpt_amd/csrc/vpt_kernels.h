@@ -703,9 +703,9 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
         ph.position = f3{ 0.0f, 0.0f, 0.0f };
         ph.direction = f3{ 0.0f, 0.0f, 1.0f };
     }
-    a.st0[p.k] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
+    ((f3 *)a.st0)[p.k] = ph.position;
     a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
-    a.st2[p.k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    ((f3 *)a.st2)[p.k] = f3{ 1.0f, 1.0f, 1.0f };
     a.st3[p.k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
 
@@ -793,15 +793,46 @@ VPT_DEV f3 sample_hg_fast(uint32_t &state, float g, f3 dir) {
     float sq = hw_sqrt(fmaf(-hgcos, hgcos, 1.0f)) * hw_rsq(dot3(cc, cc));
     return f3{ fmaf(sq, cc.x, hgcos * dir.x), fmaf(sq, cc.y, hgcos * dir.y), fmaf(sq, cc.z, hgcos * dir.z) };
 }
+// the end of a path in the fast variant: deposit `rad`, then resetPhoton (MCMRenderer.glsl:146-151 / 153-158, :70-78)
+struct FastPixel { f3 from0; float4 fb; float jx, jy; };
+VPT_DEV void fast_path_end(const PassArgs &a, const FastPixel &c, uint32_t &state, Photon &ph, f3 rad, float px, float py) {
+    const float *m = a.mvp_inv.m;
+    ph.samples++;
+    float inv_n = hw_rcp((float)ph.samples);
+    ph.radiance.x = fmaf(rad.x - ph.radiance.x, inv_n, ph.radiance.x);
+    ph.radiance.y = fmaf(rad.y - ph.radiance.y, inv_n, ph.radiance.y);
+    ph.radiance.z = fmaf(rad.z - ph.radiance.z, inv_n, ph.radiance.z);
+    if (a.blur == 0.0f) {
+        state = pcg(pcg(state));                          // the disk sample's two draws (multiplied by blur = 0)
+        float ax = fmaf(pcg_float(state), c.jx, -a.inv_w);
+        float ay = fmaf(pcg_float(state), c.jy, -a.inv_h);
+        float4 th = { fmaf(m[4], ay, fmaf(m[0], ax, c.fb.x)), fmaf(m[5], ay, fmaf(m[1], ax, c.fb.y)),
+                      fmaf(m[6], ay, fmaf(m[2], ax, c.fb.z)), fmaf(m[7], ay, fmaf(m[3], ax, c.fb.w)) };
+        f3 d = { fmaf(-th.w, c.from0.x, th.x), fmaf(-th.w, c.from0.y, th.y), fmaf(-th.w, c.from0.z, th.z) };
+        float inv = __builtin_copysignf(hw_rsq(dot3(d, d)), th.w);
+        f3 dir = { d.x * inv, d.y * inv, d.z * inv };
+        f3 iv = { hw_rcp(dir.x), hw_rcp(dir.y), hw_rcp(dir.z) };
+        float tx = vmin((0.0f - c.from0.x) * iv.x, (1.0f - c.from0.x) * iv.x);
+        float ty = vmin((0.0f - c.from0.y) * iv.y, (1.0f - c.from0.y) * iv.y);
+        float tz = vmin((0.0f - c.from0.z) * iv.z, (1.0f - c.from0.z) * iv.z);
+        float tnear = vmax(vmax(vmax(tx, ty), tz), 0.0f);
+        ph.direction = dir;
+        ph.position = madd3(c.from0, tnear, dir);
+        ph.bounces = 0u;
+        ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
+    } else {
+        reset_photon(state, ph, px, py, a, c.from0);      // depth-of-field runs: the contract's general path
+    }
+}
 template <int V>
 VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
-    const float *m = a.mvp_inv.m;
     // pixel constants of resetPhoton with blur == 0: the near-plane point and the far-plane base point (homogeneous)
+    FastPixel c;
     const float4 nb = mat4_mul_point(a.mvp_inv, px, py, -1.0f);
     const float inw = hw_rcp(nb.w);
-    const f3 from0 = { nb.x * inw, nb.y * inw, nb.z * inw };
-    const float4 fb = mat4_mul_point(a.mvp_inv, px, py, 1.0f);
-    const float jx = 0x1p-31f * a.inv_w, jy = 0x1p-31f * a.inv_h;
+    c.from0 = f3{ nb.x * inw, nb.y * inw, nb.z * inw };
+    c.fb = mat4_mul_point(a.mvp_inv, px, py, 1.0f);
+    c.jx = 0x1p-31f * a.inv_w; c.jy = 0x1p-31f * a.inv_h;
     const float ld = -0.6931471805599453f * a.inv_extinction;
 
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
@@ -810,6 +841,51 @@ VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, 
         ph.position = madd3(ph.position, dist, ph.direction);
         f3 q = ph.position;
         bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+#if defined(VPT_FAST_EARLY_RESET) && VPT_FAST_EARLY_RESET
+        if (!(V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32 | VPT_V_ALIGNED)) && a.vol.atlas != nullptr) {
+            // A photon outside the cube ends its path whatever the (discarded) sample says: the sample's loads are issued, the
+            // path is ended and re-started while they fly, and the sample is blended afterwards.  Same draws in the same order.
+            uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0; float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;   // shared by the two kinds of sample
+            if (oob) {
+                d0 = a.vol.atlas[boundary_cell(a.vol, q, f0, f1)];
+            } else {
+                uint32_t x, y, z;
+                linear_cell(q.x, a.vol.fnx, a.vol.hx, x, f0); linear_cell(q.y, a.vol.fny, a.vol.hy, y, f1); linear_cell(q.z, a.vol.fnz, a.vol.hz, z, f2);
+                const uint8_t *b = cell_addr<(V & VPT_V_WIDE) != 0>(a.vol, t, x, y, z);
+                uint64_t w0, w1;
+                __builtin_memcpy(&w0, b, 8); __builtin_memcpy(&w1, b + 25, 8);
+                d0 = (uint32_t)w0; d1 = (uint32_t)(w0 >> 32); d2 = (uint32_t)w1; d3 = (uint32_t)(w1 >> 32);
+            }
+            float wheel = pcg_float(state) * 0x1p-32f;
+            if (oob) {
+                float4 env = sample_environment(a.env, ph.direction);
+                fast_path_end(a, c, state, ph, f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z }, px, py);
+            }
+            asm volatile("" ::: "memory");
+            float r;
+            if (oob) r = boundary_blend(d0, f0, f1);
+            else {
+                float c00 = lerpf(cvt_ubyte<0>(d0), cvt_ubyte<1>(d0), f0), c10 = lerpf(cvt_ubyte<1>(d1), cvt_ubyte<2>(d1), f0);
+                float c01 = lerpf(cvt_ubyte<0>(d2), cvt_ubyte<1>(d2), f0), c11 = lerpf(cvt_ubyte<1>(d3), cvt_ubyte<2>(d3), f0);
+                r = lerpf(lerpf(c00, c10, f1), lerpf(c01, c11, f1), f2) * VPT_INV255;
+            }
+            float4 vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
+            asm volatile("" : "+v"(vs.w));
+            if (!oob) {
+                float p_null = 1.0f - vs.w;
+                float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
+                float p_abs = 1.0f - p_null - p_scat;
+                if (wheel < p_abs) {
+                    fast_path_end(a, c, state, ph, f3{ 0.0f, 0.0f, 0.0f }, px, py);
+                } else if (wheel < p_abs + p_scat) {
+                    ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
+                    ph.direction = sample_hg_fast(state, a.anisotropy, ph.direction);
+                    ph.bounces++;
+                }
+            }
+            continue;
+        }
+#endif
         float4 vs = mcm_sample<V>(a, t, q, oob);
         float p_null = 1.0f - vs.w;
         float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
@@ -821,32 +897,7 @@ VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, 
                 float4 env = sample_environment(a.env, ph.direction);
                 rad = f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z };
             }
-            ph.samples++;
-            float inv_n = hw_rcp((float)ph.samples);
-            ph.radiance.x = fmaf(rad.x - ph.radiance.x, inv_n, ph.radiance.x);
-            ph.radiance.y = fmaf(rad.y - ph.radiance.y, inv_n, ph.radiance.y);
-            ph.radiance.z = fmaf(rad.z - ph.radiance.z, inv_n, ph.radiance.z);
-            if (a.blur == 0.0f) {
-                state = pcg(pcg(state));                          // the disk sample's two draws (multiplied by blur = 0)
-                float ax = fmaf(pcg_float(state), jx, -a.inv_w);
-                float ay = fmaf(pcg_float(state), jy, -a.inv_h);
-                float4 th = { fmaf(m[4], ay, fmaf(m[0], ax, fb.x)), fmaf(m[5], ay, fmaf(m[1], ax, fb.y)),
-                              fmaf(m[6], ay, fmaf(m[2], ax, fb.z)), fmaf(m[7], ay, fmaf(m[3], ax, fb.w)) };
-                f3 d = { fmaf(-th.w, from0.x, th.x), fmaf(-th.w, from0.y, th.y), fmaf(-th.w, from0.z, th.z) };
-                float inv = __builtin_copysignf(hw_rsq(dot3(d, d)), th.w);
-                f3 dir = { d.x * inv, d.y * inv, d.z * inv };
-                f3 iv = { hw_rcp(dir.x), hw_rcp(dir.y), hw_rcp(dir.z) };
-                float tx = vmin((0.0f - from0.x) * iv.x, (1.0f - from0.x) * iv.x);
-                float ty = vmin((0.0f - from0.y) * iv.y, (1.0f - from0.y) * iv.y);
-                float tz = vmin((0.0f - from0.z) * iv.z, (1.0f - from0.z) * iv.z);
-                float tnear = vmax(vmax(vmax(tx, ty), tz), 0.0f);
-                ph.direction = dir;
-                ph.position = madd3(from0, tnear, dir);
-                ph.bounces = 0u;
-                ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
-            } else {
-                reset_photon(state, ph, px, py, a, from0);        // depth-of-field runs: the contract's general path
-            }
+            fast_path_end(a, c, state, ph, rad, px, py);
         } else if (wheel < p_abs + p_scat) {
             ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
             ph.direction = sample_hg_fast(state, a.anisotropy, ph.direction);
@@ -854,6 +905,17 @@ VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, 
         }
     }
 }
+// Photon state in HBM (MCMRenderer.js:214-263 keeps four RGBA32F attachments: [pos, 0] [dir, bounces] [T, 0] [radiance, samples]):
+// the two constant zeros are not stored — position and transmittance are 12-byte texels (one dwordx3 per lane, a wave's
+// 64 texels one contiguous 768-byte segment), direction+bounces and radiance+samples 16-byte texels: 56 bytes per pixel each
+// way instead of 64.  vpt_renderer_read re-expands them to RGBA32F (k_detile_mcm3).
+struct PhotonState { f3 s0; float4 s1; f3 s2; float4 s3; };
+VPT_DEV PhotonState photon_load(const PassArgs &a, int k) {
+    PhotonState s;
+    s.s0 = ((const f3 *)a.st0)[k]; s.s1 = a.st1[k]; s.s2 = ((const f3 *)a.st2)[k]; s.s3 = a.st3[k];
+    return s;
+}
+VPT_DEV void photon_store(const PassArgs &a, int k, const struct Photon &ph);
 VPT_DEV Photon photon_unpack(float4 s0, float4 s1, float4 s2, float4 s3) {   // MCMRenderer.glsl:117-126
     Photon ph;
     ph.position = f3{ s0.x, s0.y, s0.z };
@@ -863,6 +925,15 @@ VPT_DEV Photon photon_unpack(float4 s0, float4 s1, float4 s2, float4 s3) {   // 
     ph.radiance = f3{ s3.x, s3.y, s3.z };
     ph.samples = (uint32_t)(s3.w + 0.5f);
     return ph;
+}
+VPT_DEV Photon photon_unpack(const PhotonState &s) {
+    return photon_unpack(make_float4(s.s0.x, s.s0.y, s.s0.z, 0.0f), s.s1, make_float4(s.s2.x, s.s2.y, s.s2.z, 0.0f), s.s3);
+}
+VPT_DEV void photon_store(const PassArgs &a, int k, const Photon &ph) {       // MCMRenderer.glsl:168-171
+    ((f3 *)a.st0)[k] = ph.position;
+    a.st1[k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
+    ((f3 *)a.st2)[k] = ph.transmittance;
+    a.st3[k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
 }
 
 // Persistent form of the integrate pass: every wave walks several 8x8-pixel segments of the tile-ordered state arrays
@@ -880,17 +951,17 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     int g = (int)blockIdx.x * (VPT_BLOCK / 64) + ((int)threadIdx.x >> 6);
     if (g >= nseg) return;
     size_t k = (size_t)g * 64 + lane;
-    float4 n0, n1, n2, n3;
-    if (PREFETCH) { n0 = a.st0[k]; n1 = a.st1[k]; n2 = a.st2[k]; n3 = a.st3[k]; }
+    PhotonState nx;
+    if (PREFETCH) nx = photon_load(a, (int)k);
     while (g < nseg) {
         const int gc = g;
         const size_t kc = k;
-        if (!PREFETCH) { n0 = a.st0[k]; n1 = a.st1[k]; n2 = a.st2[k]; n3 = a.st3[k]; }
-        Photon ph = photon_unpack(n0, n1, n2, n3);
+        if (!PREFETCH) nx = photon_load(a, (int)k);
+        Photon ph = photon_unpack(nx);
         g += nwaves;
         k = (size_t)g * 64 + lane;
         if (PREFETCH && g < nseg) {              // wave-uniform: prefetch the next segment's photon state
-            n0 = a.st0[k]; n1 = a.st1[k]; n2 = a.st2[k]; n3 = a.st3[k];
+            nx = photon_load(a, (int)k);
         }
         int t16 = gc >> 2, w = gc & 3;
         int ty = t16 / a.pm.tiles_x, tx = t16 - ty * a.pm.tiles_x;
@@ -899,10 +970,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
         int j = global_row(a.pm, l);
         if (i < a.pm.W && l < a.pm.local_h && j < a.pm.H) {
             mcm_events<V>(a, t, ph, ndc_col(a.pm, i), ndc_row(a.pm, j));
-            a.st0[kc] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
-            a.st1[kc] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
-            a.st2[kc] = make_float4(ph.transmittance.x, ph.transmittance.y, ph.transmittance.z, 0.0f);
-            a.st3[kc] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
+            photon_store(a, (int)kc, ph);
             if (FUSE_RENDER)
                 a.render[(size_t)l * a.pm.W + i] = pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f);
         }
@@ -920,19 +988,16 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // the photon state (4 x dwordx4 per lane, one contiguous 1 KiB segment per wave and array) does not depend on the LDS
     // image: its loads are issued first, so they fly while the workgroup stages the tables and hashes its seed
     Pix p = map_pixel(a.pm);
-    float4 s0, s1, s2, s3;
-    if (p.tile) { s0 = a.st0[p.k]; s1 = a.st1[p.k]; s2 = a.st2[p.k]; s3 = a.st3[p.k]; }
+    PhotonState st;
+    if (p.tile) st = photon_load(a, p.k);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     if (!p.valid) return;
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
-    Photon ph = photon_unpack(s0, s1, s2, s3);
+    Photon ph = photon_unpack(st);
     if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
     else mcm_events<V>(a, t, ph, px, py);
-    a.st0[p.k] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
-    a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
-    a.st2[p.k] = make_float4(ph.transmittance.x, ph.transmittance.y, ph.transmittance.z, 0.0f);
-    a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
+    photon_store(a, p.k, ph);
     if (FUSE_RENDER)
         a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f);
 }
@@ -948,14 +1013,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
-    float4 s0 = a.st0[p.k], s1 = a.st1[p.k], s2 = a.st2[p.k], s3 = a.st3[p.k];
-    Photon ph;
-    ph.position = f3{ s0.x, s0.y, s0.z };
-    ph.direction = f3{ s1.x, s1.y, s1.z };
-    ph.bounces = (uint32_t)(s1.w + 0.5f);
-    ph.transmittance = f3{ s2.x, s2.y, s2.z };
-    ph.radiance = f3{ s3.x, s3.y, s3.z };
-    ph.samples = (uint32_t)(s3.w + 0.5f);
+    Photon ph = photon_unpack(photon_load(a, p.k));
     uint32_t base = *a.frame_counter;
     for (uint32_t f = 0; f < npasses; f++) {
         a.seed = a.frame_table[(base + f) & a.frame_mask].seed;
@@ -964,10 +1022,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
         // the unfused sequence stores the counters as floats between passes and re-reads them with uint(w + 0.5):
         // identical for every count below 2^24
     }
-    a.st0[p.k] = make_float4(ph.position.x, ph.position.y, ph.position.z, 0.0f);
-    a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, (float)ph.bounces);
-    a.st2[p.k] = make_float4(ph.transmittance.x, ph.transmittance.y, ph.transmittance.z, 0.0f);
-    a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
+    photon_store(a, p.k, ph);
     a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f);
 }
 __global__ void k_advance_frames(uint32_t *counter, uint32_t n) { *counter = *counter + n; }
@@ -988,6 +1043,14 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_detile(PixMap pm, const uint8_t *
     const uint8_t *s = src + (size_t)p.k * elem;
     uint8_t *d = dst + ((size_t)p.l * pm.W + p.i) * elem;
     for (int b = 0; b < elem; b++) d[b] = s[b];
+}
+
+// the MCM position / transmittance arrays (12-byte texels, tile order) -> RGBA32F rows with w = 0, as the reference's attachments hold them
+__global__ void __launch_bounds__(VPT_BLOCK) k_detile_mcm3(PixMap pm, const f3 *src, float4 *dst) {
+    Pix p = map_pixel(pm);
+    if (!(p.i < pm.W && p.l < pm.local_h)) return;
+    f3 v = src[p.k];
+    dst[(size_t)p.l * pm.W + p.i] = make_float4(v.x, v.y, v.z, 0.0f);
 }
 
 // texSubImage3D: contiguous block (bw x bh x bd, `ch` interleaved bytes per voxel) -> linear volume at (x0,y0,z0)
