@@ -69,8 +69,8 @@ def parse():
                          "checked against the contract by tolerance, not bit for bit)")
     ap.add_argument("--boundary-atlas", type=int, default=1,
                     help="MCM: 0 = out-of-cube samples from the bricks as well (VPT_OPTION_BOUNDARY_ATLAS off; results identical)")
-    ap.add_argument("--split-streams", type=int, default=2,
-                    help="MCM: 2 = launch every pass as two tile-row ranges on two HIP streams (VPT_OPTION_SPLIT_STREAMS; results identical)")
+    ap.add_argument("--split-streams", type=int, default=3,
+                    help="MCM: K >= 2 = launch every pass as K tile-row ranges on K HIP streams (VPT_OPTION_SPLIT_STREAMS; results identical)")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
     return ap.parse_args()
 
@@ -204,9 +204,9 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
                          "roofline": {"frac": B_ALG_MCM * ns / t / (HBM_PEAK_GBS * 1e9), "achieved": B_ALG_MCM * ns / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
         out["C4_mcm_1024_1080p"]["volume_generate_s"] = t_gen
         g1024.destroy()
-        # the headline workload in its other forms (the line above is --fast-math 1 --split-streams 2)
-        for name, fm, sp in (("H_mcm_512_1080p_bit_exact_one_stream", 0, 1), ("H_mcm_512_1080p_bit_exact_two_streams", 0, 2),
-                             ("H_mcm_512_1080p_fast_math_one_stream", 1, 1), ("H_mcm_512_1080p_fast_math_two_streams", 1, 2)):
+        # the headline workload in its other forms (the line above is --fast-math 1 --split-streams 3)
+        for name, fm, sp in (("H_mcm_512_1080p_bit_exact_one_stream", 0, 1), ("H_mcm_512_1080p_bit_exact_three_streams", 0, 3),
+                             ("H_mcm_512_1080p_fast_math_one_stream", 1, 1), ("H_mcm_512_1080p_fast_math_three_streams", 1, 3)):
             t, ns = run('mcm', gvol512, frames=200, fast_math=fm, split=sp)
             out[name] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "roofline": {"frac": B_ALG_MCM * ns / t / (HBM_PEAK_GBS * 1e9)}}
     except Exception as e:                              # reporting only: the headline line must still be printed
@@ -302,8 +302,8 @@ def main():
             r.set_option(N.OPTION_FAST_MATH, 1)
         if world > 1:
             args.split_streams = 1                    # every frame is handed to the gather: nothing to overlap across frames
-        if args.split_streams == 2 and args.renderer == "mcm":
-            r.set_option(N.OPTION_SPLIT_STREAMS, 2)
+        if args.split_streams >= 2 and args.renderer == "mcm":
+            r.set_option(N.OPTION_SPLIT_STREAMS, args.split_streams)
         if not args.boundary_atlas and args.renderer == "mcm":
             r.set_option(N.OPTION_BOUNDARY_ATLAS, 0)
         if args.mcs_persistent >= 0:
@@ -342,9 +342,9 @@ def main():
             per_launch_samples = res["samples_local"] / max(args.steps, 1)
             avg_ms = res["kernel_ms"] / res["launches"] if res["launches"] else res["dt"] / args.steps * 1e3
             event_ms = avg_ms
-            split = args.split_streams == 2 and args.renderer == "mcm" and not use_dist
+            split = args.split_streams >= 2 and args.renderer == "mcm" and not use_dist
             if split:
-                # a step is TWO launches (two tile-row ranges on two streams) that overlap each other and the next step's: a
+                # a step is K launches (K tile-row ranges on K streams) that overlap each other and the next step's: a
                 # per-launch duration no longer says what the chip does.  The chip-level rate is bytes of a step / time of a step.
                 avg_ms = res["dt"] / args.steps * 1e3
             bps = B_ALG_MCM if args.renderer == "mcm" else 8.0
@@ -397,9 +397,9 @@ def main():
                              "frac_of_measured": (achieved / stream_gbs) if stream_gbs else None,
                              "kernel": ("k_mcm_integrate<fused render, %s>" % ("fast-math" if args.fast_math else "bit-exact")) if args.renderer == "mcm" else "k_%s<fused>" % args.renderer,
                              "kernel_avg_ms": avg_ms, "launches": res["launches"],
-                             "launches_per_step": 2 if split else 1,
-                             "duration_source": ("timed block / steps: the step's two launches (tile-row ranges on two HIP streams) overlap each other "
-                                                 "and the next step's; HIP events around the first range's launch alone read %.4f ms" % event_ms) if split
+                             "launches_per_step": args.split_streams if split else 1,
+                             "duration_source": ("timed block / steps: the step's %d launches (tile-row ranges on %d HIP streams) overlap each other "
+                                                 "and the next step's; HIP events around the first range's launch alone read %.4f ms" % (args.split_streams, args.split_streams, event_ms)) if split
                                                 else "HIP events around every %d-th launch on the kernel's stream" % max(args.profile_kernel, 1),
                              "bytes_per_sample": bps},
                 "frame_check": res["ok"],

@@ -187,11 +187,12 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * value bit for bit (a clamped cell has weight 0 along the clamped axis), one aligned 4-byte gather instead of two unaligned
  * 8-byte ones.  0 = always the bricks. */
 #define VPT_OPTION_BOUNDARY_ATLAS 3
-/* VPT_OPTION_SPLIT_STREAMS (default 1; MCM renderer): 2 = a pass is launched as two tile-row ranges, the second on a private side
- * stream.  A pixel's pass depends on its own previous pass only, so consecutive passes of the two ranges never wait for each
- * other and the launch gap, ramp and tail of one range overlap the body of the other (HIP streams in place of one longer
- * launch).  Every other entry point (reads, reset, tone mapper, gather, synchronize ...) first joins the side stream into the
- * context's stream, so callers see the usual in-order semantics.  Results identical. */
+/* VPT_OPTION_SPLIT_STREAMS (default 1; MCM renderer): K in 2 .. VPT_MAX_SPLIT = a pass is launched as K tile-row ranges, all but
+ * the first on private side streams.  A pixel's pass depends on its own previous pass only, so consecutive passes of the
+ * ranges never wait for each other and the launch gap, ramp and tail of one range overlap the body of the others (HIP
+ * streams in place of one longer launch).  Every other entry point (reads, reset, tone mapper, gather, synchronize ...) first
+ * joins the side streams into the context's stream, so callers see the usual in-order semantics.  Results identical. */
+#define VPT_MAX_SPLIT 4
 #define VPT_OPTION_SPLIT_STREAMS 4
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
 /* the LAO renderer's own uniforms (gl.uniform* calls of LAORenderer.js:159-169; uStepSize and uExtinction travel in

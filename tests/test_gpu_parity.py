@@ -378,8 +378,8 @@ def test_mcm_boundary_atlas_is_bit_identical_to_the_bricks(gpu_ctx, oracle, dims
 
 @pytest.mark.parametrize("fast", [0, 1])
 def test_mcm_split_streams_give_identical_buffers(gpu_ctx, oracle, fast):
-    """VPT_OPTION_SPLIT_STREAMS = 2: every pass as two tile-row ranges on two HIP streams — with reads, a reset, a transfer
-    function change and a tone mapper in between (each joins the side stream), every buffer equals the one-stream run's"""
+    """VPT_OPTION_SPLIT_STREAMS = 2, 3, 4: every pass as K tile-row ranges on K HIP streams — with reads, a reset, a transfer
+    function change and a tone mapper in between (each joins the side streams), every buffer equals the one-stream run's"""
     sc = Scene(gpu_ctx, oracle, 32, 176, 150, tf=colour_tf(64, 1), camera=orbit_camera(176 / 150))
 
     def run(split):
@@ -405,10 +405,16 @@ def test_mcm_split_streams_give_identical_buffers(gpu_ctx, oracle, fast):
         r.destroy()
         return outs
 
-    a, b = run(1), run(2)
-    assert len(a) == len(b)
-    for k, (x, y) in enumerate(zip(a, b)):
-        assert_same_bits(y, x, "split streams, output %d" % k)
+    a = run(1)
+    for split in (2, 3, 4):
+        b = run(split)
+        assert len(a) == len(b)
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert_same_bits(y, x, "%d split streams, output %d" % (split, k))
+    r = sc.renderer('mcm')
+    with pytest.raises(vpt_amd.VptError):
+        r.set_option(N.OPTION_SPLIT_STREAMS, 5)
+    r.destroy()
     sc.gvol.destroy()
 
 

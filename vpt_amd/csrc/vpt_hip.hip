@@ -92,10 +92,10 @@ struct vpt_renderer {
     float2 *dos_samples; int dos_nsamples;   // DOS: uOcclusionSamples (vpt_renderer_set_occlusion_samples)
     int dos_rect[4]; bool dos_rect_valid;   // DOS: tile rectangle [x0, y0, x1, y1) of the previous integrate call (see dos_tile_rect)
     int dos_cur;                   // DOS: which of the occlusion buffers st[2|3] holds the latest slice (colour: st[0], in place)
-    // VPT_OPTION_SPLIT_STREAMS: the MCM pass is launched as two tile-row ranges, the second on a private side stream.  A pixel's pass
-    // depends on its own previous pass only, so the two ranges never wait for each other: the launch gap, ramp and tail of one
-    // overlap the body of the other.  Every other entry point joins the side stream into the context's stream first.
-    int split; hipStream_t side; hipEvent_t ev_fork, ev_join; bool side_busy, main_dirty;
+    // VPT_OPTION_SPLIT_STREAMS = K: the MCM pass is launched as K tile-row ranges, all but the first on private side streams.  A
+    // pixel's pass depends on its own previous pass only, so the ranges never wait for each other: the launch gap, ramp and tail
+    // of one overlap the body of the others.  Every other entry point joins the side streams into the context's stream first.
+    int split; hipStream_t side[VPT_MAX_SPLIT - 1]; hipEvent_t ev_fork, ev_join[VPT_MAX_SPLIT - 1]; bool side_busy, main_dirty;
     int boundary_atlas;            // VPT_OPTION_BOUNDARY_ATLAS (default 1): MCM takes out-of-cube samples from the volume's boundary atlas
     int fast_math;                 // VPT_OPTION_FAST_MATH: MCM events with hardware rcp / rsq / log / sin / cos (k_mcm_integrate<.., V | VPT_V_FAST>)
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
@@ -465,7 +465,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
     r->fast_math = 0; r->boundary_atlas = 1;
-    r->split = 1; r->side = nullptr; r->ev_fork = r->ev_join = nullptr; r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->split = 1; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -500,7 +500,8 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (r->frame_table) hipFree(r->frame_table);
     if (r->frame_staging) hipHostFree(r->frame_staging);
     if (r->frame_counter) hipFree(r->frame_counter);
-    if (r->side) { hipStreamDestroy(r->side); hipEventDestroy(r->ev_fork); hipEventDestroy(r->ev_join); }
+    for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) if (r->side[i]) { hipStreamDestroy(r->side[i]); hipEventDestroy(r->ev_join[i]); }
+    if (r->ev_fork) hipEventDestroy(r->ev_fork);
     if (r->play_graph) play_graph_free(r->play_graph);
     for (auto &ev : r->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete r;
@@ -605,8 +606,10 @@ static bool wave_blocks(const vpt_renderer *r) {
 // the side stream's work happens-before everything enqueued on the context's stream from here on
 static int join_side(vpt_renderer *r) {
     if (!r || !r->side_busy) return VPT_OK;
-    HIP_TRY(hipEventRecord(r->ev_join, r->side));
-    HIP_TRY(hipStreamWaitEvent(r->ctx->stream, r->ev_join, 0));
+    for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) if (r->side[i]) {
+        HIP_TRY(hipEventRecord(r->ev_join[i], r->side[i]));
+        HIP_TRY(hipStreamWaitEvent(r->ctx->stream, r->ev_join[i], 0));
+    }
     r->side_busy = false; r->main_dirty = true;
     return VPT_OK;
 }
@@ -618,18 +621,20 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     if (wave_blocks(r)) {
         dim3 g = tile_grid(r);
         hipLaunchKernelGGL(kernel, dim3(g.x * 4u, g.y), dim3(64), lds, r->ctx->stream, a);
-    } else if (r->split == 2 && r->kind == VPT_RENDERER_MCM && r->tiles_y >= 2) {
+    } else if (r->split >= 2 && r->kind == VPT_RENDERER_MCM && r->tiles_y >= r->split) {
         dim3 g = tile_grid(r);
-        const unsigned h1 = g.y / 2u;
-        PassArgs lo = a, hi = a;
-        lo.pm.ty0 = 0; hi.pm.ty0 = (int)h1;
+        const unsigned k = (unsigned)r->split;
         if (r->main_dirty) {      // whatever the context's stream did to the renderer's buffers since the last join comes first
             HIP_TRY(hipEventRecord(r->ev_fork, r->ctx->stream));
-            HIP_TRY(hipStreamWaitEvent(r->side, r->ev_fork, 0));
+            for (unsigned i = 0; i + 1 < k; i++) HIP_TRY(hipStreamWaitEvent(r->side[i], r->ev_fork, 0));
             r->main_dirty = false;
         }
-        hipLaunchKernelGGL(kernel, dim3(g.x, h1), dim3(VPT_BLOCK), lds, r->ctx->stream, lo);
-        hipLaunchKernelGGL(kernel, dim3(g.x, g.y - h1), dim3(VPT_BLOCK), lds, r->side, hi);
+        for (unsigned i = 0; i < k; i++) {            // tile rows [g.y * i / k, g.y * (i + 1) / k)
+            const unsigned y0 = g.y * i / k, y1 = g.y * (i + 1u) / k;
+            PassArgs part = a;
+            part.pm.ty0 = (int)y0;
+            hipLaunchKernelGGL(kernel, dim3(g.x, y1 - y0), dim3(VPT_BLOCK), lds, i == 0 ? r->ctx->stream : r->side[i - 1], part);
+        }
         r->side_busy = true;
     } else {
         hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a);
@@ -1216,13 +1221,13 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
         case VPT_OPTION_BOUNDARY_ATLAS: r->boundary_atlas = value != 0; return VPT_OK;
         case VPT_OPTION_SPLIT_STREAMS:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_SPLIT_STREAMS: MCM renderer only");
-            if (value != 1 && value != 2) return fail(VPT_ERR_INVALID, "VPT_OPTION_SPLIT_STREAMS: 1 or 2");
+            if (value < 1 || value > VPT_MAX_SPLIT) return fail(VPT_ERR_INVALID, "VPT_OPTION_SPLIT_STREAMS: 1 .. %d", VPT_MAX_SPLIT);
             VPT_TRY(join_side(r));
             HIP_TRY(hipSetDevice(r->ctx->device));
-            if (value == 2 && !r->side) {
-                HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
+            if (value >= 2 && !r->ev_fork) HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
+            for (int i = 0; i + 1 < value; i++) if (!r->side[i]) {
+                HIP_TRY(hipStreamCreateWithFlags(&r->side[i], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&r->ev_join[i], hipEventDisableTiming));
             }
             r->split = value; return VPT_OK;
         case VPT_OPTION_FAST_MATH:

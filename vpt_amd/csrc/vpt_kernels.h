@@ -812,9 +812,10 @@ VPT_DEV void fast_path_end(const PassArgs &a, const FastPixel &c, uint32_t &stat
         float inv = __builtin_copysignf(hw_rsq(dot3(d, d)), th.w);
         f3 dir = { d.x * inv, d.y * inv, d.z * inv };
         f3 iv = { hw_rcp(dir.x), hw_rcp(dir.y), hw_rcp(dir.z) };
-        float tx = vmin((0.0f - c.from0.x) * iv.x, (1.0f - c.from0.x) * iv.x);
-        float ty = vmin((0.0f - c.from0.y) * iv.y, (1.0f - c.from0.y) * iv.y);
-        float tz = vmin((0.0f - c.from0.z) * iv.z, (1.0f - c.from0.z) * iv.z);
+        // min((0 - f) * iv, (1 - f) * iv) = -f * iv + min(iv, 0): one min and one fma per slab
+        float tx = fmaf(-c.from0.x, iv.x, vmin(iv.x, 0.0f));
+        float ty = fmaf(-c.from0.y, iv.y, vmin(iv.y, 0.0f));
+        float tz = fmaf(-c.from0.z, iv.z, vmin(iv.z, 0.0f));
         float tnear = vmax(vmax(vmax(tx, ty), tz), 0.0f);
         ph.direction = dir;
         ph.position = madd3(c.from0, tnear, dir);
@@ -833,59 +834,15 @@ VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, 
     c.from0 = f3{ nb.x * inw, nb.y * inw, nb.z * inw };
     c.fb = mat4_mul_point(a.mvp_inv, px, py, 1.0f);
     c.jx = 0x1p-31f * a.inv_w; c.jy = 0x1p-31f * a.inv_h;
-    const float ld = -0.6931471805599453f * a.inv_extinction;
+    // -ln(u * 2^-32) / extinction = (log2(u) - 32) * ld
+    const float ld = -0.6931471805599453f * a.inv_extinction, ld32 = -32.0f * ld;
 
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
     for (uint32_t s = 0u; s < a.steps; s++) {
-        float dist = hw_log2(pcg_float(state) * 0x1p-32f) * ld;
+        float dist = fmaf(hw_log2(pcg_float(state)), ld, ld32);
         ph.position = madd3(ph.position, dist, ph.direction);
         f3 q = ph.position;
         bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
-#if defined(VPT_FAST_EARLY_RESET) && VPT_FAST_EARLY_RESET
-        if (!(V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32 | VPT_V_ALIGNED)) && a.vol.atlas != nullptr) {
-            // A photon outside the cube ends its path whatever the (discarded) sample says: the sample's loads are issued, the
-            // path is ended and re-started while they fly, and the sample is blended afterwards.  Same draws in the same order.
-            uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0; float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;   // shared by the two kinds of sample
-            if (oob) {
-                d0 = a.vol.atlas[boundary_cell(a.vol, q, f0, f1)];
-            } else {
-                uint32_t x, y, z;
-                linear_cell(q.x, a.vol.fnx, a.vol.hx, x, f0); linear_cell(q.y, a.vol.fny, a.vol.hy, y, f1); linear_cell(q.z, a.vol.fnz, a.vol.hz, z, f2);
-                const uint8_t *b = cell_addr<(V & VPT_V_WIDE) != 0>(a.vol, t, x, y, z);
-                uint64_t w0, w1;
-                __builtin_memcpy(&w0, b, 8); __builtin_memcpy(&w1, b + 25, 8);
-                d0 = (uint32_t)w0; d1 = (uint32_t)(w0 >> 32); d2 = (uint32_t)w1; d3 = (uint32_t)(w1 >> 32);
-            }
-            float wheel = pcg_float(state) * 0x1p-32f;
-            if (oob) {
-                float4 env = sample_environment(a.env, ph.direction);
-                fast_path_end(a, c, state, ph, f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z }, px, py);
-            }
-            asm volatile("" ::: "memory");
-            float r;
-            if (oob) r = boundary_blend(d0, f0, f1);
-            else {
-                float c00 = lerpf(cvt_ubyte<0>(d0), cvt_ubyte<1>(d0), f0), c10 = lerpf(cvt_ubyte<1>(d1), cvt_ubyte<2>(d1), f0);
-                float c01 = lerpf(cvt_ubyte<0>(d2), cvt_ubyte<1>(d2), f0), c11 = lerpf(cvt_ubyte<1>(d3), cvt_ubyte<2>(d3), f0);
-                r = lerpf(lerpf(c00, c10, f1), lerpf(c01, c11, f1), f2) * VPT_INV255;
-            }
-            float4 vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
-            asm volatile("" : "+v"(vs.w));
-            if (!oob) {
-                float p_null = 1.0f - vs.w;
-                float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
-                float p_abs = 1.0f - p_null - p_scat;
-                if (wheel < p_abs) {
-                    fast_path_end(a, c, state, ph, f3{ 0.0f, 0.0f, 0.0f }, px, py);
-                } else if (wheel < p_abs + p_scat) {
-                    ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
-                    ph.direction = sample_hg_fast(state, a.anisotropy, ph.direction);
-                    ph.bounces++;
-                }
-            }
-            continue;
-        }
-#endif
         float4 vs = mcm_sample<V>(a, t, q, oob);
         float p_null = 1.0f - vs.w;
         float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
