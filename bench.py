@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_ALG_MCM = 24.0          # algorithmic bytes per volume sample: 8 * sizeof(u8) + (64 B read + 64 B write) / steps(8)
+B_OWN_MCM = 22.0          # the same with this library's 56-byte photon state: 8 + (56 + 56) / 8
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -198,8 +199,9 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
         t_gen = time.perf_counter() - t0
         g1024 = vpt_amd.Volume.from_array(ctx, v, 'linear')
         del v
-        for name, fm in (("C4_mcm_1024_1080p", 0), ("C4_mcm_1024_1080p_fast_math", 1)):
-            t, ns = run('mcm', g1024, fast_math=fm)
+        for name, fm, sp in (("C4_mcm_1024_1080p", 0, 1), ("C4_mcm_1024_1080p_fast_math", 1, 1),
+                             ("C4_mcm_1024_1080p_three_streams", 0, 3), ("C4_mcm_1024_1080p_fast_math_three_streams", 1, 3)):
+            t, ns = run('mcm', g1024, fast_math=fm, split=sp)
             out[name] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "bytes_per_sample": B_ALG_MCM,
                          "roofline": {"frac": B_ALG_MCM * ns / t / (HBM_PEAK_GBS * 1e9), "achieved": B_ALG_MCM * ns / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
         out["C4_mcm_1024_1080p"]["volume_generate_s"] = t_gen
@@ -401,7 +403,11 @@ def main():
                              "duration_source": ("timed block / steps: the step's %d launches (tile-row ranges on %d HIP streams) overlap each other "
                                                  "and the next step's; HIP events around the first range's launch alone read %.4f ms" % (args.split_streams, args.split_streams, event_ms)) if split
                                                 else "HIP events around every %d-th launch on the kernel's stream" % max(args.profile_kernel, 1),
-                             "bytes_per_sample": bps},
+                             "bytes_per_sample": bps,
+                             # the kernel's own photon-state layout is 56 B per pixel each way (not the reference's 64): priced by
+                             # the bytes it moves itself, 8 + 112 / steps per sample
+                             "bytes_per_sample_own_layout": (B_OWN_MCM if args.renderer == "mcm" else bps),
+                             "frac_own_layout": achieved / HBM_PEAK_GBS * ((B_OWN_MCM / B_ALG_MCM) if args.renderer == "mcm" else 1.0)},
                 "frame_check": res["ok"],
             }
             if res.get("frame_check_kind"):
