@@ -302,8 +302,8 @@ def main():
             args.fast_math, args.split_streams = 0, 1       # MCM options
         if args.fast_math:
             r.set_option(N.OPTION_FAST_MATH, 1)
-        if world > 1:
-            args.split_streams = 1                    # every frame is handed to the gather: nothing to overlap across frames
+        # N > 1: the native pipeline keeps the ranges' streams apart across frames (its communication stream waits for every range);
+        # the torch.distributed pipeline renders into caller memory, where the library keeps the pass on one stream by itself
         if args.split_streams >= 2 and args.renderer == "mcm":
             r.set_option(N.OPTION_SPLIT_STREAMS, args.split_streams)
         if not args.boundary_atlas and args.renderer == "mcm":
@@ -344,7 +344,7 @@ def main():
             per_launch_samples = res["samples_local"] / max(args.steps, 1)
             avg_ms = res["kernel_ms"] / res["launches"] if res["launches"] else res["dt"] / args.steps * 1e3
             event_ms = avg_ms
-            split = args.split_streams >= 2 and args.renderer == "mcm" and not use_dist
+            split = args.split_streams >= 2 and args.renderer == "mcm" and (not use_dist or res["native"])
             if split:
                 # a step is K launches (K tile-row ranges on K streams) that overlap each other and the next step's: a
                 # per-launch duration no longer says what the chip does.  The chip-level rate is bytes of a step / time of a step.
@@ -388,7 +388,7 @@ def main():
                            "arithmetic": ("fast-math variant (VPT_OPTION_FAST_MATH: hardware rcp/rsq/sqrt/log/sin/cos; tolerance-checked against the "
                                           "contract oracle, tests/test_gpu_fast_math.py)" if args.fast_math else
                                           "bit-exact contract (every buffer identical to oracle/vpt_oracle.c)"),
-                           "boundary_atlas": bool(args.boundary_atlas), "split_streams": args.split_streams,
+                           "boundary_atlas": bool(args.boundary_atlas), "split_streams": args.split_streams if (args.renderer == "mcm" and (not use_dist or res["native"])) else 1,
                            "repeats": args.repeats, "block_ms_min": min(res["blocks_ms"]), "block_ms_max": max(res["blocks_ms"]),
                            "block_ms_median": res["dt"] * 1e3, "timed_block": "median of `repeats` blocks of `steps` steps"},
                 # `frac` prices the kernel against the HBM roofline by ALGORITHMIC bytes, as the metric is defined; what actually
@@ -573,6 +573,9 @@ def main():
                         whole = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, o2)
                         if args.extinction is not None:
                             whole.extinction = args.extinction
+                        if args.renderer == "mcm":                # the same kernel variant as the ranks ran
+                            whole.set_option(N.OPTION_FAST_MATH, int(bool(args.fast_math)))
+                            whole.set_option(N.OPTION_BOUNDARY_ATLAS, int(bool(args.boundary_atlas)))
                         whole.reset()
                         for _ in range(frames_done[0]):
                             whole.render()

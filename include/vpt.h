@@ -191,7 +191,9 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * the first on private side streams.  A pixel's pass depends on its own previous pass only, so consecutive passes of the
  * ranges never wait for each other and the launch gap, ramp and tail of one range overlap the body of the others (HIP
  * streams in place of one longer launch).  Every other entry point (reads, reset, tone mapper, gather, synchronize ...) first
- * joins the side streams into the context's stream, so callers see the usual in-order semantics.  Results identical. */
+ * joins the side streams into the context's stream, so callers see the usual in-order semantics; while the render buffer is
+ * redirected into caller memory (vpt_renderer_set_render_target, vpt_gather_*) passes stay on the context's stream, because the
+ * caller's own work on that stream reads the frame.  Results identical. */
 #define VPT_MAX_SPLIT 4
 #define VPT_OPTION_SPLIT_STREAMS 4
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);

@@ -2,6 +2,8 @@
 seeded inputs.  Bar: BIT-EXACT for every buffer (u8, f32 bit patterns, f16 bit patterns) — the kernels and
 the oracle implement the same fp32 operation sequence."""
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -418,6 +420,18 @@ def test_mcm_split_streams_give_identical_buffers(gpu_ctx, oracle, fast):
     sc.gvol.destroy()
 
 
+def test_mcm_split_streams_with_a_caller_owned_render_target():
+    """A frame rendered into caller memory (vpt_renderer_set_render_target) is read by work the CALLER enqueues on the
+    context's stream right behind render(): with VPT_OPTION_SPLIT_STREAMS on, such passes must not leave rows on a side
+    stream.  Runs in a fresh process (tests/render_target_worker.py): the consumer is a torch copy on torch's stream, and a
+    GPU-initialised torch stays out of this process."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "render_target_worker.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and out.strip().splitlines()[-1] == "OK", out[-2000:]
+
+
 @pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "mcm"])
 def test_wide_offset_tables_variant(gpu_ctx, oracle, kind):
     """the 64-bit brick-offset-table kernels (used above 4 GiB of bricked data, e.g. 2048^3) forced on a small volume"""
@@ -616,14 +630,19 @@ def test_play_frame_sequences_equal_render_calls(gpu_ctx, oracle, kind):
     sc.gvol.destroy()
 
 
+@pytest.mark.parametrize("split", [1, 3])
 @pytest.mark.parametrize("root", [-1, 0])
-def test_native_rccl_gather_play(gpu_ctx, oracle, root):
+def test_native_rccl_gather_play(gpu_ctx, oracle, root, split):
     """vpt_gather_play: frame sequences (kernel + cross-stream event edges + RCCL gather per frame) by one call (one-rank
-    comm); root = -1 all_gather, root = 0 gather to the display rank (which renders in place into its receive slot)"""
+    comm); root = -1 all_gather, root = 0 gather to the display rank (which renders in place into its receive slot);
+    split = 3: every pass as three tile-row ranges on three streams that are never joined between frames — the communication
+    stream waits for each range's event, and the ring's reverse edge (frame 16 on) holds all three streams back"""
     from vpt_amd.tiles import RcclFrameGather
     sc = Scene(gpu_ctx, oracle, 32, 100, 70, tf=colour_tf(64, 1), camera=orbit_camera(100 / 70))
     plain = sc.renderer('mcm'); plain.extinction = 9; plain.reset()
-    shard = sc.renderer('mcm', shard=(0, 1, 8)); shard.extinction = 9; shard.reset()
+    shard = sc.renderer('mcm', shard=(0, 1, 8)); shard.extinction = 9
+    shard.set_option(N.OPTION_SPLIT_STREAMS, split)
+    shard.reset()
     g = RcclFrameGather(shard, RcclFrameGather.unique_id(), 0, 1, root=root)
     assert g.receives()
     g.render(); g.render()

@@ -89,6 +89,30 @@ class VptError(RuntimeError):
 _lib = None
 
 
+def _share_the_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7, the same as
+    /opt/rocm's).  A process that imports torch first serves this library from torch's copy — one runtime, all is well
+    (bench.py, the multi-GPU hosts).  The other order leaves TWO runtimes in the process and torch then finds no GPU
+    ("No HIP GPUs are available"; measured, tools/r02_exp20.sh).  So when torch is installed but not imported yet, its copy of
+    the runtime is loaded first (by path, without importing torch): the order of imports stops mattering."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                                     # not loadable: the library falls back to /opt/rocm's runtime
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -97,6 +121,7 @@ def lib():
         raise ImportError(
             "libvpt_hip.so not found at %s — build it with `make -C vpt_amd/csrc` (or __graft_entry__.build()). "
             "vpt_amd has no CPU fallback." % LIB_PATH)
+    _share_the_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     P, I, SZ = C.c_void_p, C.c_int, C.c_size_t
     PP = C.POINTER(C.c_void_p)

@@ -95,6 +95,8 @@ struct vpt_renderer {
     // VPT_OPTION_SPLIT_STREAMS = K: the MCM pass is launched as K tile-row ranges, all but the first on private side streams.  A
     // pixel's pass depends on its own previous pass only, so the ranges never wait for each other: the launch gap, ramp and tail
     // of one overlap the body of the others.  Every other entry point joins the side streams into the context's stream first.
+    bool target_is_callers;        // render_target was set by vpt_renderer_set_render_target (not by the gather pipeline)
+    int last_ranges;               // how many tile-row ranges (streams) the last sampling launch used
     int split; hipStream_t side[VPT_MAX_SPLIT - 1]; hipEvent_t ev_fork, ev_join[VPT_MAX_SPLIT - 1]; bool side_busy, main_dirty;
     int boundary_atlas;            // VPT_OPTION_BOUNDARY_ATLAS (default 1): MCM takes out-of-cube samples from the volume's boundary atlas
     int fast_math;                 // VPT_OPTION_FAST_MATH: MCM events with hardware rcp / rsq / log / sin / cos (k_mcm_integrate<.., V | VPT_V_FAST>)
@@ -301,7 +303,7 @@ extern "C" int vpt_volume_finalize(vpt_volume *v) {
         hipLaunchKernelGGL(k_brickify_f32, dim3((unsigned)strips, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, (const float *)v->linear, (float *)v->bricks, v->nx, v->ny, v->nz, v->tabc);
         fast = strips;                                    // nothing left for the byte kernels
     } else if (fast > 0)
-        hipLaunchKernelGGL(k_brickify_strip, dim3((unsigned)fast, (unsigned)((nby + VPT_BRICKIFY_ROWS - 1) / VPT_BRICKIFY_ROWS), (unsigned)nbz), dim3(256), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->tabc);
+        hipLaunchKernelGGL(k_brickify_strip, dim3((unsigned)fast, (unsigned)((nby + VPT_BRICKIFY_ROWS - 1) / VPT_BRICKIFY_ROWS), (unsigned)((nbz + VPT_BRICKIFY_ROWS - 1) / VPT_BRICKIFY_ROWS)), dim3(256), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->tabc);
     if (fast < strips)
         hipLaunchKernelGGL(k_brickify, dim3((unsigned)(strips - fast), (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->channels, v->tabc, fast * VPT_BRICKIFY_RUN);
     if (v->atlas) {
@@ -365,7 +367,7 @@ static void renderer_free_buffers(vpt_renderer *r) {
 static int renderer_alloc_buffers(vpt_renderer *r) {
     vpt_context *c = r->ctx;
     if (r->play_graph) { hipStreamSynchronize(c->stream); play_graph_free(r->play_graph); r->play_graph = nullptr; }
-    r->render_target = nullptr;   // an external target was sized for the old geometry
+    r->render_target = nullptr; r->target_is_callers = false;   // an external target was sized for the old geometry
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     renderer_free_buffers(r);
@@ -465,7 +467,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
     r->fast_math = 0; r->boundary_atlas = 1;
-    r->split = 1; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->split = 1; r->target_is_callers = false; r->last_ranges = 1; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -621,7 +623,9 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     if (wave_blocks(r)) {
         dim3 g = tile_grid(r);
         hipLaunchKernelGGL(kernel, dim3(g.x * 4u, g.y), dim3(64), lds, r->ctx->stream, a);
-    } else if (r->split >= 2 && r->kind == VPT_RENDERER_MCM && r->tiles_y >= r->split) {
+    } else if (r->split >= 2 && r->kind == VPT_RENDERER_MCM && r->tiles_y >= r->split && !r->target_is_callers) {
+        // (a frame rendered into caller memory — vpt_renderer_set_render_target — is consumed by work the caller enqueues on the
+        // context's stream right behind it: such passes stay on that stream.  The gather pipeline waits for every range itself.)
         dim3 g = tile_grid(r);
         const unsigned k = (unsigned)r->split;
         if (r->main_dirty) {      // whatever the context's stream did to the renderer's buffers since the last join comes first
@@ -635,7 +639,7 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
             part.pm.ty0 = (int)y0;
             hipLaunchKernelGGL(kernel, dim3(g.x, y1 - y0), dim3(VPT_BLOCK), lds, i == 0 ? r->ctx->stream : r->side[i - 1], part);
         }
-        r->side_busy = true;
+        r->side_busy = true; r->last_ranges = (int)k;
     } else {
         hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a);
     }
@@ -1093,7 +1097,7 @@ extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t
     VPT_TRY(join_side(r));
     size_t need = (size_t)r->W * r->local_h * 8;
     if (ptr && nbytes < need) return fail(VPT_ERR_INVALID, "render target too small: %zu < %zu", nbytes, need);
-    r->render_target = (uint2 *)ptr;
+    r->render_target = (uint2 *)ptr; r->target_is_callers = ptr != nullptr;
     return VPT_OK;
 }
 // uOcclusionSamples: the RG32F row of DOSRenderer.js:103-140
@@ -1626,7 +1630,7 @@ struct vpt_gather {
     // the compute stream waits for it when it re-enters that half a whole ring later.  (With two buffers the reverse edge
     // was paid every frame: ~11 us of event traffic per frame at a 24 us kernel.)
     void *send[VPT_GATHER_RING], *recv[VPT_GATHER_RING];
-    hipEvent_t rendered[2], gathered[2];
+    hipEvent_t rendered[2][VPT_MAX_SPLIT], gathered[2];   // rendered: per tile-row range (stream) of a split pass
     uint64_t frames;
     void *assembled;                   // [H][W] RGBA16F scratch for read_frame
 };
@@ -1686,7 +1690,7 @@ extern "C" int vpt_gather_destroy(vpt_gather *g) {
         if (g->recv[b]) hipFree(g->recv[b]);
     }
     for (int b = 0; b < 2; b++) {
-        if (g->rendered[b]) hipEventDestroy(g->rendered[b]);
+        for (int i = 0; i < VPT_MAX_SPLIT; i++) if (g->rendered[b][i]) hipEventDestroy(g->rendered[b][i]);
         if (g->gathered[b]) hipEventDestroy(g->gathered[b]);
     }
     if (g->assembled) hipFree(g->assembled);
@@ -1707,7 +1711,7 @@ extern "C" int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, i
     int rc = VPT_OK;
     hipError_t e = hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking);
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
-        e = hipEventCreateWithFlags(&g->rendered[b], hipEventDisableTiming);
+        for (int i = 0; i < VPT_MAX_SPLIT && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->rendered[b][i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->gathered[b], hipEventDisableTiming);
     }
     for (int b = 0; b < VPT_GATHER_RING && e == hipSuccess; b++) {
@@ -1808,7 +1812,11 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
     vpt_gather_step st;
     VPT_TRY(vpt_gather_plan(g->frames, g->rank, g->world, g->root, g->send_bytes, &st));
     const int b = st.buffer;
-    if (st.wait_gathered) HIP_TRY(hipStreamWaitEvent(cs, g->gathered[st.parity], 0));
+    if (st.wait_gathered) {                                                  // on every stream that may carry a range of this frame
+        HIP_TRY(hipStreamWaitEvent(cs, g->gathered[st.parity], 0));
+        for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) if (r->side[i]) HIP_TRY(hipStreamWaitEvent(r->side[i], g->gathered[st.parity], 0));
+    }
+    r->last_ranges = 1;
     a.render = st.in_place ? (uint2 *)((char *)g->recv[b] + st.render_offset) : (uint2 *)g->send[b];
     r->render_target = a.render;                                             // vpt_renderer_read(RENDER) returns the last frame's rows
     if (t0) HIP_TRY(hipEventRecord(t0, cs));
@@ -1819,9 +1827,13 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
         VPT_TRY(launch_fused(r, a));
     }
     if (t1) HIP_TRY(hipEventRecord(t1, cs));
-    VPT_TRY(join_side(r));                                                   // a split pass: both row ranges are in the frame
-    HIP_TRY(hipEventRecord(g->rendered[st.rendered_event], cs));
-    HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[st.rendered_event], 0));
+    // A split pass (VPT_OPTION_SPLIT_STREAMS): the communication stream waits for every range; the ranges' streams are NOT joined,
+    // so range i of the next frame starts behind range i of this one, whatever the other ranges and the gather are doing.
+    for (int i = 0; i < r->last_ranges; i++) {
+        hipStream_t s = i == 0 ? cs : r->side[i - 1];
+        HIP_TRY(hipEventRecord(g->rendered[st.rendered_event][i], s));
+        HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[st.rendered_event][i], 0));
+    }
     if (st.op == VPT_GATHER_OP_ALLGATHER) {
         RCCL_TRY(g_rccl.AllGather(g->send[b], g->recv[b], g->send_bytes, /*ncclUint8*/ 1, g->comm, g->comm_stream));
     } else if (st.op != VPT_GATHER_OP_NONE) {

@@ -1055,40 +1055,62 @@ __global__ void __launch_bounds__(128) k_brickify(const uint8_t *lin, uint8_t *b
 }
 
 // The same re-layout for one-channel volumes whose rows are dword-aligned (nx % 4 == 0), staged through LDS: a workgroup
-// takes a strip of 16 bricks along x (64 voxels + the apron column) — 25 source rows of 17 dwords, loaded as dwords —
-// and writes the brick slots as dwords (4 LDS byte reads each).
-#define VPT_BRICKIFY_ROWS 4       // brick rows (in y) per workgroup of k_brickify_strip: 16 x 4 bricks, 17 source rows per z slice
+// takes a block of 16 x 4 x 4 bricks (64 x 16 x 16 voxels + the apron column, row and slice): 17 x 17 source rows of 17
+// dwords, loaded as dwords with all of a thread's loads in flight before its first LDS write, then writes the 256 brick
+// slots as 16-byte pieces in the order of the brick codes — with Z-order codes the block is four contiguous 8 KiB runs of the
+// brick array (a wave instruction = eight whole consecutive slots).  No division in either loop.
+#define VPT_BRICKIFY_ROWS 4       // brick rows (y) and brick layers (z) per workgroup of k_brickify_strip
 __global__ void __launch_bounds__(256) k_brickify_strip(const uint8_t *lin, uint8_t *bricks, int nx, int ny, int nz, const uint32_t *codes) {
-    constexpr int NR = VPT_BRICK * VPT_BRICKIFY_ROWS + 1;                             // 17 voxel rows incl. the apron row
-    __shared__ uint32_t rows[5 * NR][17];
-    const int by0 = (int)blockIdx.y * VPT_BRICKIFY_ROWS, bz = (int)blockIdx.z, t = (int)threadIdx.x;
-    const int nby = (ny + VPT_BRICK - 1) / VPT_BRICK;
+    constexpr int NR = VPT_BRICK * VPT_BRICKIFY_ROWS + 1;                             // 17 voxel rows / slices incl. the apron
+    __shared__ uint32_t rows[NR * NR][17];
+    const int by0 = (int)blockIdx.y * VPT_BRICKIFY_ROWS, bz0 = (int)blockIdx.z * VPT_BRICKIFY_ROWS, t = (int)threadIdx.x;
+    const int nby = (ny + VPT_BRICK - 1) / VPT_BRICK, nbz = (nz + VPT_BRICK - 1) / VPT_BRICK;
     const int x0 = (int)blockIdx.x * (VPT_BRICK * VPT_BRICKIFY_RUN);                 // multiple of 64; nx % 4 == 0 guaranteed by the launch
-    for (int q = t; q < 5 * NR * 17; q += 256) {
-        int r = q / 17, d = q - r * 17;
-        int y = min(by0 * VPT_BRICK + (r % NR), ny - 1), z = min(bz * VPT_BRICK + (r / NR), nz - 1);
-        const uint8_t *row = lin + ((size_t)z * ny + y) * nx;
-        // past the row's end (the apron of the last brick column, the unused tail of a partial strip): voxel nx-1 replicated
-        rows[r][d] = (x0 + 4 * d < nx) ? *(const uint32_t *)(row + x0 + 4 * d) : (uint32_t)row[nx - 1] * 0x01010101u;
+    {   // thread t < 255 loads dword d = t % 17 of the rows t / 17 + 15 i, i = 0 .. 19 (row r = slice r / 17, voxel row r % 17)
+        const int d = t % 17, r0 = t / 17;
+        if (t < 255) {
+            // past the row's end (the apron of the last brick column, the unused tail of a partial strip): voxel nx-1 replicated
+            const bool inside = x0 + 4 * d < nx;
+            uint32_t v[20];
+            int ry = r0, zi = 0;
+#pragma unroll
+            for (int i = 0; i < 20; i++) {
+                if (zi < NR) {
+                    const int y = min(by0 * VPT_BRICK + ry, ny - 1), z = min(bz0 * VPT_BRICK + zi, nz - 1);
+                    const uint8_t *row = lin + ((size_t)z * ny + y) * nx;
+                    v[i] = inside ? *(const uint32_t *)(row + x0 + 4 * d) : (uint32_t)row[nx - 1] * 0x01010101u;
+                }
+                ry += 15; if (ry >= NR) { ry -= NR; zi++; }
+            }
+            int r = r0;
+#pragma unroll
+            for (int i = 0; i < 20; i++) {
+                if (r < NR * NR) rows[r][d] = v[i];
+                r += 15;
+            }
+        }
     }
     __syncthreads();
     const uint8_t *lb = (const uint8_t *)rows;
-    const uint32_t cz = codes[nx + ny + 4 * bz];
-    for (int q = t; q < VPT_BRICKIFY_RUN * VPT_BRICKIFY_ROWS * 32; q += 256) {
-        int u = q >> 5, w = q & 31;                          // brick u of the 16 x 4 block, dword w of its slot (bytes 4w .. 4w+3)
-        int ux = u & (VPT_BRICKIFY_RUN - 1), uy = u / VPT_BRICKIFY_RUN;
-        if (by0 + uy >= nby || x0 + 4 * ux >= nx) continue;
-        uint32_t out = 0;
+    const int w8 = t & 7, s = t >> 3;                        // 16-byte piece w8 of brick u = s + 32 it of the block
+    // byte b = 16 w8 + k of a brick = voxel (lx, ly, lz), b = lx + 5 ly + 25 lz; 125..127 are padding
+    const int b0 = 16 * w8, lz0 = b0 / 25, rem0 = b0 - 25 * lz0, ly0 = rem0 / 5, lx0 = rem0 - 5 * ly0;
+#pragma unroll 2
+    for (int it = 0; it < 8; it++) {
+        // u in Z-order over the low two bits of (ux, uy, uz), then the high bits of ux: consecutive u = consecutive brick codes
+        const int u = s + 32 * it;
+        const int ux = (u & 1) | ((u >> 2) & 2) | ((u >> 4) & 12), uy = ((u >> 1) & 1) | ((u >> 3) & 2), uz = ((u >> 2) & 1) | ((u >> 4) & 2);
+        if (x0 + 4 * ux >= nx || by0 + uy >= nby || bz0 + uz >= nbz) continue;
+        const int base = ((VPT_BRICK * uz) * NR + VPT_BRICK * uy) * 68 + 4 * ux;
+        uint32_t o[4] = { 0u, 0u, 0u, 0u };
+        int lx = lx0, ly = ly0, lz = lz0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int b = 4 * w + k;                               // byte b of the brick = voxel (lx, ly, lz), b = lx + 5 ly + 25 lz; 125..127 are padding
-            if (b < 125) {
-                int lz = b / 25, rem = b - 25 * lz, ly = rem / 5, lx = rem - 5 * ly;
-                out |= (uint32_t)lb[(lz * NR + VPT_BRICK * uy + ly) * 68 + 4 * ux + lx] << (8 * k);
-            }
+        for (int k = 0; k < 16; k++) {
+            if (b0 + k < 125) o[k >> 2] |= (uint32_t)lb[base + (lz * NR + ly) * 68 + lx] << (8 * (k & 3));
+            if (++lx == 5) { lx = 0; if (++ly == 5) { ly = 0; lz++; } }
         }
-        size_t slot = (size_t)(codes[x0 + 4 * ux] + codes[nx + 4 * (by0 + uy)] + cz) << 7;
-        *(uint32_t *)(bricks + slot + 4 * w) = out;
+        const size_t slot = (size_t)(codes[x0 + 4 * ux] + codes[nx + 4 * (by0 + uy)] + codes[nx + ny + 4 * (bz0 + uz)]) << 7;
+        *(uint4 *)(bricks + slot + 16 * w8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
