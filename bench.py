@@ -303,7 +303,12 @@ def main():
         if args.fast_math:
             r.set_option(N.OPTION_FAST_MATH, 1)
         # N > 1: the native pipeline keeps the ranges' streams apart across frames (its communication stream waits for every range);
-        # the torch.distributed pipeline renders into caller memory, where the library keeps the pass on one stream by itself
+        # the torch.distributed pipeline renders into caller memory, where the library keeps the pass on one stream by itself.
+        # Every range costs the host a launch, an event record and a stream wait per frame: measured on one GPU with frames of a
+        # shard's size (tools/r02_exp22.sh, r02_exp24.sh), three ranges pay from ~500 rows of 1920 pixels on (N <= 2 at 1080p) and
+        # lose below.
+        if use_dist and args.split_streams >= 2 and int(r.local_rows()) * W < 500 * 1920:
+            args.split_streams = 1
         if args.split_streams >= 2 and args.renderer == "mcm":
             r.set_option(N.OPTION_SPLIT_STREAMS, args.split_streams)
         if not args.boundary_atlas and args.renderer == "mcm":

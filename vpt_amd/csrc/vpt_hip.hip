@@ -3,6 +3,7 @@
 //        -fno-gpu-flush-denormals-to-zero -shared -fPIC (see vpt_amd/csrc/Makefile)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -97,6 +98,8 @@ struct vpt_renderer {
     // of one overlap the body of the others.  Every other entry point joins the side streams into the context's stream first.
     bool target_is_callers;        // render_target was set by vpt_renderer_set_render_target (not by the gather pipeline)
     int last_ranges;               // how many tile-row ranges (streams) the last sampling launch used
+    hipEvent_t *stop_events;       // gather pipeline: event i is attached to range i's launch (hipExtLaunchKernel stop event: the
+    bool stop_used;                // dispatch packet's own completion signal, no barrier packet behind the kernel)
     int split; hipStream_t side[VPT_MAX_SPLIT - 1]; hipEvent_t ev_fork, ev_join[VPT_MAX_SPLIT - 1]; bool side_busy, main_dirty;
     int boundary_atlas;            // VPT_OPTION_BOUNDARY_ATLAS (default 1): MCM takes out-of-cube samples from the volume's boundary atlas
     int fast_math;                 // VPT_OPTION_FAST_MATH: MCM events with hardware rcp / rsq / log / sin / cos (k_mcm_integrate<.., V | VPT_V_FAST>)
@@ -467,7 +470,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
     r->fast_math = 0; r->boundary_atlas = 1;
-    r->split = 1; r->target_is_callers = false; r->last_ranges = 1; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->split = 1; r->target_is_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -615,6 +618,16 @@ static int join_side(vpt_renderer *r) {
     r->side_busy = false; r->main_dirty = true;
     return VPT_OK;
 }
+// one sampling launch; in the gather pipeline the range's "rendered" event rides on the dispatch itself
+template <typename K>
+static void launch_range(K kernel, vpt_renderer *r, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const PassArgs &a, int range) {
+    if (r->stop_events) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, nullptr, r->stop_events[range], 0, a);
+        r->stop_used = true;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
+    }
+}
 template <typename K>
 static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigned) {
     size_t lds = lds_bytes(r);
@@ -622,7 +635,7 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (wave_blocks(r)) {
         dim3 g = tile_grid(r);
-        hipLaunchKernelGGL(kernel, dim3(g.x * 4u, g.y), dim3(64), lds, r->ctx->stream, a);
+        launch_range(kernel, r, dim3(g.x * 4u, g.y), dim3(64), lds, r->ctx->stream, a, 0);
     } else if (r->split >= 2 && r->kind == VPT_RENDERER_MCM && r->tiles_y >= r->split && !r->target_is_callers) {
         // (a frame rendered into caller memory — vpt_renderer_set_render_target — is consumed by work the caller enqueues on the
         // context's stream right behind it: such passes stay on that stream.  The gather pipeline waits for every range itself.)
@@ -637,11 +650,11 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
             const unsigned y0 = g.y * i / k, y1 = g.y * (i + 1u) / k;
             PassArgs part = a;
             part.pm.ty0 = (int)y0;
-            hipLaunchKernelGGL(kernel, dim3(g.x, y1 - y0), dim3(VPT_BLOCK), lds, i == 0 ? r->ctx->stream : r->side[i - 1], part);
+            launch_range(kernel, r, dim3(g.x, y1 - y0), dim3(VPT_BLOCK), lds, i == 0 ? r->ctx->stream : r->side[i - 1], part, (int)i);
         }
         r->side_busy = true; r->last_ranges = (int)k;
     } else {
-        hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a);
+        launch_range(kernel, r, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a, 0);
     }
     return VPT_OK;
 }
@@ -1817,6 +1830,9 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
         for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) if (r->side[i]) HIP_TRY(hipStreamWaitEvent(r->side[i], g->gathered[st.parity], 0));
     }
     r->last_ranges = 1;
+    // the "rendered" events ride on the dispatches themselves (hipExtLaunchKernel stop events): a hipEventRecord behind the kernel
+    // is a barrier packet of its own on the compute queue, 3-4.5 us per frame at every frame size (tools/r02_exp24.sh)
+    r->stop_events = fused_passes ? nullptr : g->rendered[st.rendered_event]; r->stop_used = false;
     a.render = st.in_place ? (uint2 *)((char *)g->recv[b] + st.render_offset) : (uint2 *)g->send[b];
     r->render_target = a.render;                                             // vpt_renderer_read(RENDER) returns the last frame's rows
     if (t0) HIP_TRY(hipEventRecord(t0, cs));
@@ -1829,9 +1845,11 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
     if (t1) HIP_TRY(hipEventRecord(t1, cs));
     // A split pass (VPT_OPTION_SPLIT_STREAMS): the communication stream waits for every range; the ranges' streams are NOT joined,
     // so range i of the next frame starts behind range i of this one, whatever the other ranges and the gather are doing.
+    const bool rode = r->stop_used;                                          // the events were attached to the launches themselves
+    r->stop_events = nullptr; r->stop_used = false;
     for (int i = 0; i < r->last_ranges; i++) {
         hipStream_t s = i == 0 ? cs : r->side[i - 1];
-        HIP_TRY(hipEventRecord(g->rendered[st.rendered_event][i], s));
+        if (!rode) HIP_TRY(hipEventRecord(g->rendered[st.rendered_event][i], s));
         HIP_TRY(hipStreamWaitEvent(g->comm_stream, g->rendered[st.rendered_event][i], 0));
     }
     if (st.op == VPT_GATHER_OP_ALLGATHER) {
