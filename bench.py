@@ -211,6 +211,28 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
                              ("H_mcm_512_1080p_fast_math_one_stream", 1, 1), ("H_mcm_512_1080p_fast_math_three_streams", 1, 3)):
             t, ns = run('mcm', gvol512, frames=200, fast_math=fm, split=sp)
             out[name] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "roofline": {"frac": B_ALG_MCM * ns / t / (HBM_PEAK_GBS * 1e9)}}
+        # NOT the judged form: 16 passes per launch with the photon state in registers (VPT_PLAY_FUSED), the render buffer written
+        # after the 16th only — a display mode ("show every 16th pass"); it says what the state round trip costs the judged form
+        for name, fm in (("H_mcm_512_1080p_bit_exact_display_every_16th_pass", 0), ("H_mcm_512_1080p_fast_math_display_every_16th_pass", 1)):
+            r = vpt_amd.RendererFactory('mcm')(ctx, gvol512, default_camera(W / H), None,
+                                               {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+            r.set_option(N.OPTION_FAST_MATH, fm)
+            r.reset()
+            for _ in range(4):
+                r.play(16, fused=True)
+            ctx.synchronize()
+            blocks = []
+            for _ in range(3):
+                r.clear_sample_count()
+                t0 = time.perf_counter()
+                for _ in range(12):
+                    r.play(16, fused=True)
+                ctx.synchronize()
+                blocks.append((time.perf_counter() - t0, r.sample_count()))
+            dt, ns = sorted(blocks)[1]
+            r.destroy()
+            out[name] = {"ms_per_pass": dt / (12 * 16) * 1e3, "samples_per_s": ns / dt, "passes_per_launch": 16,
+                         "note": "not the judged step: one launch = 16 passes, one render-buffer write"}
     except Exception as e:                              # reporting only: the headline line must still be printed
         out["error"] = repr(e)
     return out
