@@ -72,6 +72,11 @@ def parse():
                     help="MCM: 0 = out-of-cube samples from the bricks as well (VPT_OPTION_BOUNDARY_ATLAS off; results identical)")
     ap.add_argument("--split-streams", type=int, default=3,
                     help="MCM: K >= 2 = launch every pass as K tile-row ranges on K HIP streams (VPT_OPTION_SPLIT_STREAMS; results identical)")
+    ap.add_argument("--split-caller-targets", type=int, default=0,
+                    help="torch.distributed pipeline: 1 = split passes into the gather's buckets too and join once per bucket (measured: no gain)")
+    ap.add_argument("--frames-per-gather", type=int, default=4,
+                    help="torch.distributed pipeline: frames per all_gather (every frame is delivered; one async collective costs the host "
+                         "~25 us whatever its size, more than a 1/8 shard's kernel takes)")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
     return ap.parse_args()
 
@@ -309,7 +314,7 @@ def main():
     with torch.cuda.stream(stream):
         ctx = vpt_amd.Context(local_rank, stream=stream.cuda_stream)
         gvol = vpt_amd.Volume.from_array(ctx, vol, 'linear')
-        gather = FrameGather(dist, torch, W, H, device, always_collective=bool(args.force_dist))
+        gather = FrameGather(dist, torch, W, H, device, always_collective=bool(args.force_dist), frames_per_gather=max(1, args.frames_per_gather))
         camera = default_camera(W / H)
         transform = Transform(Node())
         opts = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng(), 'fused': bool(args.fused)}
@@ -333,6 +338,12 @@ def main():
             args.split_streams = 1
         if args.split_streams >= 2 and args.renderer == "mcm":
             r.set_option(N.OPTION_SPLIT_STREAMS, args.split_streams)
+        # The torch.distributed pipeline hands whole buckets of frames to a collective and could join the ranges once per bucket
+        # itself (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join): measured on a one-rank RCCL group it gains nothing there
+        # (1920x1080: 122.6 us one stream, 124.9 us three; x544: 66.4 / 66.2 - tools/r02_exp29.sh), so those passes stay on one stream.
+        split_callers = bool(args.split_caller_targets and use_dist and args.split_streams >= 2 and args.renderer == "mcm")
+        if split_callers:
+            r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
         if not args.boundary_atlas and args.renderer == "mcm":
             r.set_option(N.OPTION_BOUNDARY_ATLAS, 0)
         if args.mcs_persistent >= 0:
@@ -371,7 +382,7 @@ def main():
             per_launch_samples = res["samples_local"] / max(args.steps, 1)
             avg_ms = res["kernel_ms"] / res["launches"] if res["launches"] else res["dt"] / args.steps * 1e3
             event_ms = avg_ms
-            split = args.split_streams >= 2 and args.renderer == "mcm" and (not use_dist or res["native"])
+            split = args.split_streams >= 2 and args.renderer == "mcm" and (not use_dist or res["native"] or split_callers)
             if split:
                 # a step is K launches (K tile-row ranges on K streams) that overlap each other and the next step's: a
                 # per-launch duration no longer says what the chip does.  The chip-level rate is bytes of a step / time of a step.
@@ -396,7 +407,7 @@ def main():
                 par = "image rows sharded over %d GPU(s), per-frame RCCL %s (native pipeline below the C ABI)" % (
                     world, ("gather to rank %d" % res["root"]) if res["root"] >= 0 else "all_gather")
             else:
-                par = "image rows sharded over %d GPU(s), per-frame RCCL all_gather (torch.distributed pipeline)" % world
+                par = "image rows sharded over %d GPU(s), RCCL all_gather of every %d frames (torch.distributed pipeline)" % (world, gather.F)
             line = {
                 "metric": "volume samples/s, MCM %d^3 @ %dx%d" % (args.volume, W, H) if args.renderer == "mcm"
                           else "volume samples/s, %s %d^3 @ %dx%d" % (args.renderer.upper(), args.volume, W, H),
@@ -409,13 +420,14 @@ def main():
                                        "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
                            "parallelism": par,
                            "gather_calibration": res["gather_choice"],
+                           "frames_per_gather": (gather.F if (use_dist and not res["native"]) else None),
                            "frames_per_launch": f, "hipgraph": bool(args.graph) and f > 1 and not res["native"] and not args.fused_passes,
                            "fused_passes": bool(args.fused_passes) and f > 1,
                            "samples_per_step": res["samples"] / args.steps,
                            "arithmetic": ("fast-math variant (VPT_OPTION_FAST_MATH: hardware rcp/rsq/sqrt/log/sin/cos; tolerance-checked against the "
                                           "contract oracle, tests/test_gpu_fast_math.py)" if args.fast_math else
                                           "bit-exact contract (every buffer identical to oracle/vpt_oracle.c)"),
-                           "boundary_atlas": bool(args.boundary_atlas), "split_streams": args.split_streams if (args.renderer == "mcm" and (not use_dist or res["native"])) else 1,
+                           "boundary_atlas": bool(args.boundary_atlas), "split_streams": args.split_streams if (args.renderer == "mcm" and (not use_dist or res["native"] or split_callers)) else 1,
                            "repeats": args.repeats, "block_ms_min": min(res["blocks_ms"]), "block_ms_max": max(res["blocks_ms"]),
                            "block_ms_median": res["dt"] * 1e3, "timed_block": "median of `repeats` blocks of `steps` steps"},
                 # `frac` prices the kernel against the HBM roofline by ALGORITHMIC bytes, as the metric is defined; what actually
@@ -458,17 +470,19 @@ def main():
             if not use_dist:
                 r.render()                           # one GPU: the renderer's own render buffer, nothing to exchange
                 return
-            b = k & 1
-            gather.wait(b)
-            r.set_render_target(gather.send[b].data_ptr(), nbytes)
+            r.set_render_target(gather.acquire().data_ptr(), nbytes)    # the next slot of the current bucket
             r.render()
-            gather.gather(b)
+            if split_callers and gather.bucket_closes():
+                r.join()                             # the collective reads the bucket on this stream: every range must be in
+            gather.commit()                          # a full bucket of --frames-per-gather frames: one all_gather
 
         def drain():
             if use_native[0]:
                 native.synchronize()
             else:
-                gather.wait(0); gather.wait(1)
+                if split_callers:
+                    r.join()
+                gather.flush(); gather.wait_all()
 
         frames_done = [0]
 
@@ -610,11 +624,27 @@ def main():
                         whole.destroy()
                         ok = ok and same
                 else:
-                    b = (args.steps - 1) & 1
-                    frame = gather.frame(b)
+                    frame = gather.last_frame()                         # every rank holds the assembled frame
                     rows = torch.as_tensor(rows_np, device=device)
                     valid = rows >= 0
-                    ok = bool(torch.equal(frame.index_select(0, rows[valid]), gather.send[b][valid]))
+                    ok = bool(torch.equal(frame.index_select(0, rows[valid]), gather.last_sent()[valid]))
+                    if world > 1 or args.force_dist:
+                        # and the same frames rendered UNSHARDED on this GPU must give the gathered frame bit for bit
+                        torch.cuda.synchronize()
+                        r.set_render_target(0, 0)
+                        o2 = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng(), 'fused': bool(args.fused)}
+                        whole = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, o2)
+                        if args.extinction is not None:
+                            whole.extinction = args.extinction
+                        if args.renderer == "mcm":
+                            whole.set_option(N.OPTION_FAST_MATH, int(bool(args.fast_math)))
+                            whole.set_option(N.OPTION_BOUNDARY_ATLAS, int(bool(args.boundary_atlas)))
+                        whole.reset()
+                        for _ in range(frames_done[0]):
+                            whole.render()
+                        same = bool((whole.getTexture().view(np.uint16) == frame.cpu().numpy().view(np.uint16)).all())
+                        whole.destroy()
+                        ok = ok and same
             torch.cuda.synchronize()
             res["ok"] = ok
             res["root"] = native.root if use_native[0] else -1

@@ -196,7 +196,15 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * caller's own work on that stream reads the frame.  Results identical. */
 #define VPT_MAX_SPLIT 4
 #define VPT_OPTION_SPLIT_STREAMS 4
+/* VPT_OPTION_SPLIT_CALLER_TARGETS (default 0; MCM renderer): 1 = passes into a caller-owned render target are split as well.  The
+ * caller then owes a vpt_renderer_join() before work of its own on the context's stream reads the target — e.g. once per bucket
+ * of frames handed to a collective, not once per frame (vpt_amd/tiles.py FrameGather, bench.py --gather torch). */
+#define VPT_OPTION_SPLIT_CALLER_TARGETS 5
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
+/* Joins the side streams of a split pass (VPT_OPTION_SPLIT_STREAMS) into the context's stream: everything enqueued on that
+ * stream afterwards sees every range of the passes enqueued so far.  A no-op when nothing is pending.  Every other entry point
+ * that touches the renderer's buffers does this by itself. */
+VPT_API int vpt_renderer_join(vpt_renderer *r);
 /* the LAO renderer's own uniforms (gl.uniform* calls of LAORenderer.js:159-169; uStepSize and uExtinction travel in
  * vpt_uniforms); defaults are the reference's property defaults (LAORenderer.js:17-108) */
 struct vpt_lao_params {

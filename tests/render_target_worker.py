@@ -26,26 +26,32 @@ def main():
     gvol = vpt_amd.Volume.from_array(ctx, sphere_volume(64, noise=40.0), 'linear')
     cam, tr = default_camera(W / H), Transform(Node())
     outs = []
-    for split in (1, 3):
+    # (split, caller joins): one stream; three ranges kept on the context's stream by the library; three ranges on three streams
+    # with VPT_OPTION_SPLIT_CALLER_TARGETS and a vpt_renderer_join() before the consumer
+    for split, caller_joins in ((1, False), (3, False), (3, True)):
         r = vpt_amd.MCMRenderer(ctx, gvol, cam, None, {'resolution': (W, H), 'transform': tr, 'rng': GoldenRatioRng()})
         r.set_option(N.OPTION_SPLIT_STREAMS, split)
+        r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, int(caller_joins))
         target = torch.zeros((H, W, 4), dtype=torch.float16, device=dev)
         r.set_render_target(target.data_ptr(), target.numel() * 2)
         r.reset()
         copies = []
         for _ in range(6):
             r.render()
+            if caller_joins:
+                r.join()
             copies.append(target.clone())                 # enqueued on the context's stream, straight behind the pass
         torch.cuda.synchronize()
         outs.append([c.cpu().numpy() for c in copies])
         r.set_render_target(0, 0)
         r.destroy()
     ok = True
-    for k, (a, b) in enumerate(zip(*outs)):
-        same = bool((a.view(np.uint16) == b.view(np.uint16)).all())
-        if not same:
-            sys.stderr.write("frame %d: the copy behind a 3-range pass differs from the one-stream run's\n" % k)
-        ok = ok and same
+    for which in (1, 2):
+        for k, (a, b) in enumerate(zip(outs[0], outs[which])):
+            same = bool((a.view(np.uint16) == b.view(np.uint16)).all())
+            if not same:
+                sys.stderr.write("configuration %d, frame %d: the copy behind a 3-range pass differs from the one-stream run's\n" % (which, k))
+            ok = ok and same
     last = outs[0][-1]
     ok = ok and bool(np.isfinite(last.astype(np.float32)).all()) and bool((last[..., 3] == 1).all())
     gvol.destroy(); ctx.destroy()

@@ -37,6 +37,26 @@ WORKER = textwrap.dedent("""
             assert (img[:, :, 0] == torch.arange(H, dtype=torch.float16)[:, None]).all()
             assert (img[:, :, 1] == torch.arange(W, dtype=torch.float16)[None, :]).all()
             assert (img[:, :, 2] == frame).all() and (img[:, :, 3] == 1).all()
+    # bucketed exchange: F frames per all_gather through the streaming interface (what bench.py drives), with a partial
+    # bucket flushed by last_frame() and a new bucket started after it
+    for F in (3, 4):
+        g = FrameGather(dist, torch, W, H, torch.device("cpu"), frames_per_gather=F)
+        owner, lrow = row_owner(H, world, 8)
+        mine = torch.as_tensor(np.nonzero(owner == rank)[0])
+        for frame in range(11):
+            t = g.acquire()
+            assert t.shape == (g.rows, W, 4)
+            t.zero_()
+            t[torch.as_tensor(lrow)[mine], :, 0] = mine.to(torch.float16)[:, None]
+            t[torch.as_tensor(lrow)[mine], :, 2] = frame
+            g.commit()
+            if frame in (0, 2, 3, 6, 10):                     # mid-bucket, bucket end, after a flush
+                img = g.last_frame()
+                assert img.shape == (H, W, 4)
+                assert (img[:, :, 0] == torch.arange(H, dtype=torch.float16)[:, None]).all(), (F, frame)
+                assert (img[:, :, 2] == frame).all(), (F, frame)
+                assert (g.last_sent()[torch.as_tensor(lrow)[mine], :, 2] == frame).all()
+        g.flush(); g.wait_all()
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")

@@ -42,6 +42,8 @@ def main():
         full = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
         full.set_option(N.OPTION_FAST_MATH, fast); full.reset()
         out["full_frame_%s" % tag] = timed(ctx, full.render, 200)
+        full.set_option(N.OPTION_SPLIT_STREAMS, 3)
+        out["full_frame_three_streams_%s" % tag] = timed(ctx, full.render, 200)      # the N = 1 default of bench.py
         full.destroy()
         sh = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng(), 'shard': (3, 8, 8)})
         sh.set_option(N.OPTION_FAST_MATH, fast); sh.reset()
@@ -66,6 +68,7 @@ def main():
         k, hnd = out["shard_3_of_8_kernel_%s" % tag], max(out["handoff_root0_%s" % tag], 0.0)
         out["per_rank_frame_%s" % tag] = k + hnd
         out["projected_speedup_at_8_%s" % tag] = out["full_frame_%s" % tag] / (k + hnd)
+        out["projected_speedup_at_8_vs_three_streams_%s" % tag] = out["full_frame_three_streams_%s" % tag] / (k + hnd)
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 1:
         json.dump(out, open(sys.argv[1], "w"), indent=1)

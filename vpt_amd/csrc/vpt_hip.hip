@@ -97,6 +97,7 @@ struct vpt_renderer {
     // pixel's pass depends on its own previous pass only, so the ranges never wait for each other: the launch gap, ramp and tail
     // of one overlap the body of the others.  Every other entry point joins the side streams into the context's stream first.
     bool target_is_callers;        // render_target was set by vpt_renderer_set_render_target (not by the gather pipeline)
+    bool split_callers;            // VPT_OPTION_SPLIT_CALLER_TARGETS: such passes are split too, the caller joins (vpt_renderer_join)
     int last_ranges;               // how many tile-row ranges (streams) the last sampling launch used
     hipEvent_t *stop_events;       // gather pipeline: event i is attached to range i's launch (hipExtLaunchKernel stop event: the
     bool stop_used;                // dispatch packet's own completion signal, no barrier packet behind the kernel)
@@ -470,7 +471,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
     r->fast_math = 0; r->boundary_atlas = 1;
-    r->split = 1; r->target_is_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->split = 1; r->target_is_callers = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -636,9 +637,10 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     if (wave_blocks(r)) {
         dim3 g = tile_grid(r);
         launch_range(kernel, r, dim3(g.x * 4u, g.y), dim3(64), lds, r->ctx->stream, a, 0);
-    } else if (r->split >= 2 && r->kind == VPT_RENDERER_MCM && r->tiles_y >= r->split && !r->target_is_callers) {
+    } else if (r->split >= 2 && r->kind == VPT_RENDERER_MCM && r->tiles_y >= r->split && (!r->target_is_callers || r->split_callers)) {
         // (a frame rendered into caller memory — vpt_renderer_set_render_target — is consumed by work the caller enqueues on the
-        // context's stream right behind it: such passes stay on that stream.  The gather pipeline waits for every range itself.)
+        // context's stream right behind it: such passes stay on that stream unless the caller has taken the join upon itself
+        // (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join).  The gather pipeline waits for every range itself.)
         dim3 g = tile_grid(r);
         const unsigned k = (unsigned)r->split;
         if (r->main_dirty) {      // whatever the context's stream did to the renderer's buffers since the last join comes first
@@ -1105,9 +1107,14 @@ extern "C" int vpt_renderer_render_buffer_device(vpt_renderer *r, void **ptr, si
     *ptr = r->render_target ? r->render_target : r->render; *nbytes = (size_t)r->W * r->local_h * 8;
     return VPT_OK;
 }
+extern "C" int vpt_renderer_join(vpt_renderer *r) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    return join_side(r);
+}
 extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t nbytes) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
-    VPT_TRY(join_side(r));
+    if (!r->split_callers) VPT_TRY(join_side(r));            // (launches in flight carry their target in their arguments)
     size_t need = (size_t)r->W * r->local_h * 8;
     if (ptr && nbytes < need) return fail(VPT_ERR_INVALID, "render target too small: %zu < %zu", nbytes, need);
     r->render_target = (uint2 *)ptr; r->target_is_callers = ptr != nullptr;
@@ -1247,6 +1254,9 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
                 HIP_TRY(hipEventCreateWithFlags(&r->ev_join[i], hipEventDisableTiming));
             }
             r->split = value; return VPT_OK;
+        case VPT_OPTION_SPLIT_CALLER_TARGETS:
+            VPT_TRY(join_side(r));
+            r->split_callers = value != 0; return VPT_OK;
         case VPT_OPTION_FAST_MATH:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_FAST_MATH: only the MCM renderer has a fast-arithmetic variant");
             r->fast_math = value != 0; return VPT_OK;

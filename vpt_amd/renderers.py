@@ -279,6 +279,10 @@ class AbstractRenderer(PropertyBag):
         """redirect _renderFrame output into caller-owned device memory (None restores the own buffer)"""
         N.check(N.lib().vpt_renderer_set_render_target(self._h, C.c_void_p(device_ptr) if device_ptr else None, nbytes))
 
+    def join(self):
+        """join the side streams of split passes into the context's stream (vpt_renderer_join)"""
+        N.check(N.lib().vpt_renderer_join(self._h))
+
     def probe_sample(self, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         out = np.empty((xyz.shape[0], 4), dtype=np.float32)

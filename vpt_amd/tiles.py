@@ -37,9 +37,18 @@ def gather_index(height, world, rows_per_block=ROWS_PER_BLOCK):
 class FrameGather:
     """all_gather of the per-rank RGBA16F render buffers and reassembly into the [H][W][4] frame.
 
-    ``dist`` is torch.distributed (backend nccl == RCCL on GPUs, gloo in the CPU tests)."""
+    ``dist`` is torch.distributed (backend nccl == RCCL on GPUs, gloo in the CPU tests).
 
-    def __init__(self, dist, torch, width, height, device, rows_per_block=ROWS_PER_BLOCK, nbuf=2, always_collective=False):
+    ``frames_per_gather`` = F > 1 buckets the exchange: a rank renders F consecutive frames into the F slots of a send buffer
+    and ONE all_gather moves them all (every frame is still delivered to every rank, F - 1 frames later at most).  An
+    asynchronous torch.distributed collective costs the host ~25 us whatever its size (tools/torch_pipeline_probe.py), more than
+    a 1/8 shard's kernel takes: per-frame collectives leave the GPUs idle half of the time from N = 4 on.
+
+    Streaming interface (what bench.py drives):  t = acquire() -> render into t -> commit();  flush() sends a partial bucket;
+    last_frame() / last_sent() give the most recent frame assembled / as this rank rendered it.  The per-buffer calls
+    wait(b) / gather(b) / frame(b) with send[b] / recv[b] remain for F = 1."""
+
+    def __init__(self, dist, torch, width, height, device, rows_per_block=ROWS_PER_BLOCK, nbuf=2, always_collective=False, frames_per_gather=1):
         self.dist, self.torch = dist, torch
         self.always_collective = always_collective and dist.is_initialized()   # exercise RCCL even with one rank
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -47,14 +56,24 @@ class FrameGather:
         self.W, self.H = width, height
         self.rows = local_rows(height, self.world, rows_per_block)
         self.rows_per_block = rows_per_block
-        self.send = [torch.zeros((self.rows, width, 4), dtype=torch.float16, device=device) for _ in range(nbuf)]
-        self.recv = [torch.zeros((self.world * self.rows, width, 4), dtype=torch.float16, device=device) for _ in range(nbuf)]
+        self.F = max(1, int(frames_per_gather))
+        self.nbuf = nbuf
+        self._send = [torch.zeros((self.F, self.rows, width, 4), dtype=torch.float16, device=device) for _ in range(nbuf)]
+        self._recv = [torch.zeros((self.world, self.F, self.rows, width, 4), dtype=torch.float16, device=device) for _ in range(nbuf)]
+        # F = 1 views with the shapes of the per-buffer interface: [rows][W][4] and [world * rows][W][4]
+        self.send = [t[0] for t in self._send]
+        self.recv = [t.view(self.world * self.F * self.rows, width, 4) for t in self._recv]
         self.index = torch.as_tensor(gather_index(height, self.world, rows_per_block), device=device)
         self.work = [None] * nbuf
+        self._next = 0                 # index of the next frame to acquire
+        self._pending = 0              # committed frames of the current bucket that no collective has taken yet
+        self._aliased = [False] * nbuf
+        self._last_slot = None
 
     def shard(self):
         return (self.rank, self.world, self.rows_per_block)
 
+    # ---- per-buffer interface --------------------------------------------------------------------
     def wait(self, k):
         """make the current stream wait for the gather that last used buffer k (before it is overwritten)"""
         if self.work[k] is not None:
@@ -62,18 +81,73 @@ class FrameGather:
             self.work[k] = None
 
     def gather(self, k):
-        """enqueue the all_gather of send[k] into recv[k]; overlaps with whatever is launched next"""
+        """enqueue the all_gather of buffer k (all its F slots); overlaps with whatever is launched next"""
         if self.world == 1 and not self.always_collective:
-            self.recv[k] = self.send[k]
+            self._aliased[k] = True                         # one rank: the frame is the send buffer itself
             return
-        self.work[k] = self.dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), async_op=True)
+        self.work[k] = self.dist.all_gather_into_tensor(self._recv[k].view(-1), self._send[k].view(-1), async_op=True)
 
-    def frame(self, k):
-        """the assembled [H][W][4] frame of buffer k (waits for its gather)"""
+    def _assembled(self, k, j):
         self.wait(k)
         if self.world == 1:
-            return self.recv[k][:self.H]
-        return self.recv[k].index_select(0, self.index)
+            return (self._send[k][j] if self._aliased[k] else self._recv[k][0, j])[:self.H]
+        return self._recv[k][:, j].reshape(self.world * self.rows, self.W, 4).index_select(0, self.index)
+
+    def frame(self, k):
+        """the assembled [H][W][4] frame of buffer k, slot 0 (waits for its gather)"""
+        return self._assembled(k, 0)
+
+    # ---- streaming interface ---------------------------------------------------------------------
+    def acquire(self):
+        """the [rows][W][4] tensor the next frame is rendered into (waits for the gather that last read its buffer when a new
+        bucket starts)"""
+        b, j = (self._next // self.F) % self.nbuf, self._next % self.F
+        if j == 0:
+            self.wait(b)
+        return self._send[b][j]
+
+    def bucket_closes(self):
+        """True when commit() of the frame acquired last will send the bucket"""
+        return self._next % self.F == self.F - 1
+
+    def commit(self):
+        """the frame acquired last has been enqueued: a full bucket is sent"""
+        b, j = (self._next // self.F) % self.nbuf, self._next % self.F
+        self._next += 1
+        self._pending += 1
+        self._last_slot = (b, j)
+        if j == self.F - 1:
+            self.gather(b)
+            self._pending = 0
+
+    def flush(self):
+        """send a partial bucket (its unused slots travel as they are); the next frame starts a new bucket"""
+        if self._pending:
+            b = ((self._next - 1) // self.F) % self.nbuf
+            self.gather(b)
+            self._pending = 0
+            self._next = ((self._next + self.F - 1) // self.F) * self.F
+
+    def wait_all(self):
+        for k in range(self.nbuf):
+            self.wait(k)
+
+    def _last(self):
+        if self._last_slot is None:
+            raise RuntimeError("no frame has been committed")
+        if self._pending:                                   # still in an open bucket
+            self.flush()
+        return self._last_slot
+
+    def last_frame(self):
+        """the most recently committed frame, assembled (flushes its bucket if it is still open, waits for the gather)"""
+        b, j = self._last()
+        return self._assembled(b, j)
+
+    def last_sent(self):
+        """the most recently committed frame as this rank rendered it ([rows][W][4])"""
+        b, j = self._last()
+        return self._send[b][j]
 
 
 class RcclFrameGather:
