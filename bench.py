@@ -188,11 +188,14 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
         t, ns = run('eam', g256)
         b = 8.0 + 12.0 / 64.0
         out["C2_eam_256_1080p"] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "bytes_per_sample": b, "frac": b * ns / t / (HBM_PEAK_GBS * 1e9)}
+        t, ns = run('eam', g256, split=3)              # the same passes as three tile-row ranges on three HIP streams
+        out["C2_eam_256_1080p_three_streams"] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "bytes_per_sample": b, "frac": b * ns / t / (HBM_PEAK_GBS * 1e9)}
         g256.destroy()
-        t, ns = run('mcs', gvol512)
-        b = 8.0 + 48.0 / max(ns / (W * H), 1e-9)
-        out["C3_mcs_512_1080p"] = {"ms_per_frame": t * 1e3, "ms_per_256_spp": t * 256e3, "samples_per_s": ns / t, "samples_per_pixel_per_frame": ns / (W * H),
-                                   "bytes_per_sample": b, "frac": b * ns / t / (HBM_PEAK_GBS * 1e9)}
+        for name, sp in (("C3_mcs_512_1080p", 1), ("C3_mcs_512_1080p_three_streams", 3)):
+            t, ns = run('mcs', gvol512, split=sp)
+            b = 8.0 + 48.0 / max(ns / (W * H), 1e-9)
+            out[name] = {"ms_per_frame": t * 1e3, "ms_per_256_spp": t * 256e3, "samples_per_s": ns / t, "samples_per_pixel_per_frame": ns / (W * H),
+                         "bytes_per_sample": b, "frac": b * ns / t / (HBM_PEAK_GBS * 1e9)}
         n = 1024
         v = np.empty((n, n, n), dtype=np.uint8)
 
@@ -326,7 +329,7 @@ def main():
         if args.mcm_persistent >= 0:
             r.set_option(N.OPTION_MCM_PERSISTENT, args.mcm_persistent)
         if args.renderer != "mcm":
-            args.fast_math, args.split_streams = 0, 1       # MCM options
+            args.fast_math = 0                              # an MCM option
         if args.fast_math:
             r.set_option(N.OPTION_FAST_MATH, 1)
         # N > 1: the native pipeline keeps the ranges' streams apart across frames (its communication stream waits for every range);
@@ -336,12 +339,12 @@ def main():
         # lose below.
         if use_dist and args.split_streams >= 2 and int(r.local_rows()) * W < 500 * 1920:
             args.split_streams = 1
-        if args.split_streams >= 2 and args.renderer == "mcm":
+        if args.split_streams >= 2:
             r.set_option(N.OPTION_SPLIT_STREAMS, args.split_streams)
         # The torch.distributed pipeline hands whole buckets of frames to a collective and could join the ranges once per bucket
         # itself (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join): measured on a one-rank RCCL group it gains nothing there
         # (1920x1080: 122.6 us one stream, 124.9 us three; x544: 66.4 / 66.2 - tools/r02_exp29.sh), so those passes stay on one stream.
-        split_callers = bool(args.split_caller_targets and use_dist and args.split_streams >= 2 and args.renderer == "mcm")
+        split_callers = bool(args.split_caller_targets and use_dist and args.split_streams >= 2)
         if split_callers:
             r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
         if not args.boundary_atlas and args.renderer == "mcm":
@@ -382,7 +385,7 @@ def main():
             per_launch_samples = res["samples_local"] / max(args.steps, 1)
             avg_ms = res["kernel_ms"] / res["launches"] if res["launches"] else res["dt"] / args.steps * 1e3
             event_ms = avg_ms
-            split = args.split_streams >= 2 and args.renderer == "mcm" and (not use_dist or res["native"] or split_callers)
+            split = args.split_streams >= 2 and (not use_dist or res["native"] or split_callers)
             if split:
                 # a step is K launches (K tile-row ranges on K streams) that overlap each other and the next step's: a
                 # per-launch duration no longer says what the chip does.  The chip-level rate is bytes of a step / time of a step.
@@ -427,7 +430,7 @@ def main():
                            "arithmetic": ("fast-math variant (VPT_OPTION_FAST_MATH: hardware rcp/rsq/sqrt/log/sin/cos; tolerance-checked against the "
                                           "contract oracle, tests/test_gpu_fast_math.py)" if args.fast_math else
                                           "bit-exact contract (every buffer identical to oracle/vpt_oracle.c)"),
-                           "boundary_atlas": bool(args.boundary_atlas), "split_streams": args.split_streams if (args.renderer == "mcm" and (not use_dist or res["native"] or split_callers)) else 1,
+                           "boundary_atlas": bool(args.boundary_atlas), "split_streams": args.split_streams if (not use_dist or res["native"] or split_callers) else 1,
                            "repeats": args.repeats, "block_ms_min": min(res["blocks_ms"]), "block_ms_max": max(res["blocks_ms"]),
                            "block_ms_median": res["dt"] * 1e3, "timed_block": "median of `repeats` blocks of `steps` steps"},
                 # `frac` prices the kernel against the HBM roofline by ALGORITHMIC bytes, as the metric is defined; what actually

@@ -187,13 +187,14 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * value bit for bit (a clamped cell has weight 0 along the clamped axis), one aligned 4-byte gather instead of two unaligned
  * 8-byte ones.  0 = always the bricks. */
 #define VPT_OPTION_BOUNDARY_ATLAS 3
-/* VPT_OPTION_SPLIT_STREAMS (default 1; MCM renderer): K in 2 .. VPT_MAX_SPLIT = a pass is launched as K tile-row ranges, all but
+/* VPT_OPTION_SPLIT_STREAMS (default 1; every renderer but DOS): K in 2 .. VPT_MAX_SPLIT = a pass is launched as K tile-row ranges, all but
  * the first on private side streams.  A pixel's pass depends on its own previous pass only, so consecutive passes of the
  * ranges never wait for each other and the launch gap, ramp and tail of one range overlap the body of the others (HIP
  * streams in place of one longer launch).  Every other entry point (reads, reset, tone mapper, gather, synchronize ...) first
  * joins the side streams into the context's stream, so callers see the usual in-order semantics; while the render buffer is
  * redirected into caller memory (vpt_renderer_set_render_target, vpt_gather_*) passes stay on the context's stream, because the
- * caller's own work on that stream reads the frame.  Results identical. */
+ * caller's own work on that stream reads the frame; a frame sequence captured into a hipGraph (VPT_PLAY_GRAPH) stays on the capturing
+ * stream.  Results identical. */
 #define VPT_MAX_SPLIT 4
 #define VPT_OPTION_SPLIT_STREAMS 4
 /* VPT_OPTION_SPLIT_CALLER_TARGETS (default 0; MCM renderer): 1 = passes into a caller-owned render target are split as well.  The

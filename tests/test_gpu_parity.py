@@ -420,6 +420,46 @@ def test_mcm_split_streams_give_identical_buffers(gpu_ctx, oracle, fast):
     sc.gvol.destroy()
 
 
+@pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "iso", "depth", "lao"])
+def test_split_streams_other_renderers(gpu_ctx, oracle, kind):
+    """VPT_OPTION_SPLIT_STREAMS on the other sampling renderers (their passes are per-pixel too): fused render(), the three hooks
+    as separate launches, eager and graph frame sequences (a captured sequence stays on the capturing stream) — accumulator and
+    render buffer equal the one-stream run's; DOS refuses the option"""
+    sc = Scene(gpu_ctx, oracle, 32, 176, 150, tf=colour_tf(64, 1), camera=orbit_camera(176 / 150))
+
+    def run(split, fused):
+        r = sc.renderer(kind, fused=fused)
+        r.set_option(N.OPTION_SPLIT_STREAMS, split)
+        r.reset()
+        for _ in range(4):
+            r.render()
+        outs = [r.getTexture().copy()]
+        if fused:
+            r.play(3, use_graph=False)
+            r.play(3, use_graph=True); r.play(3, use_graph=True)
+            r.render()
+        outs += [r.read(N.BUFFER_ACCUM).copy(), r.getTexture().copy(), r.sample_count()]
+        r.destroy()
+        return outs
+
+    for fused in (True, False):
+        a, b = run(1, fused), run(3, fused)
+        for k, (x, y) in enumerate(zip(a, b)):
+            if isinstance(x, np.ndarray):
+                assert_same_bits(y, x, "%s fused=%s, 3 streams vs 1, output %d" % (kind, fused, k))
+            else:
+                assert x == y
+    sc.gvol.destroy()
+
+
+def test_split_streams_refused_for_dos(gpu_ctx, oracle):
+    sc = Scene(gpu_ctx, oracle, 16, 64, 48)
+    r = sc.renderer('dos')
+    with pytest.raises(vpt_amd.VptError):
+        r.set_option(N.OPTION_SPLIT_STREAMS, 3)
+    r.destroy(); sc.gvol.destroy()
+
+
 def test_mcm_split_streams_with_a_caller_owned_render_target():
     """A frame rendered into caller memory (vpt_renderer_set_render_target) is read by work the CALLER enqueues on the
     context's stream right behind render(): with VPT_OPTION_SPLIT_STREAMS on, such passes must not leave rows on a side

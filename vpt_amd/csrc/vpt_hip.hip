@@ -97,6 +97,7 @@ struct vpt_renderer {
     // pixel's pass depends on its own previous pass only, so the ranges never wait for each other: the launch gap, ramp and tail
     // of one overlap the body of the others.  Every other entry point joins the side streams into the context's stream first.
     bool target_is_callers;        // render_target was set by vpt_renderer_set_render_target (not by the gather pipeline)
+    bool no_split;                 // set while a frame sequence is being captured into a hipGraph (one stream only)
     bool split_callers;            // VPT_OPTION_SPLIT_CALLER_TARGETS: such passes are split too, the caller joins (vpt_renderer_join)
     int last_ranges;               // how many tile-row ranges (streams) the last sampling launch used
     hipEvent_t *stop_events;       // gather pipeline: event i is attached to range i's launch (hipExtLaunchKernel stop event: the
@@ -471,7 +472,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
     r->fast_math = 0; r->boundary_atlas = 1;
-    r->split = 1; r->target_is_callers = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -634,10 +635,11 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     size_t lds = lds_bytes(r);
     if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (wave_blocks(r)) {
-        dim3 g = tile_grid(r);
-        launch_range(kernel, r, dim3(g.x * 4u, g.y), dim3(64), lds, r->ctx->stream, a, 0);
-    } else if (r->split >= 2 && r->kind == VPT_RENDERER_MCM && r->tiles_y >= r->split && (!r->target_is_callers || r->split_callers)) {
+    // one-wave workgroups (the ray marchers when their LDS image is small): four times as many blocks along x, see map_pixel
+    const bool wave = wave_blocks(r);
+    const unsigned xmul = wave ? 4u : 1u;
+    const dim3 block(wave ? 64u : (unsigned)VPT_BLOCK);
+    if (r->split >= 2 && !r->no_split && r->tiles_y >= r->split && (!r->target_is_callers || r->split_callers)) {
         // (a frame rendered into caller memory — vpt_renderer_set_render_target — is consumed by work the caller enqueues on the
         // context's stream right behind it: such passes stay on that stream unless the caller has taken the join upon itself
         // (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join).  The gather pipeline waits for every range itself.)
@@ -652,11 +654,12 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
             const unsigned y0 = g.y * i / k, y1 = g.y * (i + 1u) / k;
             PassArgs part = a;
             part.pm.ty0 = (int)y0;
-            launch_range(kernel, r, dim3(g.x, y1 - y0), dim3(VPT_BLOCK), lds, i == 0 ? r->ctx->stream : r->side[i - 1], part, (int)i);
+            launch_range(kernel, r, dim3(g.x * xmul, y1 - y0), block, lds, i == 0 ? r->ctx->stream : r->side[i - 1], part, (int)i);
         }
         r->side_busy = true; r->last_ranges = (int)k;
     } else {
-        launch_range(kernel, r, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a, 0);
+        dim3 g = tile_grid(r);
+        launch_range(kernel, r, dim3(g.x * xmul, g.y), block, lds, r->ctx->stream, a, 0);
     }
     return VPT_OK;
 }
@@ -827,6 +830,9 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
 extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r || !u) return fail(VPT_ERR_INVALID, "null argument");
     if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_INVALID, "the DOS integrate step is a sequence of slices: call vpt_renderer_integrate_slices");
+    // the marchers' integrate reads the frame their (possibly split) generate launch wrote; MCM's integrate IS the split launch and
+    // depends on its own ranges' previous passes only
+    if (r->kind != VPT_RENDERER_MCM) VPT_TRY(join_side(r));
     HIP_TRY(hipSetDevice(r->ctx->device));
     PassArgs a;
     VPT_TRY(make_args(r, u, r->kind == VPT_RENDERER_MCM, &a));
@@ -1000,10 +1006,12 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
             g->count = count; g->with_gather = false; g->key = a;
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
             int rc = VPT_OK;
+            r->no_split = true;                       // a captured sequence lives on the capturing stream alone
             for (int i = 0; i < count && rc == VPT_OK; i++) {
                 rc = launch_fused(r, a);
                 hipLaunchKernelGGL(k_advance_frame, dim3(1), dim3(1), 0, c->stream, r->frame_counter);
             }
+            r->no_split = false;
             hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
             if (rc == VPT_OK && e != hipSuccess) rc = fail(VPT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
             if (rc == VPT_OK) { e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0); if (e != hipSuccess) rc = fail(VPT_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
@@ -1244,7 +1252,7 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
         case VPT_OPTION_MCM_PERSISTENT: r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
         case VPT_OPTION_BOUNDARY_ATLAS: r->boundary_atlas = value != 0; return VPT_OK;
         case VPT_OPTION_SPLIT_STREAMS:
-            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_SPLIT_STREAMS: MCM renderer only");
+            if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_SPLIT_STREAMS: the DOS renderer's slices depend on each other across pixels");
             if (value < 1 || value > VPT_MAX_SPLIT) return fail(VPT_ERR_INVALID, "VPT_OPTION_SPLIT_STREAMS: 1 .. %d", VPT_MAX_SPLIT);
             VPT_TRY(join_side(r));
             HIP_TRY(hipSetDevice(r->ctx->device));
@@ -1265,6 +1273,7 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
 }
 extern "C" int vpt_renderer_sample_count(vpt_renderer *r, uint64_t *count) {
     if (!r || !count) return fail(VPT_ERR_INVALID, "null argument");
+    VPT_TRY(join_side(r));                                   // the ranges of a split pass count into the same slots
     HIP_TRY(hipSetDevice(r->ctx->device));
     unsigned long long slots[VPT_COUNTER_SLOTS * VPT_COUNTER_STRIDE];
     HIP_TRY(hipMemcpyAsync(slots, r->samples, COUNTER_BYTES, hipMemcpyDeviceToHost, r->ctx->stream));
@@ -1704,6 +1713,7 @@ extern "C" int vpt_gather_unique_id(void *id128) {
 extern "C" int vpt_gather_destroy(vpt_gather *g) {
     if (!g) return VPT_OK;
     hipSetDevice(g->r->ctx->device);
+    join_side(g->r);                                         // ranges of split passes still rendering into the ring
     hipStreamSynchronize(g->r->ctx->stream);
     if (g->comm_stream) hipStreamSynchronize(g->comm_stream);
     vpt_renderer_set_render_target(g->r, nullptr, 0);
@@ -1926,6 +1936,7 @@ extern "C" int vpt_gather_set_root(vpt_gather *g, int root) {
 extern "C" int vpt_gather_synchronize(vpt_gather *g) {
     if (!g) return fail(VPT_ERR_INVALID, "gather is null");
     HIP_TRY(hipSetDevice(g->r->ctx->device));
+    VPT_TRY(join_side(g->r));
     HIP_TRY(hipStreamSynchronize(g->r->ctx->stream));
     HIP_TRY(hipStreamSynchronize(g->comm_stream));
     return VPT_OK;
