@@ -241,6 +241,31 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
             r.destroy()
             out[name] = {"ms_per_pass": dt / (12 * 16) * 1e3, "samples_per_s": ns / dt, "passes_per_launch": 16,
                          "note": "not the judged step: one launch = 16 passes, one render-buffer write"}
+        # VPT_PLAY_FRAMES: 16 passes per launch with the state in registers, EVERY pass's frame written to the frame ring (what 16
+        # render() calls would have shown); a sequence mode for callers that display or record frames later than they ask for them
+        for name, fm in (("H_mcm_512_1080p_bit_exact_16_frames_per_launch_every_frame_written", 0),
+                         ("H_mcm_512_1080p_fast_math_16_frames_per_launch_every_frame_written", 1)):
+            r = vpt_amd.RendererFactory('mcm')(ctx, gvol512, default_camera(W / H), None,
+                                               {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+            r.set_option(N.OPTION_FAST_MATH, fm)
+            r.reset()
+            for _ in range(4):
+                r.play(16, frames=True)
+            ctx.synchronize()
+            blocks = []
+            for _ in range(3):
+                r.clear_sample_count()
+                t0 = time.perf_counter()
+                for _ in range(12):
+                    r.play(16, frames=True)
+                ctx.synchronize()
+                blocks.append((time.perf_counter() - t0, r.sample_count()))
+            dt, ns = sorted(blocks)[1]
+            r.destroy()
+            out[name] = {"ms_per_frame": dt / (12 * 16) * 1e3, "samples_per_s": ns / dt, "frames_per_launch": 16,
+                         "roofline": {"frac": B_ALG_MCM * ns / dt / (HBM_PEAK_GBS * 1e9)},
+                         "note": "not the judged step (one render() per launch): one launch = 16 frames, each written to its ring slot, "
+                                 "photon state read once and written once per launch"}
     except Exception as e:                              # reporting only: the headline line must still be printed
         out["error"] = repr(e)
     return out

@@ -153,12 +153,20 @@ VPT_API int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u);
  * VPT_PLAY_GRAPH: the launch sequence is captured once into a hipGraph and replayed (uniforms from a device table read
  * through a device-side frame counter).  VPT_PLAY_FUSED (MIP, EAM, MCS, MCM, ISO, Depth): ONE launch runs all `count` passes
  * of a pixel back to back with the photon state (MCM) or the accumulator (MIP, EAM, MCS, ISO, Depth) in registers — no
- * round trip through HBM between passes.  In every mode the buffers afterwards are identical to `count` calls of
- * vpt_renderer_render. */
+ * round trip through HBM between passes.  VPT_PLAY_FRAMES (MCM): VPT_PLAY_FUSED that still WRITES EVERY FRAME — pass f of the call
+ * goes to slot f of the renderer's frame ring ([VPT_FRAME_SLOTS][local rows][width] RGBA16F, allocated on first use; count <=
+ * VPT_FRAME_SLOTS): the images `count` render() calls would have shown one after the other, for a caller that displays or
+ * records them later than it asks for them.  In every mode the buffers afterwards are identical to `count` calls of
+ * vpt_renderer_render (the render buffer holds the last frame). */
 #define VPT_PLAY_EAGER 0
 #define VPT_PLAY_GRAPH 1
 #define VPT_PLAY_FUSED 2
+#define VPT_PLAY_FRAMES 3
+#define VPT_FRAME_SLOTS 16
 VPT_API int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int mode);
+/* frame `slot` of the last VPT_PLAY_FRAMES call ([local rows][width][4] RGBA16F), and the ring's device address */
+VPT_API int vpt_renderer_read_frame_slot(vpt_renderer *r, int slot, void *host_dst, size_t nbytes);
+VPT_API int vpt_renderer_frame_ring_device(vpt_renderer *r, void **device_ptr, size_t *slot_bytes);
 
 /* read-back (the reference never reads back; it hands getTexture() to the tone mapper). Row-major, local rows. */
 VPT_API int vpt_renderer_read(vpt_renderer *r, int buffer, void *host_dst, size_t nbytes);

@@ -452,6 +452,44 @@ def test_split_streams_other_renderers(gpu_ctx, oracle, kind):
     sc.gvol.destroy()
 
 
+@pytest.mark.parametrize("fast", [0, 1])
+def test_mcm_play_frames_writes_every_frame(gpu_ctx, oracle, fast):
+    """VPT_PLAY_FRAMES: one launch runs `count` passes with the photon state in registers AND writes every pass's frame into the
+    frame ring — slot f equals the render buffer after the f-th of `count` render() calls, state and sample count equal too;
+    mixed with plain render() calls, a sharded renderer, more frames than slots refused, other renderers refused"""
+    sc = Scene(gpu_ctx, oracle, 32, 176, 150, tf=colour_tf(64, 1), camera=orbit_camera(176 / 150))
+    for shard in (None, (1, 3, 8)):
+        opts = {'shard': shard} if shard else {}
+        a, b = sc.renderer('mcm', **opts), sc.renderer('mcm', **opts)
+        for r in (a, b):
+            r.set_option(N.OPTION_FAST_MATH, fast)
+            r.extinction = 6
+            r.reset()
+        a.render(); b.render()
+        for count in (5, 1, N.FRAME_SLOTS):
+            want = []
+            for _ in range(count):
+                a.render(); want.append(a.getTexture().copy())
+            b.play(count, frames=True)
+            for f in range(count):
+                assert_same_bits(b.read_frame_slot(f), want[f], "frame %d of %d (shard %r)" % (f, count, shard))
+            assert_same_bits(b.getTexture(), want[-1], "render buffer after the sequence")
+            with pytest.raises(vpt_amd.VptError):
+                b.read_frame_slot(count)
+        a.render(); b.render()
+        for buf in MCM_BUFFERS:
+            assert_same_bits(b.read(buf), a.read(buf), "state after frame sequences")
+        assert a.sample_count() == b.sample_count()
+        with pytest.raises(vpt_amd.VptError):
+            b.play(N.FRAME_SLOTS + 1, frames=True)
+        a.destroy(); b.destroy()
+    m = sc.renderer('mip'); m.reset(); m.render()
+    with pytest.raises(vpt_amd.VptError):
+        m.play(2, frames=True)
+    m.destroy()
+    sc.gvol.destroy()
+
+
 def test_split_streams_refused_for_dos(gpu_ctx, oracle):
     sc = Scene(gpu_ctx, oracle, 16, 64, 48)
     r = sc.renderer('dos')

@@ -13,7 +13,8 @@ OPTION_FAST_MATH = 2
 OPTION_BOUNDARY_ATLAS = 3
 OPTION_SPLIT_STREAMS = 4
 OPTION_SPLIT_CALLER_TARGETS = 5
-PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED = 0, 1, 2
+PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED, PLAY_FRAMES = 0, 1, 2, 3
+FRAME_SLOTS = 16
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO, RENDERER_DOS = 0, 1, 2, 3, 4, 5, 6, 7
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 FORMAT_R8, FORMAT_RG8, FORMAT_R32F = 0, 1, 2
@@ -39,7 +40,7 @@ SYMBOLS = [
     "vpt_renderer_set_environment", "vpt_renderer_resize",
     "vpt_renderer_reset", "vpt_renderer_generate", "vpt_renderer_integrate", "vpt_renderer_render_frame",
     "vpt_renderer_render", "vpt_renderer_play", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
-    "vpt_renderer_set_render_target", "vpt_renderer_join",
+    "vpt_renderer_set_render_target", "vpt_renderer_join", "vpt_renderer_read_frame_slot", "vpt_renderer_frame_ring_device",
     "vpt_renderer_set_option", "vpt_renderer_set_lao_params", "vpt_renderer_set_occlusion_samples", "vpt_renderer_integrate_slices", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile",
     "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play", "vpt_gather_set_root",
@@ -146,7 +147,7 @@ def lib():
         "vpt_renderer_read": [P, I, P, SZ], "vpt_renderer_play": [P, UP, P, I, I],
         "vpt_gather_play": [P, UP, P, I, I], "vpt_gather_set_root": [P, I],
         "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
-        "vpt_renderer_set_render_target": [P, P, SZ], "vpt_renderer_join": [P],
+        "vpt_renderer_set_render_target": [P, P, SZ], "vpt_renderer_join": [P], "vpt_renderer_read_frame_slot": [P, I, P, SZ], "vpt_renderer_frame_ring_device": [P, PP, C.POINTER(SZ)],
         "vpt_renderer_set_option": [P, I, I],
         "vpt_renderer_set_lao_params": [P, C.POINTER(LaoParams)],
         "vpt_renderer_set_occlusion_samples": [P, P, I], "vpt_renderer_integrate_slices": [P, UP, P, I],

@@ -82,6 +82,7 @@ struct vpt_renderer {
     float4 *st[4];
     uint2 *render;
     uint2 *render_target;          // caller-owned redirect of the render buffer (or null)
+    uint2 *frame_ring; int ring_frames;   // VPT_PLAY_FRAMES: VPT_FRAME_SLOTS frames of W x local_h RGBA16F (allocated on first use); frames of the last call
     float *ndc_x, *ndc_y;          // pixel-centre NDC tables (W and H entries)
     FrameVar *frame_table; FrameVar *frame_staging; uint32_t *frame_counter;   // device ring of per-frame uniforms + pinned staging
     uint64_t frames_played;        // host copy of the monotonic device frame counter
@@ -373,6 +374,7 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     vpt_context *c = r->ctx;
     if (r->play_graph) { hipStreamSynchronize(c->stream); play_graph_free(r->play_graph); r->play_graph = nullptr; }
     r->render_target = nullptr; r->target_is_callers = false;   // an external target was sized for the old geometry
+    if (r->frame_ring) { hipFree(r->frame_ring); r->frame_ring = nullptr; } r->ring_frames = 0;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     renderer_free_buffers(r);
@@ -472,7 +474,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
     r->fast_math = 0; r->boundary_atlas = 1;
-    r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->frame_ring = nullptr; r->ring_frames = 0; r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -504,6 +506,7 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (r->samples) hipFree(r->samples);
     if (r->dos_samples) hipFree(r->dos_samples);
     if (r->work_counter) hipFree(r->work_counter);
+    if (r->frame_ring) hipFree(r->frame_ring);
     if (r->frame_table) hipFree(r->frame_table);
     if (r->frame_staging) hipHostFree(r->frame_staging);
     if (r->frame_counter) hipFree(r->frame_counter);
@@ -969,20 +972,28 @@ static int launch_multi(K kernel, vpt_renderer *r, const PassArgs &a, uint32_t n
     hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a, npasses);
     return VPT_OK;
 }
-static int launch_mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses) {
+template <typename K>
+static int launch_frames(K kernel, vpt_renderer *r, const PassArgs &a, uint32_t npasses, uint2 *ring) {
+    size_t lds = lds_bytes(r);
+    if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a, npasses, ring, (uint32_t)((size_t)r->W * r->local_h));
+    return VPT_OK;
+}
+static int launch_mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses, uint2 *ring = nullptr) {
 #define MULTI_CASES(F) switch (variant_of(r)) { \
-        case 0: return launch_multi(k_mcm_multi<0 | F>, r, a, npasses); \
-        case 1: return launch_multi(k_mcm_multi<1 | F>, r, a, npasses); \
-        case 2: return launch_multi(k_mcm_multi<2 | F>, r, a, npasses); \
-        case 3: return launch_multi(k_mcm_multi<3 | F>, r, a, npasses); \
-        case 8: return launch_multi(k_mcm_multi<8 | F>, r, a, npasses); \
-        case 9: return launch_multi(k_mcm_multi<9 | F>, r, a, npasses); \
-        case 10: return launch_multi(k_mcm_multi<10 | F>, r, a, npasses); \
-        case 11: return launch_multi(k_mcm_multi<11 | F>, r, a, npasses); \
-        case 32: return launch_multi(k_mcm_multi<32 | F>, r, a, npasses); \
-        case 33: return launch_multi(k_mcm_multi<33 | F>, r, a, npasses); \
-        case 34: return launch_multi(k_mcm_multi<34 | F>, r, a, npasses); \
-        default: return launch_multi(k_mcm_multi<35 | F>, r, a, npasses); }
+        case 0: return ring ? launch_frames(k_mcm_frames<0 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<0 | F>, r, a, npasses); \
+        case 1: return ring ? launch_frames(k_mcm_frames<1 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<1 | F>, r, a, npasses); \
+        case 2: return ring ? launch_frames(k_mcm_frames<2 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<2 | F>, r, a, npasses); \
+        case 3: return ring ? launch_frames(k_mcm_frames<3 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<3 | F>, r, a, npasses); \
+        case 8: return ring ? launch_frames(k_mcm_frames<8 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<8 | F>, r, a, npasses); \
+        case 9: return ring ? launch_frames(k_mcm_frames<9 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<9 | F>, r, a, npasses); \
+        case 10: return ring ? launch_frames(k_mcm_frames<10 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<10 | F>, r, a, npasses); \
+        case 11: return ring ? launch_frames(k_mcm_frames<11 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<11 | F>, r, a, npasses); \
+        case 32: return ring ? launch_frames(k_mcm_frames<32 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<32 | F>, r, a, npasses); \
+        case 33: return ring ? launch_frames(k_mcm_frames<33 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<33 | F>, r, a, npasses); \
+        case 34: return ring ? launch_frames(k_mcm_frames<34 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<34 | F>, r, a, npasses); \
+        default: return ring ? launch_frames(k_mcm_frames<35 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<35 | F>, r, a, npasses); }
     if (r->fast_math) MULTI_CASES(VPT_V_FAST)
     MULTI_CASES(0)
 #undef MULTI_CASES
@@ -1023,6 +1034,8 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
             HIP_TRY(hipGraphLaunch(g->exec, c->stream));
         }
         g->ran = true;
+    } else if (use_graph == VPT_PLAY_FRAMES && r->kind != VPT_RENDERER_MCM) {
+        return fail(VPT_ERR_UNSUPPORTED, "VPT_PLAY_FRAMES is implemented for the MCM renderer");
     } else if (use_graph == VPT_PLAY_FUSED && r->kind != VPT_RENDERER_MCM) {
         // the accumulating renderers: the pass loop lives in their fused kernels (PassArgs.multi_passes)
         if (r->kind == VPT_RENDERER_LAO) return fail(VPT_ERR_UNSUPPORTED, "fused passes are pointless for the LAO renderer: its frames do not accumulate");
@@ -1035,11 +1048,21 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
         hipLaunchKernelGGL(k_advance_frames, dim3(1), dim3(1), 0, c->stream, r->frame_counter, (uint32_t)count);
         HIP_TRY(hipGetLastError());
         r->warmed = true;
-    } else if (use_graph == VPT_PLAY_FUSED) {
+    } else if (use_graph == VPT_PLAY_FUSED || use_graph == VPT_PLAY_FRAMES) {
+        uint2 *ring = nullptr;
+        if (use_graph == VPT_PLAY_FRAMES) {
+            if (count > VPT_FRAME_SLOTS) return fail(VPT_ERR_INVALID, "VPT_PLAY_FRAMES: %d frames, the ring holds %d", count, VPT_FRAME_SLOTS);
+            if (!r->frame_ring) {
+                const size_t bytes = (size_t)VPT_FRAME_SLOTS * r->W * r->local_h * 8;
+                HIP_TRY(hipMalloc(&r->frame_ring, bytes));
+                HIP_TRY(hipMemsetAsync(r->frame_ring, 0, bytes, c->stream));   // a shard's padding rows are never written: zero, as in the render buffer
+            }
+            ring = r->frame_ring; r->ring_frames = count;
+        }
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
         {
             Timed t(r, true, (uint32_t)count);
-            VPT_TRY(launch_mcm_multi(r, a, (uint32_t)count));
+            VPT_TRY(launch_mcm_multi(r, a, (uint32_t)count, ring));
         }
         hipLaunchKernelGGL(k_advance_frames, dim3(1), dim3(1), 0, c->stream, r->frame_counter, (uint32_t)count);   // keeps the graph path's counter in step
         HIP_TRY(hipGetLastError());
@@ -1107,6 +1130,22 @@ extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(dst, r->scratch, npix * elem, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_read_frame_slot(vpt_renderer *r, int slot, void *dst, size_t nbytes) {
+    if (!r || !dst) return fail(VPT_ERR_INVALID, "null argument");
+    if (!r->frame_ring || slot < 0 || slot >= r->ring_frames) return fail(VPT_ERR_INVALID, "frame slot %d: the last VPT_PLAY_FRAMES call wrote %d frames", slot, r->ring_frames);
+    size_t need = (size_t)r->W * r->local_h * 8;
+    if (nbytes < need) return fail(VPT_ERR_INVALID, "buffer too small: %zu < %zu", nbytes, need);
+    VPT_TRY(join_side(r));
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, (const char *)r->frame_ring + (size_t)slot * need, need, hipMemcpyDeviceToHost, r->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_frame_ring_device(vpt_renderer *r, void **ptr, size_t *slot_bytes) {
+    if (!r || !ptr || !slot_bytes) return fail(VPT_ERR_INVALID, "null argument");
+    *ptr = r->frame_ring; *slot_bytes = (size_t)r->W * r->local_h * 8;
     return VPT_OK;
 }
 extern "C" int vpt_renderer_render_buffer_device(vpt_renderer *r, void **ptr, size_t *nbytes) {

@@ -963,8 +963,8 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
 // and the launch / staging cost is paid once.  Pass f re-seeds from the f-th entry of the frame table exactly as
 // launch f of the unfused sequence would; the render buffer receives the last pass's radiance, which is all that is
 // left of the unfused sequence's render buffer as well.
-template <int V>
-__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_multi(PassArgs a, uint32_t npasses) {
+template <int V, bool FRAMES>
+VPT_DEV void mcm_multi_body(PassArgs &a, uint32_t npasses, uint2 *ring, uint32_t slot_pixels) {
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
@@ -978,9 +978,21 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
         else mcm_events<V>(a, t, ph, px, py);
         // the unfused sequence stores the counters as floats between passes and re-reads them with uint(w + 0.5):
         // identical for every count below 2^24
+        // VPT_PLAY_FRAMES: every pass's frame is written (slot f of the frame ring), as `npasses` render() calls would show them
+        if (FRAMES) ring[(size_t)f * slot_pixels + (size_t)p.l * a.pm.W + p.i] = pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f);
     }
     photon_store(a, p.k, ph);
     a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f);
+}
+template <int V>
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_multi(PassArgs a, uint32_t npasses) {
+    mcm_multi_body<V, false>(a, npasses, nullptr, 0u);
+}
+// the same with every pass's frame written to the ring: one more live address per lane, compiled for 5 waves per SIMD (96 VGPRs;
+// 5, 6 and 7 waves run the MCM events at the same rate)
+template <int V>
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) k_mcm_frames(PassArgs a, uint32_t npasses, uint2 *ring, uint32_t slot_pixels) {
+    mcm_multi_body<V, true>(a, npasses, ring, slot_pixels);
 }
 __global__ void k_advance_frames(uint32_t *counter, uint32_t n) { *counter = *counter + n; }
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_render(PassArgs a) {   // MCMRenderer.glsl:204-206

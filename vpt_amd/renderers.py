@@ -264,13 +264,20 @@ class AbstractRenderer(PropertyBag):
             vars_[k, 4:7] = list(u.light_direction)
         return u, vars_
 
-    def play(self, count, use_graph=True, fused=False):
-        """`count` render() passes enqueued by one native call: eager launches, one hipGraph replay (use_graph), or — MCM —
-        one launch running all passes with the photon state in registers (fused); same buffers as count x render()"""
+    def play(self, count, use_graph=True, fused=False, frames=False):
+        """`count` render() passes enqueued by one native call: eager launches, one hipGraph replay (use_graph), one launch
+        running all passes with the photon state / accumulator in registers (fused), or — MCM — the same with EVERY pass's
+        frame written to the renderer's frame ring (frames; read_frame_slot); same buffers as count x render()"""
         self._bind_volume()
         u, vars_ = self._collect_frames(count)
-        mode = N.PLAY_FUSED if fused else (N.PLAY_GRAPH if use_graph else N.PLAY_EAGER)
+        mode = N.PLAY_FRAMES if frames else (N.PLAY_FUSED if fused else (N.PLAY_GRAPH if use_graph else N.PLAY_EAGER))
         N.check(N.lib().vpt_renderer_play(self._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), count, mode))
+
+    def read_frame_slot(self, slot):
+        """frame `slot` of the last play(frames=True) call: [local rows][W][4] float16"""
+        out = np.empty((self.local_rows(), self._size()[0], 4), dtype=np.float16)
+        N.check(N.lib().vpt_renderer_read_frame_slot(self._h, int(slot), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
 
     def set_option(self, option, value):
         N.check(N.lib().vpt_renderer_set_option(self._h, int(option), int(value)))
