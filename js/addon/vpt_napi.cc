@@ -225,6 +225,12 @@ static napi_value RendererRead(napi_env env, napi_callback_info info) {
     VPT_CHECK(vpt_renderer_read(r, which, dst, n));
     return undefined(env);
 }
+static napi_value RendererReadFrameSlot(napi_env env, napi_callback_info info) {      // vpt_renderer_read_frame_slot (VPT_PLAY_FRAMES)
+    napi_value a[3]; vpt_renderer *r; int32_t slot; void *dst; size_t n;
+    if (!get_args(env, info, 3, a) || !get_handle(env, a[0], &r) || !get_i32(env, a[1], &slot) || !get_bytes(env, a[2], &dst, &n)) return nullptr;
+    VPT_CHECK(vpt_renderer_read_frame_slot(r, slot, dst, n));
+    return undefined(env);
+}
 static napi_value RendererSampleCount(napi_env env, napi_callback_info info) {
     napi_value a[1]; vpt_renderer *r; uint64_t n = 0;
     if (!get_args(env, info, 1, a) || !get_handle(env, a[0], &r)) return nullptr;
@@ -430,7 +436,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("rendererSetVolume", RendererSetVolume); EXPORT("rendererSetTransferFunction", RendererSetTransferFunction);
     EXPORT("rendererSetEnvironment", RendererSetEnvironment); EXPORT("rendererResize", RendererResize);
     EXPORT("rendererReset", RendererReset); EXPORT("rendererGenerate", RendererGenerate); EXPORT("rendererIntegrate", RendererIntegrate);
-    EXPORT("rendererRenderFrame", RendererRenderFrame); EXPORT("rendererRender", RendererRender); EXPORT("rendererRead", RendererRead);
+    EXPORT("rendererRenderFrame", RendererRenderFrame); EXPORT("rendererRender", RendererRender); EXPORT("rendererRead", RendererRead); EXPORT("rendererReadFrameSlot", RendererReadFrameSlot);
     EXPORT("rendererSampleCount", RendererSampleCount); EXPORT("rendererClearSampleCount", RendererClearSampleCount);
     EXPORT("rendererSetProfiling", RendererSetProfiling); EXPORT("rendererProfile", RendererProfile);
     EXPORT("rendererSetOption", RendererSetOption); EXPORT("rendererSetLaoParams", RendererSetLaoParams);

@@ -182,6 +182,22 @@ async function main() {
         a.destroy(); b.destroy();
     }
 
+    // ---- play(count, FRAMES) (MCM): slot f of the frame ring == the render buffer after the f-th of count render() calls
+    {
+        const mk = () => { const r = new vpt.MCMRenderer(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() }); r.extinction = 6; r.reset(); return r; };
+        const a = mk(), b = mk();
+        b.play(5, N.VPT_PLAY_FRAMES);
+        for (let f = 0; f < 5; f++) {
+            a.render();
+            assert.deepStrictEqual(b.readFrameSlot(f).data, a.getTexture().data, 'frame slot ' + f);
+        }
+        assert.deepStrictEqual(b.getTexture().data, a.getTexture().data, 'render buffer after a frame sequence');
+        assert.strictEqual(b.sampleCount(), a.sampleCount());
+        assert.throws(() => b.readFrameSlot(5));
+        assert.throws(() => b.play(N.VPT_FRAME_SLOTS + 1, N.VPT_PLAY_FRAMES));
+        a.destroy(); b.destroy();
+    }
+
     // ---- ISO and Depth through the Node host (uniform block offsets 112..124): hits, misses and shading present
     {
         const iso = new vpt.ISORenderer(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });

@@ -120,7 +120,7 @@ getTexture() {
 }
 
 // extension: `count` render() passes by one native call.  mode: native().VPT_PLAY_EAGER | _GRAPH | _FUSED (one launch,
-// state / accumulator in registers between passes; not LAO / DOS).  The per-frame draws are taken exactly as render() would.
+// state / accumulator in registers between passes; not LAO / DOS) | _FRAMES (MCM: _FUSED that writes every frame, readFrameSlot).  The per-frame draws are taken exactly as render() would.
 play(count, mode) {
     this._bindVolume();
     const vars = new Float32Array(8 * count);
@@ -134,6 +134,14 @@ play(count, mode) {
 }
 
 read(buffer, out) { native().rendererRead(this._h, buffer, out); return out; }
+// frame `slot` of the last play(count, VPT_PLAY_FRAMES) call (MCM): the image the slot-th of `count` render() calls would have shown
+readFrameSlot(slot) {
+    const size = this._size();
+    const rows = native().rendererLocalRows(this._h);
+    const out = new Uint16Array(rows * size[0] * 4);
+    native().rendererReadFrameSlot(this._h, slot, out);
+    return { data: out, width: size[0], height: rows, format: 'RGBA16F' };
+}
 sampleCount() { return native().rendererSampleCount(this._h); }
 
 _hooksOverridden() {
