@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames enqueued per host call (vpt_*_play); 0 = 1 (frame by frame)")
     ap.add_argument("--fused-passes", type=int, default=0,
-                    help="MCM, single GPU, with --frames-per-launch F: one launch runs F passes with the photon state in registers")
+                    help="MCM, single GPU, with --frames-per-launch F (<= 16 for 2): 1 = one launch runs F passes with the photon state in "
+                         "registers and shows the last (VPT_PLAY_FUSED); 2 = the same, every pass's frame written to the frame ring (VPT_PLAY_FRAMES)")
     ap.add_argument("--graph", type=int, default=1, help="replay frame sequences as a captured hipGraph (with --frames-per-launch > 1)")
     ap.add_argument("--watchdog", type=int, default=1500, help="abort if the whole run takes longer than this many seconds")
     ap.add_argument("--gather-root", default="auto",
@@ -450,7 +451,7 @@ def main():
                            "gather_calibration": res["gather_choice"],
                            "frames_per_gather": (gather.F if (use_dist and not res["native"]) else None),
                            "frames_per_launch": f, "hipgraph": bool(args.graph) and f > 1 and not res["native"] and not args.fused_passes,
-                           "fused_passes": bool(args.fused_passes) and f > 1,
+                           "fused_passes": bool(args.fused_passes) and f > 1, "every_frame_written": (args.fused_passes == 2 and f > 1) or not (bool(args.fused_passes) and f > 1),
                            "samples_per_step": res["samples"] / args.steps,
                            "arithmetic": ("fast-math variant (VPT_OPTION_FAST_MATH: hardware rcp/rsq/sqrt/log/sin/cos; tolerance-checked against the "
                                           "contract oracle, tests/test_gpu_fast_math.py)" if args.fast_math else
@@ -489,7 +490,8 @@ def main():
             if use_native[0]:
                 native.play(n, fused=bool(args.fused_passes))   # no graph mode: graphs holding RCCL collectives are slower here
             else:
-                r.play(n, use_graph=bool(args.graph) and n == fpl, fused=bool(args.fused_passes))   # one cached graph: only full-size chunks replay it
+                r.play(n, use_graph=bool(args.graph) and n == fpl, fused=bool(args.fused_passes) and args.fused_passes != 2,
+                       frames=args.fused_passes == 2)    # one cached graph: only full-size chunks replay it
 
         def step(k):
             if use_native[0]:
