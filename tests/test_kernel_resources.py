@@ -36,3 +36,8 @@ def test_mcm_kernels_use_no_scratch_and_fit_seven_waves():
         assert u.get("VGPRs Spill", 0) <= (16 if multi else 0), (name, u)
         assert u.get("VGPRs", 999) <= 72, (name, u)          # 7 waves per SIMD
         assert u.get("Occupancy", 0) >= 7, (name, u)
+    # the frame-sequence kernels (VPT_PLAY_FRAMES) are compiled for 5 waves per SIMD and must not spill there
+    frames = {k: v for k, v in usage.items() if k.startswith("_Z12k_mcm_framesILi0E") or k.startswith("_Z12k_mcm_framesILi16E")}
+    assert len(frames) == 2, sorted(frames)
+    for name, u in frames.items():
+        assert u.get("ScratchSize", 0) == 0 and u.get("VGPRs", 999) <= 96 and u.get("Occupancy", 0) >= 5, (name, u)
