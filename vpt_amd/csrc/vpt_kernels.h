@@ -183,7 +183,7 @@ VPT_DEV uint2 pack_half4(float x, float y, float z, float w) {
     return r;
 }
 // A frame's texels are written once and read by somebody else later (tone mapper, gather, read-back): stored non-temporally,
-// they do not take L2 lines from the photon state and the brick lines (measured: -1 % per MCM frame, same bits)
+// they do not take L2 lines from the photon state, the accumulators and the brick lines (measured: -1 % per MCM frame, -0.5 .. -1 % for the ray marchers, same bits)
 VPT_DEV void store_frame_texel(uint2 *dst, uint2 v) {
     __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x, (unsigned long long *)dst);
 }
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mip(PassArgs a) {
             }
             acc[p.k] = (uint8_t)m;
             float v = from_unorm8(m);
-            a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(v, v, v, 1.0f);
+            store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(v, v, v, 1.0f));
         }
     }
     count_samples(a.samples, ns);
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mip_render(PassArgs a) {
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
     float v = from_unorm8(((uint8_t *)a.acc)[p.k]);
-    a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(v, v, v, 1.0f);
+    store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(v, v, v, 1.0f));
 }
 __global__ void __launch_bounds__(VPT_BLOCK) k_mip_reset(PassArgs a) {   // MIPRenderer.glsl:168-170
     Pix p = map_pixel(a.pm);
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_eam(PassArgs a) {
                 m = eam_mix(m, eam_pixel<V>(a, t, p, ns), a.mix);
             }
             acc[p.k] = m;
-            a.render[(size_t)p.l * a.pm.W + p.i] = eam_to_half4(m);
+            store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], eam_to_half4(m));
         }
     }
     count_samples(a.samples, ns);
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_eam_integrate(PassArgs a) {
 __global__ void __launch_bounds__(VPT_BLOCK) k_eam_render(PassArgs a) {
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
-    a.render[(size_t)p.l * a.pm.W + p.i] = eam_to_half4(((uint32_t *)a.acc)[p.k]);
+    store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], eam_to_half4(((uint32_t *)a.acc)[p.k]));
 }
 __global__ void __launch_bounds__(VPT_BLOCK) k_eam_reset(PassArgs a) {   // EAMRenderer.glsl:177-179
     Pix p = map_pixel(a.pm);
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
                 m = mcs_mix(m, mcs_pixel<V>(a, t, p, ns), a.mix);
             }
             acc[p.k] = m;
-            a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(m.x, m.y, m.z, m.w);
+            store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(m.x, m.y, m.z, m.w));
         }
     }
     count_samples(a.samples, ns);
@@ -500,7 +500,7 @@ VPT_DEV void mcs_write(const PassArgs &a, const McsLane &s, float4 c) {
     } else {
         float4 m = mcs_mix(acc[s.k], c, a.mix);
         acc[s.k] = m;
-        a.render[(size_t)s.l * a.pm.W + s.i] = pack_half4(m.x, m.y, m.z, m.w);
+        store_frame_texel(&a.render[(size_t)s.l * a.pm.W + s.i], pack_half4(m.x, m.y, m.z, m.w));
     }
 }
 template <int MODE, int V>
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs_render(PassArgs a) {   // MCS
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
     float4 m = ((float4 *)a.acc)[p.k];
-    a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(m.x, m.y, m.z, m.w);
+    store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(m.x, m.y, m.z, m.w));
 }
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcs_reset(PassArgs a) {    // MCSRenderer.glsl:238-240
     Pix p = map_pixel(a.pm);
