@@ -91,6 +91,8 @@ def random_case(seed):
 
 # VPT_FUZZ_SEEDS=a:b widens the sweep (e.g. 40:400); the default 40 seeds keep the suite short
 _SEEDS = range(*[int(v) for v in os.environ.get("VPT_FUZZ_SEEDS", "0:40").split(":")])
+# VPT_FUZZ_SPLIT=K: every case with VPT_OPTION_SPLIT_STREAMS = K; 1: none; default (-1): every third seed with three streams
+_SPLIT = int(os.environ.get("VPT_FUZZ_SPLIT", "-1"))
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -108,6 +110,8 @@ def test_random_scene(gpu_ctx, oracle, kind, seed):
         world = int(rng.integers(2, 6))
         opts['shard'] = (int(rng.integers(0, world)), world, int(rng.choice([1, 3, 8, 16])))
     r = vpt_amd.RendererFactory(kind)(gpu_ctx, gvol, camera, env, opts)
+    if _SPLIT >= 2 or (_SPLIT < 0 and seed % 3 == 1):          # a third of the default cases run their passes on three streams
+        r.set_option(N.OPTION_SPLIT_STREAMS, max(_SPLIT, 3) if _SPLIT >= 2 else 3)
     rows = r.global_rows()
     valid = rows >= 0
 
