@@ -164,7 +164,8 @@ VPT_API int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u);
 #define VPT_PLAY_FRAMES 3
 #define VPT_FRAME_SLOTS 16
 VPT_API int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int mode);
-/* frame `slot` of the last VPT_PLAY_FRAMES call ([local rows][width][4] RGBA16F), and the ring's device address */
+/* frame `slot` of the last VPT_PLAY_FRAMES call ([local rows][width][4] RGBA16F), and the ring's device address (extensions: the
+ * reference renders one frame per animation tick, AbstractRenderer.js:60-70, and has no frame sequences) */
 VPT_API int vpt_renderer_read_frame_slot(vpt_renderer *r, int slot, void *host_dst, size_t nbytes);
 VPT_API int vpt_renderer_frame_ring_device(vpt_renderer *r, void **device_ptr, size_t *slot_bytes);
 
@@ -210,7 +211,7 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * of frames handed to a collective, not once per frame (vpt_amd/tiles.py FrameGather, bench.py --gather torch). */
 #define VPT_OPTION_SPLIT_CALLER_TARGETS 5
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
-/* Joins the side streams of a split pass (VPT_OPTION_SPLIT_STREAMS) into the context's stream: everything enqueued on that
+/* (extension, no reference counterpart) Joins the side streams of a split pass (VPT_OPTION_SPLIT_STREAMS) into the context's stream: everything enqueued on that
  * stream afterwards sees every range of the passes enqueued so far.  A no-op when nothing is pending.  Every other entry point
  * that touches the renderer's buffers does this by itself. */
 VPT_API int vpt_renderer_join(vpt_renderer *r);
