@@ -71,6 +71,8 @@ def parse():
                          "checked against the contract by tolerance, not bit for bit)")
     ap.add_argument("--boundary-atlas", type=int, default=1,
                     help="MCM: 0 = out-of-cube samples from the bricks as well (VPT_OPTION_BOUNDARY_ATLAS off; results identical)")
+    ap.add_argument("--tile-classes", type=int, default=1,
+                    help="MCM: 0 = every tile through the general kernel (VPT_OPTION_TILE_CLASSES off; results identical)")
     ap.add_argument("--split-streams", type=int, default=3,
                     help="MCM: K >= 2 = launch every pass as K tile-row ranges on K HIP streams (VPT_OPTION_SPLIT_STREAMS; results identical)")
     ap.add_argument("--split-caller-targets", type=int, default=0,
@@ -375,6 +377,8 @@ def main():
             r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
         if not args.boundary_atlas and args.renderer == "mcm":
             r.set_option(N.OPTION_BOUNDARY_ATLAS, 0)
+        if not args.tile_classes and args.renderer == "mcm":
+            r.set_option(N.OPTION_TILE_CLASSES, 0)
         if args.mcs_persistent >= 0:
             r.set_option(N.OPTION_MCS_PERSISTENT, args.mcs_persistent)
         assert r.local_rows() == gather.rows
@@ -456,7 +460,9 @@ def main():
                            "arithmetic": ("fast-math variant (VPT_OPTION_FAST_MATH: hardware rcp/rsq/sqrt/log/sin/cos; tolerance-checked against the "
                                           "contract oracle, tests/test_gpu_fast_math.py)" if args.fast_math else
                                           "bit-exact contract (every buffer identical to oracle/vpt_oracle.c)"),
-                           "boundary_atlas": bool(args.boundary_atlas), "split_streams": args.split_streams if (not use_dist or res["native"] or split_callers) else 1,
+                           "boundary_atlas": bool(args.boundary_atlas),
+                           "tile_classes": (dict(zip(("hit_tiles", "miss_tiles"), r.tile_classes()[:2])) if (args.renderer == "mcm" and args.tile_classes) else None),
+                           "split_streams": args.split_streams if (not use_dist or res["native"] or split_callers) else 1,
                            "repeats": args.repeats, "block_ms_min": min(res["blocks_ms"]), "block_ms_max": max(res["blocks_ms"]),
                            "block_ms_median": res["dt"] * 1e3, "timed_block": "median of `repeats` blocks of `steps` steps"},
                 # `frac` prices the kernel against the HBM roofline by ALGORITHMIC bytes, as the metric is defined; what actually

@@ -204,13 +204,30 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * redirected into caller memory (vpt_renderer_set_render_target, vpt_gather_*) passes stay on the context's stream, because the
  * caller's own work on that stream reads the frame; a frame sequence captured into a hipGraph (VPT_PLAY_GRAPH) stays on the capturing
  * stream.  Results identical. */
-#define VPT_MAX_SPLIT 4
+#define VPT_MAX_SPLIT 6
 #define VPT_OPTION_SPLIT_STREAMS 4
 /* VPT_OPTION_SPLIT_CALLER_TARGETS (default 0; MCM renderer): 1 = passes into a caller-owned render target are split as well.  The
  * caller then owes a vpt_renderer_join() before work of its own on the context's stream reads the target — e.g. once per bucket
  * of frames handed to a collective, not once per frame (vpt_amd/tiles.py FrameGather, bench.py --gather torch). */
 #define VPT_OPTION_SPLIT_CALLER_TARGETS 5
+/* VPT_OPTION_TILE_CLASSES (default 1; MCM renderer, LINEAR filter, one-channel volumes with the boundary atlas; extension, no
+ * reference counterpart): vpt_renderer_reset() sorts the 16x16 tiles into those none of whose camera rays (jitter included) can meet
+ * the unit cube ("MISS") and the rest; while the passes keep the reset's uMvpInverseMatrix and blur == 0, a MISS tile's photon is
+ * re-emitted and leaves again at every event (MCMRenderer.glsl:135-141 after resetPhoton :70-78), so its passes run a straight-line
+ * kernel on 32 of the 56 state bytes per pixel.  Every buffer a caller can read is identical either way.
+ * VPT_OPTION_VERIFY_TILE_CLASSES (default 0): the MISS-tile kernel also counts events that were inside the cube after all
+ * (vpt_renderer_tile_classes' `violations`: must stay 0). */
+#define VPT_OPTION_TILE_CLASSES 6
+#define VPT_OPTION_VERIFY_TILE_CLASSES 7
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
+/* (extension) tiles of each class under the last reset's matrix (all HIT when no classification is in force) and the
+ * VPT_OPTION_VERIFY_TILE_CLASSES counter; any pointer may be null */
+VPT_API int vpt_renderer_tile_classes(vpt_renderer *r, int *hit_tiles, int *miss_tiles, uint64_t *violations);
+/* (extension, host only: touches no GPU) the classification itself for an image of width x height whose rows are sharded
+ * (rank of world, rows_per_block): classes[ty * tiles_x + tx] = 1 where tile (tx, ty) of the rank's LOCAL rows is a MISS tile.
+ * `classes` may be null to query the tile grid. */
+VPT_API int vpt_classify_tiles(int width, int height, int rank, int world, int rows_per_block, const float *mvp_inverse,
+                               uint8_t *classes, size_t nclasses, int *tiles_x, int *tiles_y);
 /* (extension, no reference counterpart) Joins the side streams of a split pass (VPT_OPTION_SPLIT_STREAMS) into the context's stream: everything enqueued on that
  * stream afterwards sees every range of the passes enqueued so far.  A no-op when nothing is pending.  Every other entry point
  * that touches the renderer's buffers does this by itself. */

@@ -1,0 +1,279 @@
+"""GPU: tile classes (VPT_OPTION_TILE_CLASSES, vpt_kernels.h "Tile classes") — the MCM passes of tiles none of whose camera rays
+can meet the cube run k_mcm_miss on 32 of the 56 state bytes per pixel; HIT tiles run k_mcm_integrate from a tile list.
+
+Everything a caller can read must be identical, bit for bit, with the option on and off, and identical to the CPU oracle
+(contract arithmetic): all four photon-state buffers (position / transmittance of MISS tiles are materialised on demand), the
+render buffer, the sample count — through reads in the middle of a sequence, a matrix that changes without a reset, a blur,
+an option toggled between passes, shards, frame sequences in every mode.  VPT_OPTION_VERIFY_TILE_CLASSES counts events that
+contradict the classification: 0."""
+import numpy as np
+import pytest
+
+import vpt_amd
+from vpt_amd import _native as N
+from vpt_amd.synthetic import colour_tf, ramp_tf, GoldenRatioRng
+
+from conftest import orbit_camera
+from test_gpu_parity import Scene, to_frame, assert_same_bits, MCM_BUFFERS, env_map
+
+pytestmark = pytest.mark.gpu
+
+
+def far_scene(gpu_ctx, oracle, w=208, h=144, env=None, cam=(0.7, -0.3, 3.2), n=24, filt="linear"):
+    """a camera far enough that most 16x16 tiles miss the cube"""
+    return Scene(gpu_ctx, oracle, n, w, h, filt, tf=colour_tf(48, 1), env=env, camera=orbit_camera(w / h, *cam))
+
+
+def all_buffers(r):
+    return [r.read(b).copy() for b in MCM_BUFFERS] + [r.getTexture().copy()]
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("split", [1, 3])
+def test_classes_on_and_off_give_identical_buffers(gpu_ctx, oracle, fast, split):
+    sc = far_scene(gpu_ctx, oracle, env=env_map(16, 8))
+
+    def run(classes):
+        r = sc.renderer('mcm')
+        r.set_option(N.OPTION_TILE_CLASSES, classes)
+        r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
+        r.set_option(N.OPTION_FAST_MATH, fast)
+        r.set_option(N.OPTION_SPLIT_STREAMS, split)
+        r.extinction = 4; r.steps = 5; r.anisotropy = 0.3
+        r.reset()
+        hit, miss, _ = r.tile_classes()
+        if classes:
+            assert miss > hit > 0, (hit, miss)
+        outs = all_buffers(r)                               # the reset's buffers
+        for k in range(6):
+            r.render()
+            if k in (0, 3):
+                outs += all_buffers(r)                      # position / transmittance of MISS tiles materialised mid-sequence
+        r.render(); r.render()
+        outs += all_buffers(r)
+        assert r.sample_count() == sc.w * sc.h * 5 * 8
+        assert r.tile_classes()[2] == 0                     # no event of a MISS tile was inside the cube
+        r.destroy()
+        return outs
+
+    a, b = run(0), run(1)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert_same_bits(y, x, "tile classes on vs off, output %d" % k)
+    sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("env", [None, (16, 8)])
+@pytest.mark.parametrize("cam", [(0.7, -0.3, 3.2), (2.4, 0.5, 2.1)])
+def test_classes_against_the_oracle(gpu_ctx, oracle, env, cam):
+    sc = far_scene(gpu_ctx, oracle, env=env_map(*env) if env else None, cam=cam)
+    r = sc.renderer('mcm')
+    r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
+    r.extinction = 5; r.steps = 6
+    o = oracle.OracleRenderer('mcm', sc.osc, sc.w, sc.h)
+    r.reset()
+    o.reset(oracle.make_frame(sc.w, sc.h, sc.m, seed=np.float32(GoldenRatioRng()())))
+    assert r.tile_classes()[1] > 0
+    for k in range(5):
+        r.render()
+        o.render(to_frame(oracle, sc, r._u))
+        if k in (1, 4):
+            for b, s in zip(MCM_BUFFERS, o.state):
+                assert_same_bits(r.read(b), s.reshape(sc.h, sc.w, 4), "state buffer %d after pass %d" % (b, k))
+            assert_same_bits(r.getTexture().view(np.uint16), o.image_f16().view(np.uint16), "render buffer")
+    assert r.tile_classes()[2] == 0
+    r.destroy(); sc.gvol.destroy()
+
+
+class BlurredMCM(vpt_amd.MCMRenderer):
+    """uBlur is always 0 in the reference (MCMRenderer.js:93,157); the boundary takes any value"""
+    blur_value = 0.0
+
+    def _prepare_integrate(self):
+        u = super()._prepare_integrate()
+        u.blur = float(np.float32(self.blur_value))
+        return u
+
+
+BlurredMCM._BASE = BlurredMCM
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_matrix_or_blur_changing_without_a_reset_voids_the_classes(gpu_ctx, oracle, fast):
+    """passes with another matrix (the camera moved, nobody called reset()) or a blur: the MISS tiles' photons may enter the cube
+    now — the library must notice by itself, bring the lazily kept arrays up to date and go back to the general kernel"""
+    def run(classes):
+        sc = far_scene(gpu_ctx, oracle)
+        o = {'resolution': (sc.w, sc.h), 'transform': sc.transform, 'rng': GoldenRatioRng()}
+        r = BlurredMCM(gpu_ctx, sc.gvol, sc.camera, None, o)
+        r.setTransferFunction(sc.tf)
+        r.set_option(N.OPTION_TILE_CLASSES, classes)
+        r.set_option(N.OPTION_FAST_MATH, fast)
+        r.set_option(N.OPTION_SPLIT_STREAMS, 2)
+        r.extinction = 4; r.steps = 4
+        r.reset()
+        outs = []
+        for _ in range(3):
+            r.render()
+        # the camera swings round towards the volume: former MISS tiles now look at it
+        sc.camera.transform.localTranslation = [0.2, 0.1, 1.2]
+        sc.camera.transform.localRotation = [0, 0, 0, 1]
+        for _ in range(3):
+            r.render()
+        if classes:
+            assert r.tile_classes()[1] == 0             # void until the next reset
+        outs += all_buffers(r)
+        r.reset()
+        if classes:
+            assert r.tile_classes()[1] >= 0
+        r.render(); r.render()
+        r.blur_value = 0.4                              # a blurred pass: near-plane points move off the pixel's ray
+        r.render(); r.render()
+        r.blur_value = 0.0
+        r.render()
+        outs += all_buffers(r)
+        r.destroy(); sc.gvol.destroy()
+        return outs
+
+    a, b = run(0), run(1)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert_same_bits(y, x, "output %d" % k)
+
+
+def test_option_toggles_between_passes(gpu_ctx, oracle):
+    """fast-math, the atlas, the classes themselves and the filter switched between passes of one sequence: the MISS tiles'
+    positions are materialised in the arithmetic that produced their directions"""
+    sc = far_scene(gpu_ctx, oracle)
+
+    def run(classes):
+        r = sc.renderer('mcm')
+        r.set_option(N.OPTION_TILE_CLASSES, classes)
+        r.extinction = 4; r.steps = 3
+        r.reset()
+        seq = [(N.OPTION_FAST_MATH, 1), (N.OPTION_FAST_MATH, 0), (N.OPTION_BOUNDARY_ATLAS, 0), (N.OPTION_FAST_MATH, 1),
+               (N.OPTION_BOUNDARY_ATLAS, 1), (N.OPTION_SPLIT_STREAMS, 3), (N.OPTION_FAST_MATH, 0), (N.OPTION_SPLIT_STREAMS, 1)]
+        for opt, val in seq:
+            r.render(); r.render()
+            r.set_option(opt, val)
+        if classes:
+            r.set_option(N.OPTION_TILE_CLASSES, 0)
+            r.render()
+            r.set_option(N.OPTION_TILE_CLASSES, 1)
+        else:
+            r.render()
+        r.render()
+        outs = all_buffers(r)
+        r.destroy()
+        return outs
+
+    for k, (x, y) in enumerate(zip(run(0), run(1))):
+        assert_same_bits(y, x, "output %d" % k)
+    sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("world,rows", [(3, 5), (8, 8), (2, 16)])
+@pytest.mark.parametrize("fast", [0, 1])
+def test_sharded_classes_equal_the_unsharded_general_kernel(gpu_ctx, oracle, world, rows, fast):
+    sc = far_scene(gpu_ctx, oracle, w=200, h=230)
+    whole = sc.renderer('mcm')
+    whole.set_option(N.OPTION_TILE_CLASSES, 0)
+    whole.set_option(N.OPTION_FAST_MATH, fast)
+    whole.extinction = 4; whole.steps = 4
+    whole.reset()
+    for _ in range(4):
+        whole.render()
+    want = all_buffers(whole)
+    whole.destroy()
+    for rank in range(world):
+        r = sc.renderer('mcm', shard=(rank, world, rows))
+        r.set_option(N.OPTION_FAST_MATH, fast)
+        r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
+        r.extinction = 4; r.steps = 4
+        r.reset()
+        for _ in range(4):
+            r.render()
+        g = r.global_rows()
+        ok = g >= 0
+        for k, (x, y) in enumerate(zip(all_buffers(r), want)):
+            assert_same_bits(x[ok], y[g[ok]], "rank %d of %d, output %d" % (rank, world, k))
+        assert r.tile_classes()[2] == 0
+        r.destroy()
+    sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_frame_sequences_after_classified_passes(gpu_ctx, oracle, fast):
+    """vpt_renderer_play in every mode mixed with classified render() calls"""
+    sc = far_scene(gpu_ctx, oracle)
+
+    def run(classes):
+        r = sc.renderer('mcm')
+        r.set_option(N.OPTION_TILE_CLASSES, classes)
+        r.set_option(N.OPTION_FAST_MATH, fast)
+        r.set_option(N.OPTION_SPLIT_STREAMS, 2)
+        r.extinction = 4; r.steps = 4
+        r.reset()
+        r.render(); r.render()
+        r.play(3, use_graph=False)
+        r.render()
+        r.play(3, use_graph=True); r.play(3, use_graph=True)
+        r.render()
+        r.play(4, fused=True)
+        r.render()
+        r.play(5, frames=True)
+        slots = [r.read_frame_slot(k).copy() for k in range(5)]
+        r.render(); r.render()
+        outs = all_buffers(r) + slots
+        assert r.sample_count() == sc.w * sc.h * 4 * (2 + 3 + 1 + 6 + 1 + 4 + 1 + 5 + 2)
+        r.destroy()
+        return outs
+
+    for k, (x, y) in enumerate(zip(run(0), run(1))):
+        assert_same_bits(y, x, "output %d" % k)
+    sc.gvol.destroy()
+
+
+def test_classes_need_the_atlas_path(gpu_ctx, oracle):
+    """NEAREST filter, two-channel and float volumes, a switched-off atlas: k_mcm_miss has no sampler for them — such renderers keep
+    the general kernel (and stay bit-identical to the oracle: the parity suites run them)"""
+    sc = far_scene(gpu_ctx, oracle, filt="nearest")
+    r = sc.renderer('mcm')
+    r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
+    r.extinction = 4; r.steps = 4
+    o = oracle.OracleRenderer('mcm', sc.osc, sc.w, sc.h)
+    r.reset()
+    o.reset(oracle.make_frame(sc.w, sc.h, sc.m, seed=np.float32(GoldenRatioRng()())))
+    for _ in range(3):
+        r.render()
+        o.render(to_frame(oracle, sc, r._u))
+    for b, s in zip(MCM_BUFFERS, o.state):
+        assert_same_bits(r.read(b), s.reshape(sc.h, sc.w, 4), "state buffer %d" % b)
+    r.destroy(); sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_full_hd_frame_classes_on_and_off(gpu_ctx, oracle, fast):
+    """the benchmark's image size and camera (1920x1080, default camera: ~77 % MISS tiles) on a 128^3 volume, three streams"""
+    from vpt_amd.scene import default_camera
+    sc = Scene(gpu_ctx, oracle, 128, 1920, 1080, camera=default_camera(1920 / 1080), noise=48.0)
+
+    def run(classes):
+        r = sc.renderer('mcm')
+        r.set_option(N.OPTION_TILE_CLASSES, classes)
+        r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
+        r.set_option(N.OPTION_FAST_MATH, fast)
+        r.set_option(N.OPTION_SPLIT_STREAMS, 3)
+        r.reset()
+        if classes:
+            hit, miss, _ = r.tile_classes()
+            assert hit + miss == 120 * 68 and miss > 0.7 * (hit + miss)
+        for _ in range(12):
+            r.render()
+        outs = all_buffers(r)
+        assert r.sample_count() == 1920 * 1080 * 8 * 12
+        assert r.tile_classes()[2] == 0
+        r.destroy()
+        return outs
+
+    for k, (x, y) in enumerate(zip(run(0), run(1))):
+        assert_same_bits(y, x, "output %d" % k)
+    sc.gvol.destroy()

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""One build of the library, one configuration of the headline workload (MCM 512^3 @ 1920x1080, default camera), timed the way
+bench.py times it (blocks of N render() calls between synchronisations, median block) but without the oracle frame check —
+the A/B workhorse of tools/ab.sh.  The library is chosen through VPT_HIP_LIBRARY (vpt_amd/_native.py), the in-tree artefact is
+not touched.  Prints one line: tag, median / min us per frame."""
+import argparse
+import os
+import sys
+import time
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default="")
+ap.add_argument("--tag", default="")
+ap.add_argument("--fast", type=int, default=1)
+ap.add_argument("--split", type=int, default=3)
+ap.add_argument("--classes", type=int, default=1)
+ap.add_argument("--volume", type=int, default=512)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--frames", type=int, default=300)
+ap.add_argument("--blocks", type=int, default=5)
+ap.add_argument("--shard", default="", help="rank,world,rows: time one rank's share of the frame")
+ap.add_argument("--renderer", default="mcm")
+ap.add_argument("--steps", type=int, default=8)
+args = ap.parse_args()
+if args.lib:
+    os.environ["VPT_HIP_LIBRARY"] = os.path.abspath(args.lib)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import vpt_amd
+from vpt_amd import _native as N
+from vpt_amd.scene import default_camera, Transform, Node
+from vpt_amd.synthetic import sphere_volume, GoldenRatioRng
+
+cache = "/tmp/vpt_vol_%d.npy" % args.volume
+if os.path.exists(cache):
+    vol = np.load(cache)
+else:
+    vol = sphere_volume(args.volume, noise=48.0)
+    np.save(cache, vol)
+ctx = vpt_amd.Context(0)
+gvol = vpt_amd.Volume.from_array(ctx, vol, 'linear')
+W, H = args.width, args.height
+opts = {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()}
+if args.shard:
+    opts['shard'] = tuple(int(x) for x in args.shard.split(","))
+r = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, default_camera(W / H), None, opts)
+if args.renderer == "mcm":
+    r.set_option(N.OPTION_FAST_MATH, args.fast)
+    r.steps = args.steps
+    try:
+        r.set_option(N.OPTION_TILE_CLASSES, args.classes)
+    except vpt_amd.VptError:
+        pass                                          # a build from before the option existed
+if args.split > 1:
+    r.set_option(N.OPTION_SPLIT_STREAMS, args.split)
+r.reset()
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.3:
+    for _ in range(50):
+        r.render()
+    ctx.synchronize()
+blocks = []
+for _ in range(args.blocks):
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.frames):
+        r.render()
+    ctx.synchronize()
+    blocks.append((time.perf_counter() - t0) / args.frames * 1e6)
+blocks.sort()
+med = blocks[len(blocks) // 2]
+samples = W * H * args.steps if not args.shard else None
+print("%-28s fast %d split %d classes %d%s: median %7.2f us  min %7.2f  max %7.2f%s" % (
+    args.tag or os.path.basename(args.lib) or "in-tree", args.fast, args.split, args.classes, (" shard " + args.shard) if args.shard else "",
+    med, blocks[0], blocks[-1], ("  frac %.3f" % (24.0 * samples / (med * 1e-6) / 8e12)) if samples and args.renderer == "mcm" else ""), flush=True)
+r.destroy(); gvol.destroy(); ctx.destroy()

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvpt_hip.so")
+# VPT_HIP_LIBRARY selects another build of the same library (A/B measurements: tools/ab.sh) without touching the in-tree artefact
+LIB_PATH = os.environ.get("VPT_HIP_LIBRARY") or os.path.join(_HERE, "libvpt_hip.so")
 
 OK = 0
 OPTION_MCS_PERSISTENT = 0
@@ -13,6 +14,8 @@ OPTION_FAST_MATH = 2
 OPTION_BOUNDARY_ATLAS = 3
 OPTION_SPLIT_STREAMS = 4
 OPTION_SPLIT_CALLER_TARGETS = 5
+OPTION_TILE_CLASSES = 6
+OPTION_VERIFY_TILE_CLASSES = 7
 PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED, PLAY_FRAMES = 0, 1, 2, 3
 FRAME_SLOTS = 16
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO, RENDERER_DOS = 0, 1, 2, 3, 4, 5, 6, 7
@@ -42,7 +45,7 @@ SYMBOLS = [
     "vpt_renderer_render", "vpt_renderer_play", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
     "vpt_renderer_set_render_target", "vpt_renderer_join", "vpt_renderer_read_frame_slot", "vpt_renderer_frame_ring_device",
     "vpt_renderer_set_option", "vpt_renderer_set_lao_params", "vpt_renderer_set_occlusion_samples", "vpt_renderer_integrate_slices", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
-    "vpt_renderer_set_profiling", "vpt_renderer_profile",
+    "vpt_renderer_set_profiling", "vpt_renderer_profile", "vpt_renderer_tile_classes", "vpt_classify_tiles",
     "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play", "vpt_gather_set_root",
     "vpt_gather_synchronize",
     "vpt_gather_read_frame",
@@ -153,6 +156,8 @@ def lib():
         "vpt_renderer_set_occlusion_samples": [P, P, I], "vpt_renderer_integrate_slices": [P, UP, P, I],
         "vpt_renderer_sample_count": [P, C.POINTER(C.c_uint64)], "vpt_renderer_clear_sample_count": [P],
         "vpt_renderer_set_profiling": [P, I],
+        "vpt_renderer_tile_classes": [P, C.POINTER(I), C.POINTER(I), C.POINTER(C.c_uint64)],
+        "vpt_classify_tiles": [I, I, I, I, I, P, P, SZ, C.POINTER(I), C.POINTER(I)],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],
         "vpt_probe_math": [P, I, P, P, SZ], "vpt_probe_sample": [P, P, P, SZ], "vpt_probe_stream_read": [P, SZ, I, P], "vpt_probe_assemble_rows": [P, P, I, I, I, I, I, P],
         "vpt_tonemapper_create": [P, I, I, I, P], "vpt_tonemapper_destroy": [P], "vpt_tonemapper_resize": [P, I, I],

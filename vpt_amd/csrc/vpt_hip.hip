@@ -8,6 +8,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -66,6 +68,19 @@ struct vpt_volume {
     uint32_t atlas_face, atlas_shift;   // dwords per face image (row pitch x rows), log2 of the row pitch
 };
 
+// Tile classes (vpt_kernels.h, "Tile classes"): per reset the host sorts the 16x16 tiles into those none of whose camera rays
+// can meet the cube (MISS) and the rest (HIT).  While every pass uses the reset's matrix (and blur == 0) a MISS tile's photons
+// never enter the cube, so its passes run k_mcm_miss on 32 B of state; `stale` says that the position / transmittance arrays
+// of the MISS tiles are behind and k_mcm_materialize must run before anything but k_mcm_miss looks at them.
+struct TileClasses {
+    bool enabled, verify;          // VPT_OPTION_TILE_CLASSES (default on), VPT_OPTION_VERIFY_TILE_CLASSES
+    bool valid;                    // the lists describe `mvp` for the present geometry, and every pass since that reset used it
+    float mvp[16];
+    uint32_t *list; int capacity;  // device: n_hit HIT tiles, then n_miss MISS tiles, each tx | ty << 16
+    int n_hit, n_miss;
+    bool stale, stale_fast;        // MISS tiles' position / transmittance arrays are behind; the pass that left them ran the fast variant
+    unsigned long long *violations;
+};
 struct vpt_renderer {
     vpt_context *ctx;
     int kind;
@@ -107,6 +122,8 @@ struct vpt_renderer {
     int boundary_atlas;            // VPT_OPTION_BOUNDARY_ATLAS (default 1): MCM takes out-of-cube samples from the volume's boundary atlas
     int fast_math;                 // VPT_OPTION_FAST_MATH: MCM events with hardware rcp / rsq / log / sin / cos (k_mcm_integrate<.., V | VPT_V_FAST>)
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
+    struct TileClasses cls;        // MCM: HIT / MISS tile lists of the last reset's matrix (see classify_tiles)
+    int last_layout;               // how the last sampling launch mapped tiles to streams: 0 = tile-row ranges, 1 = tile lists
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
     void *scratch; size_t scratch_bytes;
@@ -378,6 +395,7 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     renderer_free_buffers(r);
+    r->cls.valid = false; r->cls.stale = false;            // new geometry, zeroed state: classes come back with the next reset
     r->dos_cur = 0; r->dos_rect_valid = false;
     int nblocks = (r->H + r->R - 1) / r->R;                 // row blocks in the image
     int mine = (nblocks - r->g + r->G - 1) / r->G;          // blocks b with b % G == g
@@ -476,6 +494,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->fast_math = 0; r->boundary_atlas = 1;
     r->frame_ring = nullptr; r->ring_frames = 0; r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
+    memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
@@ -506,6 +525,8 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (r->samples) hipFree(r->samples);
     if (r->dos_samples) hipFree(r->dos_samples);
     if (r->work_counter) hipFree(r->work_counter);
+    if (r->cls.list) hipFree(r->cls.list);
+    if (r->cls.violations) hipFree(r->cls.violations);
     if (r->frame_ring) hipFree(r->frame_ring);
     if (r->frame_table) hipFree(r->frame_table);
     if (r->frame_staging) hipHostFree(r->frame_staging);
@@ -551,6 +572,124 @@ extern "C" int vpt_renderer_set_volume(vpt_renderer *r, vpt_volume *v) {
     VPT_TRY(join_side(r));
     if (v && v->ctx != r->ctx) return fail(VPT_ERR_INVALID, "volume belongs to another context");
     r->vol = v;
+    return VPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile classes: which 16x16 tiles can no camera ray of theirs take into the cube?  (host only, double precision)
+// ---------------------------------------------------------------------------------------------
+// inverse of a column-major float matrix by Gauss-Jordan with partial pivoting; out[row][col]; false: singular
+static bool invert_matrix(const float *m, double out[4][4]) {
+    double a[4][8];
+    for (int row = 0; row < 4; row++)
+        for (int col = 0; col < 4; col++) { a[row][col] = (double)m[col * 4 + row]; a[row][4 + col] = row == col ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; col++) {
+        int piv = col;
+        for (int row = col + 1; row < 4; row++) if (fabs(a[row][col]) > fabs(a[piv][col])) piv = row;
+        if (!(fabs(a[piv][col]) > 1e-300)) return false;
+        if (piv != col) for (int k = 0; k < 8; k++) std::swap(a[piv][k], a[col][k]);
+        double inv = 1.0 / a[col][col];
+        for (int k = 0; k < 8; k++) a[col][k] *= inv;
+        for (int row = 0; row < 4; row++) if (row != col) { double f = a[row][col]; for (int k = 0; k < 8; k++) a[row][k] -= f * a[col][k]; }
+    }
+    for (int row = 0; row < 4; row++) for (int col = 0; col < 4; col++) out[row][col] = a[row][4 + col];
+    return true;
+}
+// A camera ray of pixel (i, j) — unprojectRand with blur == 0 (mixins/unprojectRand.glsl:3-24) — joins the NDC points
+// (x_i, y_j, -1) and (x_i + ax, y_j + ay, +1), |ax| <= 1/W, |ay| <= 1/H.  The unprojection is projective, so the world-space
+// line is the image of that NDC line, whose point at depth z lies within (1/W, 1/H) * |z + 1| / 2 of (x_i, y_j).  The cube
+// [0,1]^3 (taken as [-VPT_CLASS_EPS, 1 + VPT_CLASS_EPS]^3 against the kernels' fp32 rounding) with all eight corners in front
+// of the eye plane (clip w > 0) maps onto the convex hull of its projected corners, at depths z in [zmin, zmax].  Hence: if the
+// rectangle of a tile's pixel centres, widened by that drift at the cube's depths plus one pixel, does not touch the hull of the
+// cube's projection, no ray of the tile — and no photon travelling along one — can be inside the cube: the tile is a MISS tile.
+// Exact arithmetic is not needed, only conservatism: every doubt (a corner at or behind the eye plane, a singular matrix, wild
+// depths) makes every tile a HIT tile, which is always correct.  classes[ty * tiles_x + tx] = 1 for MISS.  Rows are the LOCAL rows
+// of shard (g of G, R rows per block): a tile whose 16 local rows are several runs of global rows is tested run by run.
+#ifndef VPT_CLASS_EPS
+#define VPT_CLASS_EPS 0.001
+#endif
+static void classify_tiles(int W, int H, int local_h, int G, int g, int R, const float *mvp_inverse, std::vector<uint8_t> &classes, int *ptx, int *pty) {
+    const int tiles_x = (W + VPT_TILE - 1) / VPT_TILE, tiles_y = (local_h + VPT_TILE - 1) / VPT_TILE;
+    *ptx = tiles_x; *pty = tiles_y;
+    classes.assign((size_t)tiles_x * tiles_y, 0);
+    double M[4][4];
+    for (int k = 0; k < 16; k++) if (!(fabsf(mvp_inverse[k]) < 1e30f)) return;       // NaN / inf / absurd entries
+    if (!invert_matrix(mvp_inverse, M)) return;
+    double px[8], py[8], zmin = 1e300, zmax = -1e300;
+    for (int c = 0; c < 8; c++) {
+        const double e = VPT_CLASS_EPS;
+        double p[4] = { (c & 1) ? 1.0 + e : -e, (c & 2) ? 1.0 + e : -e, (c & 4) ? 1.0 + e : -e, 1.0 }, q[4];
+        for (int row = 0; row < 4; row++) q[row] = M[row][0] * p[0] + M[row][1] * p[1] + M[row][2] * p[2] + M[row][3] * p[3];
+        if (!(q[3] > 1e-3)) return;                              // at or behind the eye plane
+        px[c] = q[0] / q[3]; py[c] = q[1] / q[3];
+        const double z = q[2] / q[3];
+        if (!(fabs(px[c]) < 1e6) || !(fabs(py[c]) < 1e6) || !(fabs(z) < 1e3)) return;
+        zmin = std::min(zmin, z); zmax = std::max(zmax, z);
+    }
+    // convex hull (monotone chain, counter-clockwise)
+    int order[8]; for (int c = 0; c < 8; c++) order[c] = c;
+    std::sort(order, order + 8, [&](int a, int b) { return px[a] < px[b] || (px[a] == px[b] && py[a] < py[b]); });
+    auto cross = [&](double ax, double ay, double bx, double by, double cx, double cy) { return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax); };
+    double hx[18], hy[18]; int nh = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int start = nh;
+        for (int k = 0; k < 8; k++) {
+            const int c = pass == 0 ? order[k] : order[7 - k];
+            while (nh - start >= 2 && cross(hx[nh - 2], hy[nh - 2], hx[nh - 1], hy[nh - 1], px[c], py[c]) <= 0.0) nh--;
+            hx[nh] = px[c]; hy[nh] = py[c]; nh++;
+        }
+        nh--;                                                    // the last point of a chain opens the next one
+    }
+    if (nh < 3) return;                                          // degenerate projection
+    double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
+    for (int k = 0; k < nh; k++) { bx0 = std::min(bx0, hx[k]); bx1 = std::max(bx1, hx[k]); by0 = std::min(by0, hy[k]); by1 = std::max(by1, hy[k]); }
+    const double drift = 1.01 * std::max(fabs(zmin + 1.0), fabs(zmax + 1.0)) * 0.5;
+    const double mx = drift / W + 2.0 / W, my = drift / H + 2.0 / H;      // the jitter's drift at the cube's depths + one pixel
+    auto rect_misses = [&](double x0, double x1, double y0, double y1) {
+        if (x1 < bx0 || x0 > bx1 || y1 < by0 || y0 > by1) return true;
+        for (int k = 0; k < nh; k++) {                           // a hull edge with the whole rectangle strictly on its outer side
+            const int k1 = (k + 1) % nh;
+            const double ex = hx[k1] - hx[k], ey = hy[k1] - hy[k];
+            const double tol = -1e-12 * (fabs(ex) + fabs(ey) + 1.0);
+            if (cross(hx[k], hy[k], hx[k1], hy[k1], x0, y0) < tol && cross(hx[k], hy[k], hx[k1], hy[k1], x1, y0) < tol &&
+                cross(hx[k], hy[k], hx[k1], hy[k1], x0, y1) < tol && cross(hx[k], hy[k], hx[k1], hy[k1], x1, y1) < tol) return true;
+        }
+        return false;
+    };
+    for (int ty = 0; ty < tiles_y; ty++) {
+        // runs of consecutive global rows among the tile row's local rows (rows past the image are padding: no pixels)
+        int run0[16], run1[16], nruns = 0;
+        for (int l = ty * VPT_TILE; l < std::min((ty + 1) * VPT_TILE, local_h); l++) {
+            int j = l;
+            if (G > 1) { int lb = l / R; j = (lb * G + g) * R + (l - lb * R); }
+            if (j >= H) continue;
+            if (nruns && run1[nruns - 1] + 1 == j) run1[nruns - 1] = j;
+            else { run0[nruns] = run1[nruns] = j; nruns++; }
+        }
+        for (int tx = 0; tx < tiles_x; tx++) {
+            const int i0 = tx * VPT_TILE, i1 = std::min(i0 + VPT_TILE - 1, W - 1);
+            const double x0 = (2.0 * i0 + 1.0) / W - 1.0 - mx, x1 = (2.0 * i1 + 1.0) / W - 1.0 + mx;
+            bool miss = true;
+            for (int k = 0; k < nruns && miss; k++)
+                miss = rect_misses(x0, x1, (2.0 * run0[k] + 1.0) / H - 1.0 - my, (2.0 * run1[k] + 1.0) / H - 1.0 + my);
+            classes[(size_t)ty * tiles_x + tx] = miss ? 1 : 0;
+        }
+    }
+}
+// (extension, host only: no GPU is touched) the classification as tests/test_tile_classes.py checks it against brute force
+extern "C" int vpt_classify_tiles(int width, int height, int rank, int world, int rows_per_block, const float *mvp_inverse,
+                                  uint8_t *classes, size_t nclasses, int *tiles_x, int *tiles_y) {
+    if (!mvp_inverse || !tiles_x || !tiles_y) return fail(VPT_ERR_INVALID, "null argument");
+    if (width < 1 || height < 1 || width > 32768 || height > 32768 || world < 1 || rank < 0 || rank >= world || rows_per_block < 1)
+        return fail(VPT_ERR_INVALID, "bad geometry");
+    int local_h = height;
+    if (world > 1) { int nblocks = (height + rows_per_block - 1) / rows_per_block; local_h = ((nblocks + world - 1) / world) * rows_per_block; }
+    std::vector<uint8_t> cls;
+    classify_tiles(width, height, local_h, world, rank, rows_per_block, mvp_inverse, cls, tiles_x, tiles_y);
+    if (classes) {
+        if (nclasses < cls.size()) return fail(VPT_ERR_INVALID, "classes buffer too small: %zu < %zu", nclasses, cls.size());
+        memcpy(classes, cls.data(), cls.size());
+    }
     return VPT_OK;
 }
 
@@ -642,6 +781,8 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     const bool wave = wave_blocks(r);
     const unsigned xmul = wave ? 4u : 1u;
     const dim3 block(wave ? 64u : (unsigned)VPT_BLOCK);
+    if (r->side_busy && r->last_layout != 0) VPT_TRY(join_side(r));     // the previous pass dealt tile LISTS to the streams
+    r->last_layout = 0;
     if (r->split >= 2 && !r->no_split && r->tiles_y >= r->split && (!r->target_is_callers || r->split_callers)) {
         // (a frame rendered into caller memory — vpt_renderer_set_render_target — is consumed by work the caller enqueues on the
         // context's stream right behind it: such passes stay on that stream unless the caller has taken the join upon itself
@@ -705,6 +846,124 @@ static int variant_of(const vpt_renderer *r) {
 #define K_MCM0F(V) (k_mcm_integrate<false, V | VPT_V_FAST>)
 #define K_MCM1F(V) (k_mcm_integrate<true, V | VPT_V_FAST>)
 
+// ---- MCM passes over the tile classes ---------------------------------------------------------------------------------
+typedef void (*PassKernel)(PassArgs);
+static bool mcm_classes_usable(const vpt_renderer *r, const PassArgs &a) {
+    return r->cls.enabled && r->cls.valid && a.blur == 0.0f && memcmp(r->cls.mvp, a.mvp_inv.m, sizeof(r->cls.mvp)) == 0;
+}
+// the kernel side of it: LINEAR one-channel volume with its boundary atlas (what k_mcm_miss samples), no persistent-wave option
+static bool mcm_classes_runnable(const vpt_renderer *r, const PassArgs &a) {
+    return a.vol.atlas != nullptr && (variant_of(r) & ~VPT_V_WIDE) == 0 && !r->mcm_persistent;
+}
+// position / transmittance of the MISS tiles, as the last pass's arithmetic would have stored them
+static int mcm_materialize(vpt_renderer *r) {
+    if (!r->cls.stale) return VPT_OK;
+    VPT_TRY(join_side(r));
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    PassArgs a;
+    VPT_TRY(make_args(r, nullptr, false, &a));
+    memcpy(a.mvp_inv.m, r->cls.mvp, sizeof(r->cls.mvp));
+    a.pm.tile_list = r->cls.list + r->cls.n_hit;
+    if (r->cls.n_miss > 0) {
+        if (r->cls.stale_fast) hipLaunchKernelGGL(k_mcm_materialize<true>, dim3((unsigned)r->cls.n_miss), dim3(VPT_BLOCK), 0, r->ctx->stream, a);
+        else hipLaunchKernelGGL(k_mcm_materialize<false>, dim3((unsigned)r->cls.n_miss), dim3(VPT_BLOCK), 0, r->ctx->stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    r->cls.stale = false;
+    return VPT_OK;
+}
+// a reset with matrix `mvp_inverse` has just been enqueued: classify the tiles for it (see classify_tiles)
+static int mcm_classify(vpt_renderer *r, const vpt_uniforms *u) {
+    r->cls.valid = false; r->cls.stale = false;               // the reset rewrote every array
+    if (!r->cls.enabled || u->blur != 0.0f) return VPT_OK;
+    std::vector<uint8_t> cls; int tx, ty;
+    classify_tiles(r->W, r->H, r->local_h, r->G, r->g, r->R, u->mvp_inverse, cls, &tx, &ty);
+    if (tx != r->tiles_x || ty != r->tiles_y || tx > 0xffff || ty > 0xffff) return VPT_OK;
+    std::vector<uint32_t> list(cls.size());
+    int nh = 0, nm = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (int y = 0; y < ty; y++) for (int x = 0; x < tx; x++)
+            if ((int)cls[(size_t)y * tx + x] == pass) { list[(size_t)nh + nm] = (uint32_t)x | ((uint32_t)y << 16); (pass ? nm : nh)++; }
+    if (r->cls.capacity < (int)list.size()) {
+        HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+        if (r->cls.list) { HIP_TRY(hipFree(r->cls.list)); r->cls.list = nullptr; }
+        HIP_TRY(hipMalloc(&r->cls.list, list.size() * sizeof(uint32_t)));
+        r->cls.capacity = (int)list.size();
+    }
+    if (!r->cls.violations) {
+        HIP_TRY(hipMalloc(&r->cls.violations, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(r->cls.violations, 0, sizeof(unsigned long long), r->ctx->stream));
+    }
+    // (the reset joined the side streams; the lists travel on the context's stream, behind the passes that read the old ones)
+    HIP_TRY(hipMemcpyAsync(r->cls.list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, r->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));              // `list` is pageable host memory about to go out of scope
+    r->main_dirty = true;
+    r->cls.n_hit = nh; r->cls.n_miss = nm;
+    memcpy(r->cls.mvp, u->mvp_inverse, sizeof(r->cls.mvp));
+    r->cls.valid = true;
+    return VPT_OK;
+}
+// one MCM pass (integrate, or render() = integrate + renderFrame) as list launches: the HIT tiles through k_mcm_integrate on the
+// context's stream, the MISS tiles through k_mcm_miss — with VPT_OPTION_SPLIT_STREAMS = K as K - 1 equal parts on the side streams,
+// so that the latency-bound HIT tiles and the arithmetic-bound MISS tiles share the chip for the whole frame
+template <bool FUSE>
+static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
+    const bool wide = (variant_of(r) & VPT_V_WIDE) != 0, fast = r->fast_math != 0, check = r->cls.verify;
+    PassKernel kh, km;
+    if (fast) kh = wide ? (PassKernel)k_mcm_integrate<FUSE, VPT_V_WIDE | VPT_V_FAST> : (PassKernel)k_mcm_integrate<FUSE, VPT_V_FAST>;
+    else kh = wide ? (PassKernel)k_mcm_integrate<FUSE, VPT_V_WIDE> : (PassKernel)k_mcm_integrate<FUSE, 0>;
+    if (check) km = fast ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, true> : (PassKernel)k_mcm_miss<FUSE, 0, true>;
+    else km = fast ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, false> : (PassKernel)k_mcm_miss<FUSE, 0, false>;
+    const size_t lds_hit = lds_bytes(r), lds_miss = (size_t)r->tf_w * 2 * sizeof(float4);
+    if (lds_hit > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds_hit);
+    if (lds_hit > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hit));
+    int k = 1;
+    if (r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers)) k = r->split;
+    if (r->side_busy && r->last_layout != 1) VPT_TRY(join_side(r));      // the tile -> stream map changes: order the streams once
+    r->last_layout = 1;
+    struct Part { PassKernel kernel; const uint32_t *list; int n; size_t lds; };
+    Part parts[VPT_MAX_SPLIT]; int np = 0;
+    int hit_parts = r->cls.n_hit > 0 ? 1 : 0;
+    int miss_parts = std::max(1, k - hit_parts);
+    {   // EXPERIMENT: VPT_EXP_LAYOUT="H,M" = H streams of HIT tiles, M streams of MISS tiles (H + M <= the split option)
+        static int eh = -1, em = -1;
+        if (eh < 0) { eh = 0; em = 0; const char *e = getenv("VPT_EXP_LAYOUT"); if (e) sscanf(e, "%d,%d", &eh, &em); }
+        if (eh > 0 && em > 0 && eh + em <= k) { hit_parts = r->cls.n_hit > 0 ? eh : 0; miss_parts = em; }
+    }
+    for (int i = 0; i < hit_parts; i++) {
+        const int h0 = (int)((long long)r->cls.n_hit * i / hit_parts), h1 = (int)((long long)r->cls.n_hit * (i + 1) / hit_parts);
+        if (h1 > h0) parts[np++] = Part{ kh, r->cls.list + h0, h1 - h0, lds_hit };
+    }
+    for (int i = 0; i < miss_parts; i++) {
+        const int m0 = (int)((long long)r->cls.n_miss * i / miss_parts), m1 = (int)((long long)r->cls.n_miss * (i + 1) / miss_parts);
+        if (m1 > m0) parts[np++] = Part{ km, r->cls.list + r->cls.n_hit + m0, m1 - m0, lds_miss };
+    }
+    if (k == 1) {
+        // one stream: the launches follow each other; the dispatch's completion event (gather pipeline) rides on the last
+        for (int i = 0; i < np; i++) {
+            PassArgs part = a;
+            part.pm.tile_list = parts[i].list; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
+            if (i + 1 == np) launch_range(parts[i].kernel, r, dim3((unsigned)parts[i].n), dim3(VPT_BLOCK), parts[i].lds, r->ctx->stream, part, 0);
+            else hipLaunchKernelGGL(parts[i].kernel, dim3((unsigned)parts[i].n), dim3(VPT_BLOCK), parts[i].lds, r->ctx->stream, part);
+        }
+        r->last_ranges = 1;
+    } else {
+        if (r->main_dirty) {
+            HIP_TRY(hipEventRecord(r->ev_fork, r->ctx->stream));
+            for (int i = 0; i + 1 < k; i++) HIP_TRY(hipStreamWaitEvent(r->side[i], r->ev_fork, 0));
+            r->main_dirty = false;
+        }
+        for (int i = 0; i < np; i++) {
+            PassArgs part = a;
+            part.pm.tile_list = parts[i].list; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
+            launch_range(parts[i].kernel, r, dim3((unsigned)parts[i].n), dim3(VPT_BLOCK), parts[i].lds, i == 0 ? r->ctx->stream : r->side[i - 1], part, i);
+        }
+        r->side_busy = true; r->last_ranges = std::max(np, 1);
+    }
+    r->cls.stale = r->cls.n_miss > 0; r->cls.stale_fast = fast;
+    return VPT_OK;
+}
+
 template <typename K>
 static int launch_mcs_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
     size_t lds = lds_bytes(r);
@@ -753,6 +1012,26 @@ static int launch_mcm_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
         default: VPT_TRY(launch_mcs_persist((k_mcs_persist<MODE, 3>), (r), (a))); break; \
     } } while (0)
 
+// MCM passes with a matrix (or a blur) other than the reset's: the photons of MISS tiles may now enter the cube — the classes are
+// void until the next reset.  Whole-image kernels need the MISS tiles' position / transmittance arrays up to date first.
+static int mcm_before_pass(vpt_renderer *r, const PassArgs &a, bool *same_matrix) {
+    const bool same = r->cls.valid && a.blur == 0.0f && memcmp(r->cls.mvp, a.mvp_inv.m, sizeof(r->cls.mvp)) == 0;
+    if (r->cls.valid && !same) { VPT_TRY(mcm_materialize(r)); r->cls.valid = false; }
+    if (same_matrix) *same_matrix = same;
+    return VPT_OK;
+}
+template <bool FUSE>
+static int launch_mcm_pass(vpt_renderer *r, const PassArgs &a) {
+    bool same = false;
+    VPT_TRY(mcm_before_pass(r, a, &same));
+    if (same && r->cls.enabled && mcm_classes_runnable(r, a)) return launch_mcm_classes<FUSE>(r, a);
+    VPT_TRY(mcm_materialize(r));
+    if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCM_PERSIST(FUSE, r, a);
+    else if (r->fast_math) { if (FUSE) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM0F, r, a); }
+    else { if (FUSE) LAUNCH_S(K_MCM1, r, a); else LAUNCH_S(K_MCM0, r, a); }
+    return VPT_OK;
+}
+
 static int check_step(const vpt_uniforms *u) {
     // step sizes <= 0 or NaN would never advance t: the reference's spinner enforces min 1 (MIPRenderer.js:24, EAMRenderer.js:34)
     if (!(u->step_size > 0.0f)) return fail(VPT_ERR_INVALID, "step_size must be > 0");
@@ -796,7 +1075,7 @@ extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_MIP: LAUNCH(k_mip_reset, r, a, 0); break;
         case VPT_RENDERER_EAM: LAUNCH(k_eam_reset, r, a, 0); break;
         case VPT_RENDERER_MCS: LAUNCH(k_mcs_reset, r, a, 0); break;
-        case VPT_RENDERER_MCM: LAUNCH(k_mcm_reset, r, a, 0); break;
+        case VPT_RENDERER_MCM: LAUNCH(k_mcm_reset, r, a, 0); HIP_TRY(hipGetLastError()); VPT_TRY(mcm_classify(r, u)); break;
         case VPT_RENDERER_ISO: LAUNCH(k_iso_reset, r, a, 0); break;
         case VPT_RENDERER_DEPTH: LAUNCH(k_depth_reset, r, a, 0); break;
         case VPT_RENDERER_LAO: LAUNCH(k_eam_reset, r, a, 0); break;           // LAORenderer.glsl:285-287: (0, 0, 0, 1) into RGBA8
@@ -848,7 +1127,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
         case VPT_RENDERER_LAO: LAUNCH(k_lao_integrate, r, a, 0); break;
         case VPT_RENDERER_MCM: {
             Timed t(r, true);
-            if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCM_PERSIST(false, r, a); else if (r->fast_math) LAUNCH_S(K_MCM0F, r, a); else LAUNCH_S(K_MCM0, r, a);
+            VPT_TRY(launch_mcm_pass<false>(r, a));
             r->samples_host += r->valid_pixels * (uint64_t)u->steps;   // exactly W*H*steps per pass (MCMRenderer.glsl:129-133)
         } break;
     }
@@ -884,9 +1163,7 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
         case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH1, r, a); break;
         case VPT_RENDERER_LAO: LAUNCH_S(K_LAO1, r, a); break;
         case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
-        case VPT_RENDERER_MCM:
-            if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCM_PERSIST(true, r, a); else if (r->fast_math) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM1, r, a);
-            break;
+        case VPT_RENDERER_MCM: VPT_TRY(launch_mcm_pass<true>(r, a)); break;
     }
     return VPT_OK;
 }
@@ -981,6 +1258,9 @@ static int launch_frames(K kernel, vpt_renderer *r, const PassArgs &a, uint32_t 
     return VPT_OK;
 }
 static int launch_mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses, uint2 *ring = nullptr) {
+    VPT_TRY(mcm_before_pass(r, a, nullptr));
+    VPT_TRY(mcm_materialize(r));                      // a whole-image kernel: every tile's full photon state
+    if (r->side_busy) VPT_TRY(join_side(r));
 #define MULTI_CASES(F) switch (variant_of(r)) { \
         case 0: return ring ? launch_frames(k_mcm_frames<0 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<0 | F>, r, a, npasses); \
         case 1: return ring ? launch_frames(k_mcm_frames<1 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<1 | F>, r, a, npasses); \
@@ -1111,6 +1391,7 @@ extern "C" int vpt_renderer_read(vpt_renderer *r, int buffer, void *dst, size_t 
         src = (buffer == VPT_BUFFER_FRAME) ? r->frame : r->acc;
     } else if (buffer >= VPT_BUFFER_MCM_POSITION && buffer <= VPT_BUFFER_MCM_RADIANCE) {
         if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_INVALID, "not an MCM renderer");
+        if (buffer == VPT_BUFFER_MCM_POSITION || buffer == VPT_BUFFER_MCM_TRANSMITTANCE) VPT_TRY(mcm_materialize(r));
         elem = 16; src = r->st[buffer - VPT_BUFFER_MCM_POSITION];
     } else {
         return fail(VPT_ERR_INVALID, "unknown buffer %d", buffer);
@@ -1190,22 +1471,12 @@ extern "C" int vpt_renderer_set_occlusion_samples(vpt_renderer *r, const float *
 static void dos_tile_rect(const vpt_renderer *r, const float *mvp_inverse, int rect[4]) {
     const int tx = r->tiles_x, ty = r->tiles_y;
     rect[0] = 0; rect[1] = 0; rect[2] = tx; rect[3] = ty;
-    double a[4][8];                                  // [M^-1 | I], column-major source -> row-major work matrix
-    for (int row = 0; row < 4; row++)
-        for (int col = 0; col < 4; col++) { a[row][col] = (double)mvp_inverse[col * 4 + row]; a[row][4 + col] = row == col ? 1.0 : 0.0; }
-    for (int col = 0; col < 4; col++) {              // Gauss-Jordan with partial pivoting
-        int piv = col;
-        for (int row = col + 1; row < 4; row++) if (fabs(a[row][col]) > fabs(a[piv][col])) piv = row;
-        if (!(fabs(a[piv][col]) > 1e-300)) return;
-        if (piv != col) for (int k = 0; k < 8; k++) std::swap(a[piv][k], a[col][k]);
-        double inv = 1.0 / a[col][col];
-        for (int k = 0; k < 8; k++) a[col][k] *= inv;
-        for (int row = 0; row < 4; row++) if (row != col) { double f = a[row][col]; for (int k = 0; k < 8; k++) a[row][k] -= f * a[col][k]; }
-    }
+    double a[4][4];
+    if (!invert_matrix(mvp_inverse, a)) return;
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
     for (int c = 0; c < 8; c++) {
         double p[4] = { (double)(c & 1), (double)((c >> 1) & 1), (double)((c >> 2) & 1), 1.0 }, q[4];
-        for (int row = 0; row < 4; row++) q[row] = a[row][4] * p[0] + a[row][5] * p[1] + a[row][6] * p[2] + a[row][7] * p[3];
+        for (int row = 0; row < 4; row++) q[row] = a[row][0] * p[0] + a[row][1] * p[1] + a[row][2] * p[2] + a[row][3] * p[3];
         if (!(q[3] > 1e-4)) return;
         double x = q[0] / q[3], y = q[1] / q[3];
         if (!(fabs(x) < 1e6) || !(fabs(y) < 1e6)) return;
@@ -1297,7 +1568,12 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
             HIP_TRY(hipSetDevice(r->ctx->device));
             if (value >= 2 && !r->ev_fork) HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
             for (int i = 0; i + 1 < value; i++) if (!r->side[i]) {
+#ifdef VPT_EXP_SIDE_LOW_PRIO
+                { int least = 0, greatest = 0; HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                  HIP_TRY(hipStreamCreateWithPriority(&r->side[i], hipStreamNonBlocking, least)); }
+#else
                 HIP_TRY(hipStreamCreateWithFlags(&r->side[i], hipStreamNonBlocking));
+#endif
                 HIP_TRY(hipEventCreateWithFlags(&r->ev_join[i], hipEventDisableTiming));
             }
             r->split = value; return VPT_OK;
@@ -1306,7 +1582,14 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
             r->split_callers = value != 0; return VPT_OK;
         case VPT_OPTION_FAST_MATH:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_FAST_MATH: only the MCM renderer has a fast-arithmetic variant");
+            if ((value != 0) != (r->fast_math != 0)) VPT_TRY(mcm_materialize(r));   // MISS-tile positions in the arithmetic that produced the directions
             r->fast_math = value != 0; return VPT_OK;
+        case VPT_OPTION_TILE_CLASSES:
+            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_TILE_CLASSES: an MCM option");
+            r->cls.enabled = value != 0; return VPT_OK;
+        case VPT_OPTION_VERIFY_TILE_CLASSES:
+            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_VERIFY_TILE_CLASSES: an MCM option");
+            r->cls.verify = value != 0; return VPT_OK;
         default: return fail(VPT_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -1328,6 +1611,23 @@ extern "C" int vpt_renderer_clear_sample_count(vpt_renderer *r) {
     HIP_TRY(hipSetDevice(r->ctx->device));
     HIP_TRY(hipMemsetAsync(r->samples, 0, COUNTER_BYTES, r->ctx->stream));
     r->samples_host = 0;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_tile_classes(vpt_renderer *r, int *hit_tiles, int *miss_tiles, uint64_t *violations) {
+    if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
+    if (hit_tiles) *hit_tiles = r->cls.valid ? r->cls.n_hit : r->ntiles;
+    if (miss_tiles) *miss_tiles = r->cls.valid ? r->cls.n_miss : 0;
+    if (violations) {
+        *violations = 0;
+        if (r->cls.violations) {
+            VPT_TRY(join_side(r));
+            HIP_TRY(hipSetDevice(r->ctx->device));
+            unsigned long long v = 0;
+            HIP_TRY(hipMemcpyAsync(&v, r->cls.violations, sizeof(v), hipMemcpyDeviceToHost, r->ctx->stream));
+            HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+            *violations = v;
+        }
+    }
     return VPT_OK;
 }
 extern "C" int vpt_renderer_set_profiling(vpt_renderer *r, int enabled) {

@@ -27,6 +27,9 @@ struct PixMap {
     int rshift;        // log2(R) when R is a power of two, else -1
     int ty0;           // first tile row of this launch (a pass split over two streams launches two row ranges; else 0)
     const float *ndc_x, *ndc_y;   // pixel-centre NDC per column / global row: fl(fl((2i+1)/W) - 1), W resp. H entries
+    // launch over a LIST of tiles instead of the whole tile grid (tile classes): workgroup b of a
+    // 1-D grid takes tile tile_list[b] = tx | ty << 16; null = the 2-D grid below
+    const uint32_t *tile_list;
 };
 struct Pix { int i, j, l, k; bool valid, tile; };   // tile: the workgroup maps to a tile of the buffers (valid or padding pixel)
 
@@ -48,7 +51,12 @@ VPT_DEV int global_row(const PixMap &m, int l) {
 VPT_DEV Pix map_pixel(const PixMap &m) {
     int xcd = (int)blockIdx.x & 7, ty = (int)blockIdx.y + m.ty0;
     int tx, w, lane = (int)threadIdx.x & 63;
-    if (blockDim.x == 64) {
+    if (m.tile_list) {
+        // listed tiles (one scalar load): consecutive workgroups = consecutive list entries, dealt round-robin over the XCDs
+        const uint32_t e = m.tile_list[blockIdx.x];
+        tx = (int)(e & 0xffffu); ty = (int)(e >> 16);
+        w = (int)threadIdx.x >> 6;
+    } else if (blockDim.x == 64) {
         // one-wave workgroups (the ray marchers when their LDS image is small): blockIdx.x = (group * 4 + wave) * 8 + xcd.
         // Same tile -> XCD map and the same buffer order; the unit the dispatcher balances over the CUs is a quarter
         // of a tile, so the few cube-crossing tiles of a frame spread evenly (wave-uniform branch on blockDim)
@@ -97,6 +105,8 @@ struct PassArgs {
         DosParams dos;           // DOS renderer: one slice (vpt_kernels_iso_depth.h)
     };
     uint32_t multi_passes;       // > 1: the fused (MODE 1) kernels run that many passes per pixel in one launch (VPT_PLAY_FUSED)
+    uint32_t miss_load_pos;      // k_mcm_miss: 1 = the position array is up to date (first classified pass after a reset or a whole-image pass): load it
+    unsigned long long *violations;   // k_mcm_miss<.., CHECK>: events of "miss" tiles that were inside the cube (must stay 0)
     void *frame;                 // tile order
     void *acc;                   // tile order (ping-pong collapsed: each pixel reads and writes only itself)
     float4 *st0, *st1, *st2, *st3;   // MCM photon state, tile order
@@ -643,8 +653,10 @@ struct Photon {
 // mixins/unprojectRand.glsl:3-24.  The near-plane point depends on the pixel only when blur == 0 (the reference
 // always passes 0: MCMRenderer.js:93,157): the two disk uniforms are still drawn, their product with 0 is an exact
 // zero, so `from` equals the un-jittered unprojection `from0` computed once per pixel.
+// NOBLUR: the caller knows blur == 0 (k_mcm_miss: the tile classes are only used with it), the general branch is not compiled
+template <bool NOBLUR = false>
 VPT_DEV void unproject_rand(uint32_t &state, float px, float py, const PassArgs &a, f3 from0, f3 &from, f3 &to) {
-    if (a.blur == 0.0f) {
+    if (NOBLUR || a.blur == 0.0f) {
         random_uniform(state); random_uniform(state);
         from = from0;
     } else {
@@ -660,13 +672,19 @@ VPT_DEV f3 unproject_near(float px, float py, const PassArgs &a) {
     return dehomogenize(mat4_mul_point(a.mvp_inv, px + 0.0f, py + 0.0f, -1.0f));
 }
 // resetPhoton: MCMRenderer.glsl:70-78
+// the photon's start on its ray: from + max(tnear, 0) * direction (MCMRenderer.glsl:75-77).  A function of (from, direction) alone:
+// the kernels of cube-missing tiles (k_mcm_miss) recompute it from the stored direction instead of storing it.
+VPT_DEV f3 photon_start(f3 from, f3 dir) {
+    float tnear = vmax(intersect_cube_near(from, dir), 0.0f);
+    return madd3(from, tnear, dir);
+}
+template <bool NOBLUR = false>
 VPT_DEV void reset_photon(uint32_t &state, Photon &ph, float px, float py, const PassArgs &a, f3 from0) {
     f3 from, to;
-    unproject_rand(state, px, py, a, from0, from, to);
+    unproject_rand<NOBLUR>(state, px, py, a, from0, from, to);
     ph.direction = normalize3(sub3(to, from));
     ph.bounces = 0u;
-    float tnear = vmax(intersect_cube_near(from, ph.direction), 0.0f);
-    ph.position = madd3(from, tnear, ph.direction);
+    ph.position = photon_start(from, ph.direction);
     ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
 }
 // sampleHenyeyGreensteinAngleCosine: MCMRenderer.glsl:91-95
@@ -800,6 +818,26 @@ VPT_DEV f3 sample_hg_fast(uint32_t &state, float g, f3 dir) {
 }
 // the end of a path in the fast variant: deposit `rad`, then resetPhoton (MCMRenderer.glsl:146-151 / 153-158, :70-78)
 struct FastPixel { f3 from0; float4 fb; float jx, jy; };
+// photon_start in the fast variant's arithmetic: min((0 - f) * iv, (1 - f) * iv) = -f * iv + min(iv, 0), one min and one fma per slab
+VPT_DEV f3 photon_start_fast(f3 from0, f3 dir) {
+    f3 iv = { hw_rcp(dir.x), hw_rcp(dir.y), hw_rcp(dir.z) };
+    float tx = fmaf(-from0.x, iv.x, vmin(iv.x, 0.0f));
+    float ty = fmaf(-from0.y, iv.y, vmin(iv.y, 0.0f));
+    float tz = fmaf(-from0.z, iv.z, vmin(iv.z, 0.0f));
+    float tnear = vmax(vmax(vmax(tx, ty), tz), 0.0f);
+    return madd3(from0, tnear, dir);
+}
+// the pixel constants of the fast variant's resetPhoton with blur == 0: the near-plane point and the far-plane base point (homogeneous)
+VPT_DEV FastPixel fast_pixel(const PassArgs &a, float px, float py) {
+    FastPixel c;
+    const float4 nb = mat4_mul_point(a.mvp_inv, px, py, -1.0f);
+    const float inw = hw_rcp(nb.w);
+    c.from0 = f3{ nb.x * inw, nb.y * inw, nb.z * inw };
+    c.fb = mat4_mul_point(a.mvp_inv, px, py, 1.0f);
+    c.jx = 0x1p-31f * a.inv_w; c.jy = 0x1p-31f * a.inv_h;
+    return c;
+}
+template <bool NOBLUR = false>
 VPT_DEV void fast_path_end(const PassArgs &a, const FastPixel &c, uint32_t &state, Photon &ph, f3 rad, float px, float py) {
     const float *m = a.mvp_inv.m;
     ph.samples++;
@@ -807,7 +845,7 @@ VPT_DEV void fast_path_end(const PassArgs &a, const FastPixel &c, uint32_t &stat
     ph.radiance.x = fmaf(rad.x - ph.radiance.x, inv_n, ph.radiance.x);
     ph.radiance.y = fmaf(rad.y - ph.radiance.y, inv_n, ph.radiance.y);
     ph.radiance.z = fmaf(rad.z - ph.radiance.z, inv_n, ph.radiance.z);
-    if (a.blur == 0.0f) {
+    if (NOBLUR || a.blur == 0.0f) {
         state = pcg(pcg(state));                          // the disk sample's two draws (multiplied by blur = 0)
         float ax = fmaf(pcg_float(state), c.jx, -a.inv_w);
         float ay = fmaf(pcg_float(state), c.jy, -a.inv_h);
@@ -816,14 +854,8 @@ VPT_DEV void fast_path_end(const PassArgs &a, const FastPixel &c, uint32_t &stat
         f3 d = { fmaf(-th.w, c.from0.x, th.x), fmaf(-th.w, c.from0.y, th.y), fmaf(-th.w, c.from0.z, th.z) };
         float inv = __builtin_copysignf(hw_rsq(dot3(d, d)), th.w);
         f3 dir = { d.x * inv, d.y * inv, d.z * inv };
-        f3 iv = { hw_rcp(dir.x), hw_rcp(dir.y), hw_rcp(dir.z) };
-        // min((0 - f) * iv, (1 - f) * iv) = -f * iv + min(iv, 0): one min and one fma per slab
-        float tx = fmaf(-c.from0.x, iv.x, vmin(iv.x, 0.0f));
-        float ty = fmaf(-c.from0.y, iv.y, vmin(iv.y, 0.0f));
-        float tz = fmaf(-c.from0.z, iv.z, vmin(iv.z, 0.0f));
-        float tnear = vmax(vmax(vmax(tx, ty), tz), 0.0f);
         ph.direction = dir;
-        ph.position = madd3(c.from0, tnear, dir);
+        ph.position = photon_start_fast(c.from0, dir);
         ph.bounces = 0u;
         ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
     } else {
@@ -832,13 +864,7 @@ VPT_DEV void fast_path_end(const PassArgs &a, const FastPixel &c, uint32_t &stat
 }
 template <int V>
 VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
-    // pixel constants of resetPhoton with blur == 0: the near-plane point and the far-plane base point (homogeneous)
-    FastPixel c;
-    const float4 nb = mat4_mul_point(a.mvp_inv, px, py, -1.0f);
-    const float inw = hw_rcp(nb.w);
-    c.from0 = f3{ nb.x * inw, nb.y * inw, nb.z * inw };
-    c.fb = mat4_mul_point(a.mvp_inv, px, py, 1.0f);
-    c.jx = 0x1p-31f * a.inv_w; c.jy = 0x1p-31f * a.inv_h;
+    const FastPixel c = fast_pixel(a, px, py);
     // -ln(u * 2^-32) / extinction = (log2(u) - 32) * ld
     const float ld = -0.6931471805599453f * a.inv_extinction, ld32 = -32.0f * ld;
 
@@ -946,6 +972,9 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
 template <bool FUSE_RENDER, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(VPT_MCM_WAVES, 8))) k_mcm_integrate(PassArgs a) {
+#ifdef VPT_EXP_HIT_PRIO
+    if (a.pm.tile_list) __builtin_amdgcn_s_setprio(VPT_EXP_HIT_PRIO);
+#endif
     apply_frame_table(a);
     // the photon state (4 x dwordx4 per lane, one contiguous 1 KiB segment per wave and array) does not depend on the LDS
     // image: its loads are issued first, so they fly while the workgroup stages the tables and hashes its seed
@@ -963,6 +992,126 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     if (FUSE_RENDER)
         store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
 }
+// =============================================================================================
+// Tile classes (round 3).  The host classifies every 16x16 tile against the cube once per reset (vpt_hip.hip classify_tiles:
+// a conservative test of the tile's pixel columns, jitter included, against the projected cube, enlarged): a MISS tile is one
+// none of whose camera rays can meet the cube.  resetPhoton (MCMRenderer.glsl:70-78) parks such a photon at from + tnear * dir,
+// outside the cube, on a ray that leaves it behind — so EVERY event of a MISS tile's pixel is "sample at the clamped position
+// (MCMRenderer.glsl:132), find the position out of bounds (:135), deposit transmittance * environment (:136-140), resetPhoton
+// (:141)": no in-cube sample, no absorption / scattering / null branch, and at the end of every pass transmittance = (1, 1, 1),
+// bounces = 0 and position = photon_start(from0, direction).  k_mcm_miss runs exactly that straight-line event — the same
+// arithmetic, draw for draw, as the oob lanes of k_mcm_integrate, so the buffers are bit-identical — with
+//   * the sample still executed for every event (boundary atlas gather + transfer-function lookup, result kept alive),
+//   * 32 instead of 56 bytes of photon state each way: only [direction, bounces] and [radiance, samples] are read and written; the
+//     position is recomputed from the direction, and the position / transmittance arrays of MISS tiles are brought up to date by
+//     k_mcm_materialize before anything else looks at them (read-back, whole-image kernels, a changed matrix),
+//   * no brick tables in LDS (the atlas needs none), fewer registers: 8 waves per SIMD.
+// At the benchmark camera ~78 % of the tiles are MISS tiles.  HIT tiles run k_mcm_integrate from their own tile list.
+// CHECK: count the events that contradict the classification (tests / VPT_OPTION_VERIFY_TILE_CLASSES; must stay 0).
+// =============================================================================================
+VPT_DEV const float4 *stage_tf(float4 *lds, const PassArgs &a) {
+    const int nthreads = (int)blockDim.x;
+    for (int t = (int)threadIdx.x; t < a.tf_w; t += nthreads) {
+        float4 v = a.tf[t], n = a.tf[min(t + 1, a.tf_w - 1)];
+        lds[2 * t] = v;
+        lds[2 * t + 1] = make_float4(n.x - v.x, n.y - v.y, n.z - v.z, n.w - v.w);
+    }
+    __syncthreads();
+    return lds;
+}
+// the executed-and-discarded sample of an out-of-cube event: texture(uVolume, clamp(p)) through the boundary atlas, then the
+// transfer function (MCMRenderer.glsl:85-89,132).  Precondition (the tile class): p has a coordinate outside [0, 1].
+template <bool CHECK>
+VPT_DEV void miss_sample(const PassArgs &a, const float4 *tf, f3 q, unsigned long long *violations) {
+    float4 vs = sample_tf(tf, a.tf_fw, a.tf_hi, sample_volume_boundary(a.vol, q));
+    asm volatile("" : "+v"(vs.w));
+    if (CHECK) {
+        const bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+        if (!oob) atomicAdd(violations, 1ull);
+    }
+}
+template <int V, bool CHECK>
+VPT_DEV void mcm_events_miss(const PassArgs &a, const float4 *tf, Photon &ph, float px, float py, f3 from0) {
+    uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    for (uint32_t s = 0u; s < a.steps; s++) {
+        float dist = random_exponential(state, a.inv_extinction);
+        ph.position = madd3(ph.position, dist, ph.direction);
+        miss_sample<CHECK>(a, tf, ph.position, a.violations);
+        random_uniform(state);                                     // the wheel draw (its value decides nothing out of bounds)
+        float4 env = sample_environment(a.env, ph.direction);      // transmittance is (1, 1, 1): radiance = 1 * env, exactly env
+        photon_deposit(ph, f3{ env.x, env.y, env.z });
+        reset_photon<true>(state, ph, px, py, a, from0);
+    }
+}
+template <int V, bool CHECK>
+VPT_DEV void mcm_events_miss_fast(const PassArgs &a, const float4 *tf, const FastPixel &c, Photon &ph, float px, float py) {
+    const float ld = -0.6931471805599453f * a.inv_extinction, ld32 = -32.0f * ld;
+    uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    for (uint32_t s = 0u; s < a.steps; s++) {
+        float dist = fmaf(hw_log2(pcg_float(state)), ld, ld32);
+        ph.position = madd3(ph.position, dist, ph.direction);
+        miss_sample<CHECK>(a, tf, ph.position, a.violations);
+        state = pcg(state);                                        // the wheel draw
+        float4 env = sample_environment(a.env, ph.direction);
+        fast_path_end<true>(a, c, state, ph, f3{ env.x, env.y, env.z }, px, py);
+    }
+}
+#ifndef VPT_MISS_WAVES
+#define VPT_MISS_WAVES 8
+#endif
+template <bool FUSE_RENDER, int V, bool CHECK>
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(VPT_MISS_WAVES, 8))) k_mcm_miss(PassArgs a) {
+#ifdef VPT_EXP_MISS_PRIO
+    __builtin_amdgcn_s_setprio(VPT_EXP_MISS_PRIO);
+#endif
+    apply_frame_table(a);
+    Pix p = map_pixel(a.pm);
+    float4 s1 = make_float4(0.0f, 0.0f, 1.0f, 0.0f), s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    f3 s0 = { 0.0f, 0.0f, 0.0f };
+    if (p.tile) {
+        s1 = a.st1[p.k]; s3 = a.st3[p.k];
+        if (a.miss_load_pos) s0 = ((const f3 *)a.st0)[p.k];
+    }
+    extern __shared__ float4 lds_raw[];
+    const float4 *tf = stage_tf(lds_raw, a);
+    if (!p.valid) return;
+    const float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
+    Photon ph;
+    ph.direction = f3{ s1.x, s1.y, s1.z };
+    ph.bounces = 0u;
+    ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
+    ph.radiance = f3{ s3.x, s3.y, s3.z };
+    ph.samples = (uint32_t)(s3.w + 0.5f);
+    if (V & VPT_V_FAST) {
+        const FastPixel c = fast_pixel(a, px, py);
+        ph.position = a.miss_load_pos ? s0 : photon_start_fast(c.from0, ph.direction);
+        mcm_events_miss_fast<V & ~VPT_V_FAST, CHECK>(a, tf, c, ph, px, py);
+    } else {
+        const f3 from0 = unproject_near(px, py, a);
+        ph.position = a.miss_load_pos ? s0 : photon_start(from0, ph.direction);
+        mcm_events_miss<V, CHECK>(a, tf, ph, px, py, from0);
+    }
+    a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
+    a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
+    if (FUSE_RENDER)
+        store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+}
+// brings the position / transmittance arrays of the MISS tiles up to date: position = photon_start(from0, direction) in the
+// arithmetic of the variant that ran the last pass, transmittance = (1, 1, 1)
+template <bool FAST>
+__global__ void __launch_bounds__(VPT_BLOCK) k_mcm_materialize(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    const float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
+    const float4 s1 = a.st1[p.k];
+    const f3 dir = { s1.x, s1.y, s1.z };
+    f3 pos;
+    if (FAST) pos = photon_start_fast(fast_pixel(a, px, py).from0, dir);
+    else pos = photon_start(unproject_near(px, py, a), dir);
+    ((f3 *)a.st0)[p.k] = pos;
+    ((f3 *)a.st2)[p.k] = f3{ 1.0f, 1.0f, 1.0f };
+}
+
 // `npasses` whole render() passes of one pixel in ONE launch (vpt_renderer_play, VPT_PLAY_FUSED): the photon state
 // stays in registers between passes — one 64 B read + 64 B write per pixel for the whole sequence instead of per pass —
 // and the launch / staging cost is paid once.  Pass f re-seeds from the f-th entry of the frame table exactly as

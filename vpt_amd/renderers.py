@@ -240,6 +240,12 @@ class AbstractRenderer(PropertyBag):
     def clear_sample_count(self):
         N.check(N.lib().vpt_renderer_clear_sample_count(self._h))
 
+    def tile_classes(self):
+        """(HIT tiles, MISS tiles, violations) of the tile classes in force (vpt_renderer_tile_classes)"""
+        h, m, v = C.c_int(0), C.c_int(0), C.c_uint64(0)
+        N.check(N.lib().vpt_renderer_tile_classes(self._h, C.byref(h), C.byref(m), C.byref(v)))
+        return h.value, m.value, v.value
+
     def set_profiling(self, enabled):
         """False/0: off; True/1: time every launch; n > 1: every n-th launch"""
         N.check(N.lib().vpt_renderer_set_profiling(self._h, int(enabled)))
