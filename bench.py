@@ -22,6 +22,14 @@ sys.path.insert(0, ROOT)
 B_ALG_MCM = 24.0          # algorithmic bytes per volume sample: 8 * sizeof(u8) + (64 B read + 64 B write) / steps(8)
 B_OWN_MCM = 22.0          # the same with this library's 56-byte photon state: 8 + (56 + 56) / 8
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# Stated tolerance of the fast-arithmetic MCM variant against the contract oracle in the N = 1 frame check: per pixel, the maximum over the RGB
+# channels of |radiance - oracle radiance| on the band's texels (radiance = running mean of path radiances, each in [0, 1]), after every pass
+# played (~4 700 in the default run).  Pixels whose rays miss the cube must agree exactly in path count and to 1e-6 in value; of the pixels that
+# cross it >= 95 % must have the oracle's path count (a comparison that falls within rounding flips a path's fate: measured 98.4 %), and the
+# mean / 99.9th percentile / maximum of |d| must stay below 5e-5 / 5e-3 / 2e-2 (measured 8.0e-7 / 1.1e-4 / 1.6e-4, gpurun_out/r03/bench_run.json;
+# DESIGN.md section 3).
+FAST_MATH_BOUNDS = {"max_abs_d_missing": 1e-6, "min_equal_counts_crossing": 0.95, "mean_abs_d_crossing": 5e-5,
+                    "p999_abs_d_crossing": 5e-3, "max_abs_d_crossing": 2e-2}
 
 
 def parse():
@@ -73,7 +81,7 @@ def parse():
                     help="MCM: 0 = out-of-cube samples from the bricks as well (VPT_OPTION_BOUNDARY_ATLAS off; results identical)")
     ap.add_argument("--tile-classes", type=int, default=1,
                     help="MCM: 0 = every tile through the general kernel (VPT_OPTION_TILE_CLASSES off; results identical)")
-    ap.add_argument("--split-streams", type=int, default=3,
+    ap.add_argument("--split-streams", type=int, default=2,
                     help="MCM: K >= 2 = launch every pass as K tile-row ranges on K HIP streams (VPT_OPTION_SPLIT_STREAMS; results identical)")
     ap.add_argument("--split-caller-targets", type=int, default=0,
                     help="torch.distributed pipeline: 1 = split passes into the gather's buckets too and join once per bucket (measured: no gain)")
@@ -166,6 +174,8 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
                 r.set_option(N.OPTION_FAST_MATH, int(v))
             elif k == "split":
                 r.set_option(N.OPTION_SPLIT_STREAMS, int(v))
+            elif k == "classes":
+                r.set_option(N.OPTION_TILE_CLASSES, int(v))
             else:
                 setattr(r, k, v)
         r.reset()
@@ -210,18 +220,23 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
         t_gen = time.perf_counter() - t0
         g1024 = vpt_amd.Volume.from_array(ctx, v, 'linear')
         del v
-        for name, fm, sp in (("C4_mcm_1024_1080p", 0, 1), ("C4_mcm_1024_1080p_fast_math", 1, 1),
-                             ("C4_mcm_1024_1080p_three_streams", 0, 3), ("C4_mcm_1024_1080p_fast_math_three_streams", 1, 3)):
-            t, ns = run('mcm', g1024, fast_math=fm, split=sp)
-            out[name] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "bytes_per_sample": B_ALG_MCM,
+        # (MCM forms: tile classes on = HIT | MISS kernels on two streams, the library's best form; "_general_kernel" = every tile through
+        # k_mcm_integrate as in round 2, on one or three streams)
+        for name, fm, sp, tc in (("C4_mcm_1024_1080p", 0, 2, 1), ("C4_mcm_1024_1080p_fast_math", 1, 2, 1),
+                                 ("C4_mcm_1024_1080p_general_kernel_one_stream", 0, 1, 0), ("C4_mcm_1024_1080p_fast_math_general_kernel_three_streams", 1, 3, 0)):
+            t, ns = run('mcm', g1024, fast_math=fm, split=sp, classes=tc)
+            out[name] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "bytes_per_sample": B_ALG_MCM, "tile_classes": bool(tc), "streams": sp,
                          "roofline": {"frac": B_ALG_MCM * ns / t / (HBM_PEAK_GBS * 1e9), "achieved": B_ALG_MCM * ns / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
         out["C4_mcm_1024_1080p"]["volume_generate_s"] = t_gen
         g1024.destroy()
         # the headline workload in its other forms (the line above is --fast-math 1 --split-streams 3)
-        for name, fm, sp in (("H_mcm_512_1080p_bit_exact_one_stream", 0, 1), ("H_mcm_512_1080p_bit_exact_three_streams", 0, 3),
-                             ("H_mcm_512_1080p_fast_math_one_stream", 1, 1), ("H_mcm_512_1080p_fast_math_three_streams", 1, 3)):
-            t, ns = run('mcm', gvol512, frames=200, fast_math=fm, split=sp)
-            out[name] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "roofline": {"frac": B_ALG_MCM * ns / t / (HBM_PEAK_GBS * 1e9)}}
+        for name, fm, sp, tc in (("H_mcm_512_1080p_bit_exact", 0, 2, 1), ("H_mcm_512_1080p_fast_math", 1, 2, 1),
+                                 ("H_mcm_512_1080p_bit_exact_one_stream", 0, 1, 1), ("H_mcm_512_1080p_fast_math_one_stream", 1, 1, 1),
+                                 ("H_mcm_512_1080p_bit_exact_general_kernel_one_stream", 0, 1, 0), ("H_mcm_512_1080p_bit_exact_general_kernel_three_streams", 0, 3, 0),
+                                 ("H_mcm_512_1080p_fast_math_general_kernel_one_stream", 1, 1, 0), ("H_mcm_512_1080p_fast_math_general_kernel_three_streams", 1, 3, 0)):
+            t, ns = run('mcm', gvol512, frames=200, fast_math=fm, split=sp, classes=tc)
+            out[name] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "tile_classes": bool(tc), "streams": sp,
+                         "roofline": {"frac": B_ALG_MCM * ns / t / (HBM_PEAK_GBS * 1e9)}}
         # NOT the judged form: 16 passes per launch with the photon state in registers (VPT_PLAY_FUSED), the render buffer written
         # after the 16th only — a display mode ("show every 16th pass"); it says what the state round trip costs the judged form
         for name, fm in (("H_mcm_512_1080p_bit_exact_display_every_16th_pass", 0), ("H_mcm_512_1080p_fast_math_display_every_16th_pass", 1)):
@@ -422,14 +437,18 @@ def main():
                 avg_ms = res["dt"] / args.steps * 1e3
             bps = B_ALG_MCM if args.renderer == "mcm" else 8.0
             achieved = bps * per_launch_samples / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            traffic, valu_busy = None, None
+            traffic, valu_busy, traffic_source = None, None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            classes = res.get("tile_classes")
+            classified = bool(classes and classes[1] > 0)
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    key = "%s_%d_%dx%d_n%d%s" % (args.renderer, args.volume, W, H, world, "_fast" if args.fast_math else "")
+                    key = "%s_%d_%dx%d_n%d%s%s" % (args.renderer, args.volume, W, H, world, "_fast" if args.fast_math else "", "_classes" if classified else "")
                     traffic = tj.get(key)
                     valu_busy = tj.get(key + "_valu_busy_frac")
+                    if traffic is not None:
+                        traffic_source = tj.get(key + "_source", "profiles/traffic.json: committed rocprofv3 --pmc passes of this configuration (not measured in this run)")
                 except Exception:
                     traffic = None
             stream_gbs = state["stream_gbs"]
@@ -441,6 +460,33 @@ def main():
                     world, ("gather to rank %d" % res["root"]) if res["root"] >= 0 else "all_gather")
             else:
                 par = "image rows sharded over %d GPU(s), RCCL all_gather of every %d frames (torch.distributed pipeline)" % (world, gather.F)
+            variant = "fast-math" if args.fast_math else "bit-exact"
+            own_bps = bps
+            kernels = None
+            launches_per_step = args.split_streams if split else 1
+            if args.renderer != "mcm":
+                kernel_name = "k_%s<fused>" % args.renderer
+            elif classified:
+                ntiles = classes[0] + classes[1]
+                own_bps = 8.0 + (112.0 * classes[0] + 64.0 * classes[1]) / ntiles / 8.0
+                kernel_name = ("k_mcm_integrate<fused render, %s> on the %d HIT tiles | k_mcm_miss<fused render, %s> on the %d MISS tiles "
+                               "(tile classes, DESIGN.md section 5)" % (variant, classes[0], variant, classes[1]))
+                launches_per_step = 2 if not split else max(2, args.split_streams)
+                side_ms = res["side_kernel_ms"] / res["side_launches"] if res.get("side_launches") else None
+                kernels = [{"name": "k_mcm_integrate<fused render, %s>" % variant, "tiles": classes[0], "stream": "context",
+                            "avg_ms_hip_events": event_ms, "samples_per_launch": per_launch_samples * classes[0] / ntiles},
+                           {"name": "k_mcm_miss<fused render, %s>" % variant, "tiles": classes[1], "stream": "side 0" if split else "context",
+                            "avg_ms_hip_events": side_ms, "samples_per_launch": per_launch_samples * classes[1] / ntiles}]
+            else:
+                own_bps = B_OWN_MCM
+                kernel_name = "k_mcm_integrate<fused render, %s>" % variant
+            if split:
+                duration_source = ("timed block / steps: a step is %d launches on %d HIP streams that overlap each other and the next step's, so the chip-level "
+                                   "duration of a step is the block's wall time / steps; HIP events around the context stream's launch alone read %.4f ms%s"
+                                   % (launches_per_step, args.split_streams, event_ms,
+                                      (", around the side stream's %.4f ms" % (res["side_kernel_ms"] / res["side_launches"])) if res.get("side_launches") else ""))
+            else:
+                duration_source = "HIP events around every %d-th launch on the kernel's stream" % max(args.profile_kernel, 1)
             line = {
                 "metric": "volume samples/s, MCM %d^3 @ %dx%d" % (args.volume, W, H) if args.renderer == "mcm"
                           else "volume samples/s, %s %d^3 @ %dx%d" % (args.renderer.upper(), args.volume, W, H),
@@ -468,20 +514,20 @@ def main():
                 # `frac` prices the kernel against the HBM roofline by ALGORITHMIC bytes, as the metric is defined; what actually
                 # limits it is read off the PMC passes (profiles/): VALU issue (VALUBusy) for the MCM pass, not HBM
                 "roofline": {"bound": ("valu" if (valu_busy or 0) >= 0.7 else "hbm"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "valu_busy_frac": valu_busy,
+                             "bound_source": "VALUBusy of the committed PMC passes (profiles/traffic.json): >= 0.7 reads as VALU-issue bound, the HBM roofline "
+                                             "is what `frac` prices the step against either way",
                              "peak_measured_stream_read": stream_gbs,
                              "frac_of_measured": (achieved / stream_gbs) if stream_gbs else None,
-                             "kernel": ("k_mcm_integrate<fused render, %s>" % ("fast-math" if args.fast_math else "bit-exact")) if args.renderer == "mcm" else "k_%s<fused>" % args.renderer,
+                             "kernel": kernel_name, "kernels": kernels,
                              "kernel_avg_ms": avg_ms, "launches": res["launches"],
-                             "launches_per_step": args.split_streams if split else 1,
-                             "duration_source": ("timed block / steps: the step's %d launches (tile-row ranges on %d HIP streams) overlap each other "
-                                                 "and the next step's; HIP events around the first range's launch alone read %.4f ms" % (args.split_streams, args.split_streams, event_ms)) if split
-                                                else "HIP events around every %d-th launch on the kernel's stream" % max(args.profile_kernel, 1),
+                             "launches_per_step": launches_per_step,
+                             "duration_source": duration_source,
                              "bytes_per_sample": bps,
-                             # the kernel's own photon-state layout is 56 B per pixel each way (not the reference's 64): priced by
-                             # the bytes it moves itself, 8 + 112 / steps per sample
-                             "bytes_per_sample_own_layout": (B_OWN_MCM if args.renderer == "mcm" else bps),
-                             "frac_own_layout": achieved / HBM_PEAK_GBS * ((B_OWN_MCM / B_ALG_MCM) if args.renderer == "mcm" else 1.0)},
+                             # the kernels' own photon-state layout: 56 B per pixel each way in HIT tiles, 32 B in MISS tiles (not the
+                             # reference's 64): priced by the bytes they move themselves
+                             "bytes_per_sample_own_layout": own_bps,
+                             "frac_own_layout": achieved / HBM_PEAK_GBS * (own_bps / bps)},
                 "frame_check": res["ok"],
             }
             if res.get("frame_check_kind"):
@@ -559,10 +605,27 @@ def main():
             got = r.read(N.BUFFER_MCM_RADIANCE)[y0:y1]
             if not args.fast_math:
                 return bool((got.view(np.uint32) == want.view(np.uint32)).all()), "oracle band rows %d..%d after %d passes, bit-identical" % (y0, y1, frames_done[0])
-            same_n = float((got[..., 3] == want[..., 3]).mean())
-            d = float(np.abs(got[..., :3] - want[..., :3]).mean())
-            return bool(same_n >= 0.97 and d <= 0.02), ("oracle band rows %d..%d after %d passes, fast-math tolerance: %.4f of the pixels with equal "
-                                                        "path counts, mean |d radiance| %.2e" % (y0, y1, frames_done[0], same_n, d))
+            # The fast-arithmetic variant has no bit-exact twin.  What is asserted (bounds = FAST_MATH_BOUNDS; per pixel and
+            # per channel, on the band's radiance texels after every pass played):
+            #   * pixels whose paths never meet the cube (every event completes a path: count = 8 per pass, exactly): the same count
+            #     and |d| within rounding of the running mean;
+            #   * pixels that cross the cube (the ~21 % that the figure is about): equal path counts on >= min_equal_counts of them,
+            #     mean / 99.9th percentile / maximum of the per-pixel max-channel |d| below the stated bounds
+            full = 8.0 * frames_done[0]
+            crossing = want[..., 3] < full
+            d = np.abs(got[..., :3].astype(np.float64) - want[..., :3].astype(np.float64)).max(axis=-1)
+            dc, dm = d[crossing], d[~crossing]
+            stats = {"pixels_crossing_the_cube": int(crossing.sum()), "pixels_missing_it": int((~crossing).sum()),
+                     "equal_counts_crossing": float((got[..., 3] == want[..., 3])[crossing].mean()) if crossing.any() else 1.0,
+                     "equal_counts_missing": float((got[..., 3] == want[..., 3])[~crossing].mean()) if (~crossing).any() else 1.0,
+                     "mean_abs_d_crossing": float(dc.mean()) if dc.size else 0.0, "p999_abs_d_crossing": float(np.quantile(dc, 0.999)) if dc.size else 0.0,
+                     "max_abs_d_crossing": float(dc.max()) if dc.size else 0.0, "max_abs_d_missing": float(dm.max()) if dm.size else 0.0}
+            B = FAST_MATH_BOUNDS
+            ok = (stats["equal_counts_missing"] == 1.0 and stats["max_abs_d_missing"] <= B["max_abs_d_missing"] and
+                  stats["equal_counts_crossing"] >= B["min_equal_counts_crossing"] and stats["mean_abs_d_crossing"] <= B["mean_abs_d_crossing"] and
+                  stats["p999_abs_d_crossing"] <= B["p999_abs_d_crossing"] and stats["max_abs_d_crossing"] <= B["max_abs_d_crossing"])
+            return bool(ok), {"what": "oracle band rows %d..%d after %d passes; fast-math variant against the contract oracle, per pixel, max over the "
+                                      "RGB channels of |radiance difference|" % (y0, y1, frames_done[0]), "measured": stats, "bounds": B}
 
         def measure():
             """W warm-up steps (and >= --warmup-seconds), then --repeats blocks of EXACTLY K timed steps between barriers; the median
@@ -621,6 +684,8 @@ def main():
             res["dt"] = dt
             res["blocks_ms"] = [b * 1e3 for b in blocks]
             res["kernel_ms"], res["launches"] = r.profile()           # HIP events over ALL timed blocks, on the kernel's stream
+            res["side_kernel_ms"], res["side_launches"] = r.profile_side()   # ... and around the sampled passes' launch on the first side stream
+            res["tile_classes"] = r.tile_classes()[:2] if (args.renderer == "mcm" and args.tile_classes) else None
             r.set_profiling(False)
             res["samples_local"] = r.sample_count() / max(1, args.repeats)   # per block (every block runs the same K passes)
             tt = torch.tensor([dt, float(res["samples_local"])], dtype=torch.float64, device=device)
@@ -714,20 +779,26 @@ def main():
             except Exception:                                       # reporting only
                 stream_gbs = None
         state["stream_gbs"] = stream_gbs
+        line0 = make_line(res) if rank == 0 else None
+        matrix = r._matrix()
         other = None
         if rank == 0 and world == 1 and args.other_configs and args.renderer == "mcm":
+            # the headline renderer goes first: its side streams would share hardware queues with the configurations measured next
+            if native is not None:
+                native.destroy(); native = None
+            r.destroy(); r = None
             other = other_configs(ctx, gvol, vol, args, W, H, torch)
 
     ok = res["ok"]
     if rank == 0:
-        out = make_line(res)
+        out = line0
         if world == 1 and args.cpu_baseline and args.renderer == "mcm":
             try:
-                out["cpu_baseline"] = cpu_baseline(vol, args, r._matrix(), None)
+                out["cpu_baseline"] = cpu_baseline(vol, args, matrix, None)
             except Exception as e:                                      # the baseline is reporting only
                 out["cpu_baseline"] = {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
             try:
-                out["cpu_baseline_js"] = cpu_baseline_js(vol, args, r._matrix())
+                out["cpu_baseline_js"] = cpu_baseline_js(vol, args, matrix)
             except Exception as e:
                 out["cpu_baseline_js"] = {"value": None, "unit": "volume samples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
             out["host_cores"] = len(os.sched_getaffinity(0))
@@ -739,7 +810,9 @@ def main():
         os.dup2(2, 1)
     if native is not None:
         native.destroy()
-    r.destroy(); gvol.destroy(); ctx.destroy()
+    if r is not None:
+        r.destroy()
+    gvol.destroy(); ctx.destroy()
     if use_dist:
         dist.destroy_process_group()
     watchdog.cancel()

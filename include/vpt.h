@@ -204,7 +204,7 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * redirected into caller memory (vpt_renderer_set_render_target, vpt_gather_*) passes stay on the context's stream, because the
  * caller's own work on that stream reads the frame; a frame sequence captured into a hipGraph (VPT_PLAY_GRAPH) stays on the capturing
  * stream.  Results identical. */
-#define VPT_MAX_SPLIT 6
+#define VPT_MAX_SPLIT 4
 #define VPT_OPTION_SPLIT_STREAMS 4
 /* VPT_OPTION_SPLIT_CALLER_TARGETS (default 0; MCM renderer): 1 = passes into a caller-owned render target are split as well.  The
  * caller then owes a vpt_renderer_join() before work of its own on the context's stream reads the target — e.g. once per bucket
@@ -267,6 +267,9 @@ VPT_API int vpt_renderer_clear_sample_count(vpt_renderer *r);
  * enabled = 1 times every launch, enabled = n > 1 every n-th launch (the two event packets cost ~7 us per launch). */
 VPT_API int vpt_renderer_set_profiling(vpt_renderer *r, int enabled);
 VPT_API int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t *launches);
+/* the same for the first launch the sampled passes put on a side stream (a pass split by VPT_OPTION_SPLIT_STREAMS; with tile classes in
+ * force that is the MISS-tile kernel, k_mcm_miss, while vpt_renderer_profile covers the HIT-tile kernel on the context's stream) */
+VPT_API int vpt_renderer_profile_side(vpt_renderer *r, double *total_ms, uint32_t *launches);
 
 /* ---- tone mappers (the classes of src/js/tonemappers/ and the shaders of src/glsl/tonemappers/).  One per-pixel pass:
  * RGBA16F render buffer of a renderer (AbstractToneMapper.setTexture, AbstractToneMapper.js:34-36) -> RGBA8

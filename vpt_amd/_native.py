@@ -45,7 +45,7 @@ SYMBOLS = [
     "vpt_renderer_render", "vpt_renderer_play", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
     "vpt_renderer_set_render_target", "vpt_renderer_join", "vpt_renderer_read_frame_slot", "vpt_renderer_frame_ring_device",
     "vpt_renderer_set_option", "vpt_renderer_set_lao_params", "vpt_renderer_set_occlusion_samples", "vpt_renderer_integrate_slices", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
-    "vpt_renderer_set_profiling", "vpt_renderer_profile", "vpt_renderer_tile_classes", "vpt_classify_tiles",
+    "vpt_renderer_set_profiling", "vpt_renderer_profile", "vpt_renderer_profile_side", "vpt_renderer_tile_classes", "vpt_classify_tiles",
     "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play", "vpt_gather_set_root",
     "vpt_gather_synchronize",
     "vpt_gather_read_frame",
@@ -159,6 +159,7 @@ def lib():
         "vpt_renderer_tile_classes": [P, C.POINTER(I), C.POINTER(I), C.POINTER(C.c_uint64)],
         "vpt_classify_tiles": [I, I, I, I, I, P, P, SZ, C.POINTER(I), C.POINTER(I)],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],
+        "vpt_renderer_profile_side": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],
         "vpt_probe_math": [P, I, P, P, SZ], "vpt_probe_sample": [P, P, P, SZ], "vpt_probe_stream_read": [P, SZ, I, P], "vpt_probe_assemble_rows": [P, P, I, I, I, I, I, P],
         "vpt_tonemapper_create": [P, I, I, I, P], "vpt_tonemapper_destroy": [P], "vpt_tonemapper_resize": [P, I, I],
         "vpt_tonemapper_set_source": [P, P], "vpt_tonemapper_set_source_image": [P, P, I, I],

@@ -409,7 +409,9 @@ VPT_DEV uint32_t boundary_cell(const DevVolume &v, f3 p, float &out_fa, float &o
     // plane 0), so the clamped axis needs no filter cell at all.  The photons of a wave mostly leave through the same face
     // (8 x 8 neighbouring pixels): the three wave-uniform cases are separate straight-line paths without per-lane selects,
     // and only a wave whose lanes disagree takes the generic one.
-    const unsigned long long act = __ballot(1), bx = __ballot(ox), by = __ballot(oy);
+    // (__builtin_amdgcn_ballot_w64 on the bools themselves: __ballot() takes an int, and the compiler then materialises each predicate
+    // as 0 / 1 in a VGPR and compares it again — four VALU instructions per sample for nothing)
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true), bx = __builtin_amdgcn_ballot_w64(ox), by = __builtin_amdgcn_ballot_w64(oy);
     uint32_t a, b, idx; float fa, fb;
     if (bx == act) {
         linear_cell(p.y, fny, hy, a, fa); linear_cell(p.z, fnz, hz, b, fb);
@@ -460,7 +462,9 @@ VPT_DEV f2 sample_volume_rg(const DevVolume &v, const LdsTables &t, f3 p) {
         linear_cell(p.y, v.fny, v.hy, y, fy);
         linear_cell(p.z, v.fnz, v.hz, z, fz);
         const float *b = (const float *)cell_addr<WIDE>(v, t, x, y, z);
-        float2 r00 = *(const float2 *)b, r10 = *(const float2 *)(b + 5), r01 = *(const float2 *)(b + 25), r11 = *(const float2 *)(b + 30);
+        // (the taps are dword-aligned, not 8-byte aligned: loaded through memcpy — still one global_load_dwordx2 each)
+        float2 r00, r10, r01, r11;
+        __builtin_memcpy(&r00, b, 8); __builtin_memcpy(&r10, b + 5, 8); __builtin_memcpy(&r01, b + 25, 8); __builtin_memcpy(&r11, b + 30, 8);
         float c00 = lerpf(r00.x, r00.y, fx), c10 = lerpf(r10.x, r10.y, fx);
         float c01 = lerpf(r01.x, r01.y, fx), c11 = lerpf(r11.x, r11.y, fx);
         return f2{ lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz), 0.0f };

@@ -132,6 +132,8 @@ struct vpt_renderer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<uint32_t> event_launches;   // kernel launches covered by each event pair (1, or the frames of a graph replay)
     size_t events_used;
+    // the same around the first launch a pass puts on a SIDE stream (tile classes: the MISS-tile kernel), for the passes `events` samples
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> side_events; size_t side_events_used; bool timed_now;
 };
 
 static const size_t COUNTER_BYTES = (size_t)VPT_COUNTER_SLOTS * VPT_COUNTER_STRIDE * sizeof(unsigned long long);
@@ -488,6 +490,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame = r->acc = nullptr; r->render = nullptr; r->scratch = nullptr; r->scratch_bytes = 0;
     for (int i = 0; i < 4; i++) r->st[i] = nullptr;
     r->samples = nullptr; r->samples_host = 0; r->profiling = false; r->events_used = 0; r->profile_every = 1; r->profile_seq = 0;
+    r->side_events_used = 0; r->timed_now = false;
     r->ndc_x = r->ndc_y = nullptr;
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
@@ -535,6 +538,7 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (r->ev_fork) hipEventDestroy(r->ev_fork);
     if (r->play_graph) play_graph_free(r->play_graph);
     for (auto &ev : r->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    for (auto &ev : r->side_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete r;
     return VPT_OK;
 }
@@ -915,21 +919,16 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     if (check) km = fast ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, true> : (PassKernel)k_mcm_miss<FUSE, 0, true>;
     else km = fast ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, false> : (PassKernel)k_mcm_miss<FUSE, 0, false>;
     const size_t lds_hit = lds_bytes(r), lds_miss = (size_t)r->tf_w * 2 * sizeof(float4);
-    if (lds_hit > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds_hit);
-    if (lds_hit > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hit));
     int k = 1;
     if (r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers)) k = r->split;
     if (r->side_busy && r->last_layout != 1) VPT_TRY(join_side(r));      // the tile -> stream map changes: order the streams once
     r->last_layout = 1;
     struct Part { PassKernel kernel; const uint32_t *list; int n; size_t lds; };
     Part parts[VPT_MAX_SPLIT]; int np = 0;
-    int hit_parts = r->cls.n_hit > 0 ? 1 : 0;
-    int miss_parts = std::max(1, k - hit_parts);
-    {   // EXPERIMENT: VPT_EXP_LAYOUT="H,M" = H streams of HIT tiles, M streams of MISS tiles (H + M <= the split option)
-        static int eh = -1, em = -1;
-        if (eh < 0) { eh = 0; em = 0; const char *e = getenv("VPT_EXP_LAYOUT"); if (e) sscanf(e, "%d,%d", &eh, &em); }
-        if (eh > 0 && em > 0 && eh + em <= k) { hit_parts = r->cls.n_hit > 0 ? eh : 0; miss_parts = em; }
-    }
+    // (measured, 1080p headline frame, us per frame: HIT | MISS on two streams 81.0; HIT | MISS/2 | MISS/2 82.3-83.0; HIT/2 | HIT/2 | MISS
+    // 82.7-84.1; four streams 93; one stream, HIT then MISS: 102 — tools/r03_exp2.sh)
+    const int hit_parts = r->cls.n_hit > 0 ? 1 : 0;
+    const int miss_parts = std::max(1, k - hit_parts);
     for (int i = 0; i < hit_parts; i++) {
         const int h0 = (int)((long long)r->cls.n_hit * i / hit_parts), h1 = (int)((long long)r->cls.n_hit * (i + 1) / hit_parts);
         if (h1 > h0) parts[np++] = Part{ kh, r->cls.list + h0, h1 - h0, lds_hit };
@@ -956,7 +955,20 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
         for (int i = 0; i < np; i++) {
             PassArgs part = a;
             part.pm.tile_list = parts[i].list; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
+            // profiling: the context's stream is bracketed by the caller (Timed); the first side launch gets a pair of its own
+            hipEvent_t e1 = nullptr;
+            if (i == 1 && r->timed_now) {
+                if (r->side_events_used == r->side_events.size()) {
+                    hipEvent_t a0, a1;
+                    if (hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess) r->side_events.push_back({ a0, a1 });
+                }
+                if (r->side_events_used < r->side_events.size()) {
+                    hipEventRecord(r->side_events[r->side_events_used].first, r->side[0]);
+                    e1 = r->side_events[r->side_events_used++].second;
+                }
+            }
             launch_range(parts[i].kernel, r, dim3((unsigned)parts[i].n), dim3(VPT_BLOCK), parts[i].lds, i == 0 ? r->ctx->stream : r->side[i - 1], part, i);
+            if (e1) hipEventRecord(e1, r->side[0]);
         }
         r->side_busy = true; r->last_ranges = std::max(np, 1);
     }
@@ -1058,8 +1070,9 @@ struct Timed {   // HIP events around the dominant kernel (or around one graph r
         idx = r->events_used++;
         r->event_launches[idx] = launches;
         hipEventRecord(r->events[idx].first, r->ctx->stream);
+        r->timed_now = true;
     }
-    ~Timed() { if (on) hipEventRecord(r->events[idx].second, r->ctx->stream); }
+    ~Timed() { if (on) { hipEventRecord(r->events[idx].second, r->ctx->stream); r->timed_now = false; } }
 };
 
 #define LAUNCH(kernel, r, a, lds) hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), (lds), (r)->ctx->stream, (a))
@@ -1235,6 +1248,7 @@ static int play_upload_table(vpt_renderer *r, const float *vars, int count, Pass
         memcpy(r->frame_staging, src + first, (size_t)(count - first) * sizeof(FrameVar));
         HIP_TRY(hipMemcpyAsync(r->frame_table, r->frame_staging, (size_t)(count - first) * sizeof(FrameVar), hipMemcpyHostToDevice, c->stream));
     }
+    a->frame_base = (uint32_t)r->frames_played;       // == the device counter when the sequence starts (both advance by `count` per sequence)
     r->frames_played += (uint64_t)count;
     a->frame_table = r->frame_table;
     a->frame_counter = r->frame_counter;
@@ -1558,8 +1572,9 @@ extern "C" int vpt_renderer_set_lao_params(vpt_renderer *r, const struct vpt_lao
 extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
     switch (option) {
-        case VPT_OPTION_MCS_PERSISTENT: r->mcs_persistent = value != 0; return VPT_OK;
-        case VPT_OPTION_MCM_PERSISTENT: r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
+        // (the persistent kernels walk every tile from the context's stream: ranges of earlier split passes must be in first)
+        case VPT_OPTION_MCS_PERSISTENT: VPT_TRY(join_side(r)); r->mcs_persistent = value != 0; return VPT_OK;
+        case VPT_OPTION_MCM_PERSISTENT: VPT_TRY(join_side(r)); r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
         case VPT_OPTION_BOUNDARY_ATLAS: r->boundary_atlas = value != 0; return VPT_OK;
         case VPT_OPTION_SPLIT_STREAMS:
             if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_SPLIT_STREAMS: the DOS renderer's slices depend on each other across pixels");
@@ -1568,12 +1583,7 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
             HIP_TRY(hipSetDevice(r->ctx->device));
             if (value >= 2 && !r->ev_fork) HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
             for (int i = 0; i + 1 < value; i++) if (!r->side[i]) {
-#ifdef VPT_EXP_SIDE_LOW_PRIO
-                { int least = 0, greatest = 0; HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                  HIP_TRY(hipStreamCreateWithPriority(&r->side[i], hipStreamNonBlocking, least)); }
-#else
                 HIP_TRY(hipStreamCreateWithFlags(&r->side[i], hipStreamNonBlocking));
-#endif
                 HIP_TRY(hipEventCreateWithFlags(&r->ev_join[i], hipEventDisableTiming));
             }
             r->split = value; return VPT_OK;
@@ -1637,7 +1647,21 @@ extern "C" int vpt_renderer_set_profiling(vpt_renderer *r, int enabled) {
     r->profiling = enabled != 0;
     r->profile_every = enabled > 1 ? enabled : 1;   // enabled = n > 1: every n-th launch only (events cost ~7 us per launch)
     r->profile_seq = 0;
-    r->events_used = 0;
+    r->events_used = 0; r->side_events_used = 0;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_profile_side(vpt_renderer *r, double *total_ms, uint32_t *launches) {
+    if (!r || !total_ms || !launches) return fail(VPT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    VPT_TRY(join_side(r));
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    double sum = 0.0;
+    for (size_t i = 0; i < r->side_events_used; i++) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, r->side_events[i].first, r->side_events[i].second));
+        sum += (double)ms;
+    }
+    *total_ms = sum; *launches = (uint32_t)r->side_events_used;
     return VPT_OK;
 }
 extern "C" int vpt_renderer_profile(vpt_renderer *r, double *total_ms, uint32_t *launches) {

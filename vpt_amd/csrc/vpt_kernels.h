@@ -117,6 +117,8 @@ struct PassArgs {
     const struct FrameVar *frame_table;     // ring of frame_mask + 1 entries
     const uint32_t *frame_counter;          // frames played so far (monotonic); entry = counter & frame_mask
     uint32_t frame_mask;
+    uint32_t frame_base;                    // fused sequences (multi_passes > 1): index of the sequence's first frame, BY VALUE — a pass split over
+                                            // streams must not read the device counter, which the context's stream advances behind its own range only
 };
 struct FrameVar { float seed, offset, mix, pad0; float lx, ly, lz, pad1; };   // the uniforms that change per frame
 VPT_DEV void apply_frame_table(PassArgs &a) {
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mip(PassArgs a) {
         if (MODE == 0) {
             frame[p.k] = (uint8_t)mip_pixel<V>(a, t, p, ns);
         } else {
-            uint32_t m = acc[p.k], base = a.multi_passes > 1u ? *a.frame_counter : 0u;
+            uint32_t m = acc[p.k], base = a.frame_base;
             for (uint32_t f = 0, np = multi_pass_count(a); f < np; f++) {
                 multi_pass_select(a, base, f);
                 m = max(m, mip_pixel<V>(a, t, p, ns));
@@ -358,7 +360,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_eam(PassArgs a) {
         if (MODE == 0) {
             frame[p.k] = eam_pixel<V>(a, t, p, ns);
         } else {
-            uint32_t m = acc[p.k], base = a.multi_passes > 1u ? *a.frame_counter : 0u;
+            uint32_t m = acc[p.k], base = a.frame_base;
             for (uint32_t f = 0, np = multi_pass_count(a); f < np; f++) {
                 multi_pass_select(a, base, f);
                 m = eam_mix(m, eam_pixel<V>(a, t, p, ns), a.mix);
@@ -464,7 +466,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
             frame[p.k] = mcs_pixel<V>(a, t, p, ns);
         } else {
             float4 m = acc[p.k];
-            uint32_t base = a.multi_passes > 1u ? *a.frame_counter : 0u;
+            uint32_t base = a.frame_base;
             for (uint32_t f = 0, np = multi_pass_count(a); f < np; f++) {
                 multi_pass_select(a, base, f);
                 m = mcs_mix(m, mcs_pixel<V>(a, t, p, ns), a.mix);
@@ -972,9 +974,6 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
 template <bool FUSE_RENDER, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(VPT_MCM_WAVES, 8))) k_mcm_integrate(PassArgs a) {
-#ifdef VPT_EXP_HIT_PRIO
-    if (a.pm.tile_list) __builtin_amdgcn_s_setprio(VPT_EXP_HIT_PRIO);
-#endif
     apply_frame_table(a);
     // the photon state (4 x dwordx4 per lane, one contiguous 1 KiB segment per wave and array) does not depend on the LDS
     // image: its loads are issued first, so they fly while the workgroup stages the tables and hashes its seed
@@ -1056,14 +1055,8 @@ VPT_DEV void mcm_events_miss_fast(const PassArgs &a, const float4 *tf, const Fas
         fast_path_end<true>(a, c, state, ph, f3{ env.x, env.y, env.z }, px, py);
     }
 }
-#ifndef VPT_MISS_WAVES
-#define VPT_MISS_WAVES 8
-#endif
 template <bool FUSE_RENDER, int V, bool CHECK>
-__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(VPT_MISS_WAVES, 8))) k_mcm_miss(PassArgs a) {
-#ifdef VPT_EXP_MISS_PRIO
-    __builtin_amdgcn_s_setprio(VPT_EXP_MISS_PRIO);
-#endif
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_mcm_miss(PassArgs a) {
     apply_frame_table(a);
     Pix p = map_pixel(a.pm);
     float4 s1 = make_float4(0.0f, 0.0f, 1.0f, 0.0f), s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1125,7 +1118,7 @@ VPT_DEV void mcm_multi_body(PassArgs &a, uint32_t npasses, uint2 *ring, uint32_t
     if (!p.valid) return;
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     Photon ph = photon_unpack(photon_load(a, p.k));
-    uint32_t base = *a.frame_counter;
+    uint32_t base = a.frame_base;
     for (uint32_t f = 0; f < npasses; f++) {
         a.seed = a.frame_table[(base + f) & a.frame_mask].seed;
         if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);

@@ -72,7 +72,7 @@ VPT_DEV uint2 iso_shade(const PassArgs &a, const LdsTables &t, uint2 closest, ui
 // MODE 0: _generateFrame only.  MODE 1: the whole render(): generate, integrate, renderFrame in one pass.
 template <int MODE, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_iso(PassArgs a) {
-    if (a.multi_passes > 1u) multi_pass_select(a, *a.frame_counter, 0); else apply_frame_table(a);
+    if (a.multi_passes > 1u) multi_pass_select(a, a.frame_base, 0); else apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
             // VPT_PLAY_FUSED: the remaining passes of the sequence; every pass but the last one only leaves its 7 shading
             // samples in the counter (its render buffer is overwritten by the next pass anyway)
             if (a.multi_passes > 1u) {
-                uint32_t base = *a.frame_counter;
+                uint32_t base = a.frame_base;
                 for (uint32_t f = 1; f < a.multi_passes; f++) {
                     if (half_hi(m.y) > 0.0f) ns += 7;
                     multi_pass_select(a, base, f);
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_depth(PassArgs a) {
             frame[p.k] = depth_pixel<V>(a, t, p, ns);
         } else {
             float m = acc[p.k];
-            uint32_t base = a.multi_passes > 1u ? *a.frame_counter : 0u;
+            uint32_t base = a.frame_base;
             for (uint32_t f = 0, np = multi_pass_count(a); f < np; f++) {
                 multi_pass_select(a, base, f);
                 m = mixf(m, depth_pixel<V>(a, t, p, ns), a.mix);     // DepthRenderer.glsl:114-118

@@ -255,6 +255,12 @@ class AbstractRenderer(PropertyBag):
         N.check(N.lib().vpt_renderer_profile(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_side(self):
+        """(total ms, launches) of the sampled passes' first side-stream launch (tile classes: the MISS-tile kernel)"""
+        ms, n = C.c_double(0), C.c_uint32(0)
+        N.check(N.lib().vpt_renderer_profile_side(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def render_buffer_device(self):
         p, n = C.c_void_p(), C.c_size_t(0)
         N.check(N.lib().vpt_renderer_render_buffer_device(self._h, C.byref(p), C.byref(n)))
