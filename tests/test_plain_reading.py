@@ -214,3 +214,100 @@ def test_mcm_converged_images_agree(oracle):
     ns_c = oa.state[3].reshape(H, W, 4)[..., 3]
     assert (ns_c == sp.samples).mean() >= 0.97
     assert abs(float(ns_c.sum()) - float(sp.samples.sum())) <= 2e-3 * float(ns_c.sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The BENCHMARK regime (BASELINE.json's headline configuration, scaled down in pixels and voxels only): aspect 16:9, the
+# reference's default camera, its default 2x1 transfer function, 1x1 white environment, extinction 1, anisotropy 0, 8 bounces,
+# 8 steps per pass.  What is special about it: ~80 % of the pixels never meet the cube (their photon is parked beside the cube at from + tnear * dir
+# and leaves again at every event), and of the events of the pixels that do cross it most end outside.
+# ---------------------------------------------------------------------------------------------------------------------------
+BW, BH, BN = 128, 72, 32
+
+
+def _bench_scene():
+    return sphere_volume(BN, noise=48.0), default_matrix(BW / BH)
+
+
+def _bench_contract(O, passes, seed0=1):
+    vol, m = _bench_scene()
+    o = O.OracleRenderer("mcm", O.OracleScene(vol, "linear"), BW, BH)
+    o.reset(O.make_frame(BW, BH, m, seed=seed_k(seed0)))
+    for k in range(1, passes + 1):
+        o.integrate(O.make_frame(BW, BH, m, seed=seed_k(seed0 + k), extinction=1.0, anisotropy=0.0, max_bounces=8, mcm_steps=8))
+    return o
+
+
+def _bench_plain(passes, seed0=1, trace=None, steps=8):
+    vol, m = _bench_scene()
+    ps = P.Scene(vol, "linear")
+    st = P.mcm_reset(BW, BH, m, seed_k(seed0))
+    for k in range(1, passes + 1):
+        P.mcm_integrate(ps, st, m, seed_k(seed0 + k), 1.0, 0.0, 8, steps, trace=trace)
+    return st
+
+
+def test_mcm_benchmark_regime_reset_first_event_and_parked_photons(oracle):
+    O = oracle
+    o0 = _bench_contract(O, 0)
+    st0 = _bench_plain(0)
+    pos = o0.state[0].reshape(BH, BW, 4); dr = o0.state[1].reshape(BH, BW, 4)
+    onc = np.ones((BH, BW), bool)
+    for k in range(3):
+        onc &= (st0.pos[k] >= -1e-3) & (st0.pos[k] <= 1.001)
+    assert 0.15 < onc.mean() < 0.30                        # the cube's silhouette: about a fifth of a 16:9 image
+    far = ~onc
+    nv = np.sqrt(sum(st0.pos[k].astype(np.float64) ** 2 for k in range(3)))
+    assert nv[far].max() > 2.0                             # photons parked beside the cube on rays that run past it
+    for k in range(3):
+        assert np.abs(pos[..., k] - st0.pos[k])[onc].max() <= 2e-5
+        assert np.allclose(dr[..., k], st0.dir[k], atol=2e-6, rtol=0)
+    dv = np.sqrt(sum((pos[..., k].astype(np.float64) - st0.pos[k]) ** 2 for k in range(3)))
+    assert (dv <= 2e-4 + 2e-3 * nv).mean() >= 0.999        # parked positions: relative to their length (tnear is ill-conditioned there)
+    # one pass of ONE event: branches
+    vol, m = _bench_scene()
+    o1 = O.OracleRenderer("mcm", O.OracleScene(vol, "linear"), BW, BH)
+    o1.reset(O.make_frame(BW, BH, m, seed=seed_k(1)))
+    o1.integrate(O.make_frame(BW, BH, m, seed=seed_k(2), extinction=1.0, anisotropy=0.0, max_bounces=8, mcm_steps=1))
+    trace = []
+    st1 = _bench_plain(1, trace=trace, steps=1)
+    fin_c = o1.state[3].reshape(BH, BW, 4)[..., 3] > 0
+    sct_c = ~fin_c & (o1.state[1].reshape(BH, BW, 4)[..., 3] > 0)
+    code = trace[0]
+    agree = (fin_c == (code >= 2)) & (sct_c == (code == 1))
+    assert agree.mean() >= 0.999, float(agree.mean())
+    assert (code == 3)[far].all() and fin_c[far].all()     # every event of a pixel that misses the cube ends out of bounds
+    assert (code == 3).mean() > 0.85                       # ... and so do most events overall
+    rad = o1.state[3].reshape(BH, BW, 4)
+    for k in range(3):
+        assert np.abs(rad[..., k] - st1.rad[k])[agree].max() <= 1e-5
+        # white 1x1 environment, transmittance 1: exactly 1 (the plain reading blends the one texel with itself: 1 - 2^-24 at worst)
+        assert (rad[..., k][far] == 1.0).all() and np.abs(st1.rad[k][far] - 1.0).max() <= 2e-7
+
+
+def test_mcm_benchmark_regime_converged(oracle):
+    O = oracle
+    passes = 64
+    oa = _bench_contract(O, passes)
+    ob = _bench_contract(O, 16, seed0=7000)
+    sp = _bench_plain(passes)
+    ca = oa.state[3].reshape(BH, BW, 4); cb = ob.state[3].reshape(BH, BW, 4)
+    pa = np.stack(sp.rad, axis=-1)
+    full = 8 * passes
+    crossing = ca[..., 3] < full
+    assert 0.15 < crossing.mean() < 0.35
+    # pixels that miss the cube: one completed path per event, radiance exactly the environment's
+    assert (sp.samples[~crossing] == full).all() and (ca[..., 3][~crossing] == full).all()
+    assert np.abs(pa[~crossing] - 1.0).max() <= 2e-7 and (ca[..., :3][~crossing] == 1.0).all()
+    # pixels that cross it
+    same_n = (ca[..., 3] == sp.samples)[crossing].mean()
+    assert same_n >= 0.97, float(same_n)
+    d = np.abs(ca[..., :3] - pa).max(axis=-1)[crossing]
+    noise = np.abs(ca[..., :3] - cb[..., :3]).max(axis=-1)[crossing].mean()
+    assert noise > 0 and d.mean() <= 0.25 * noise, (float(d.mean()), float(noise))
+    se = (ca[..., :3] - cb[..., :3])[crossing].std(axis=0) / np.sqrt(crossing.sum())
+    dm = np.abs(ca[..., :3][crossing].mean(axis=0) - pa[crossing].mean(axis=0))
+    assert (dm <= K_SIGMA * se + 1e-6).all(), (dm, se)
+    # where the path counts agree the two restatements differ by rounding only
+    eq = (ca[..., 3] == sp.samples) & crossing
+    assert np.quantile(np.abs(ca[..., :3] - pa).max(axis=-1)[eq], 0.99) <= 1e-5
