@@ -49,10 +49,10 @@ r = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, default_camera(W / H), Non
 if args.renderer == "mcm":
     r.set_option(N.OPTION_FAST_MATH, args.fast)
     r.steps = args.steps
-    try:
-        r.set_option(N.OPTION_TILE_CLASSES, args.classes)
-    except vpt_amd.VptError:
-        pass                                          # a build from before the option existed
+try:
+    r.set_option(N.OPTION_TILE_CLASSES, args.classes)
+except vpt_amd.VptError:
+    pass                                              # a build from before the option existed
 if args.split > 1:
     r.set_option(N.OPTION_SPLIT_STREAMS, args.split)
 r.reset()

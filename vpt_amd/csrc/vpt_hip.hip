@@ -80,6 +80,12 @@ struct TileClasses {
     int n_hit, n_miss;
     bool stale, stale_fast;        // MISS tiles' position / transmittance arrays are behind; the pass that left them ran the fast variant
     unsigned long long *violations;
+    // the accumulating ray marchers (MIP, EAM, ISO, MCS, Depth): see marcher_track
+    uint64_t passes, fused_passes; // generate / fused passes since the reset
+    bool poisoned;                 // a pass since the reset used another matrix than the first: nothing can be skipped until the next reset
+    bool first_mix_one;            // the first pass since the reset was a fused pass with mix == 1 (MCS, Depth: accumulator = frame exactly)
+    bool list_now;                 // the launch being enqueued covers the HIT tiles only
+    bool reset_seen;               // vpt_renderer_reset has run on the present buffers (zero-filled buffers are not a reset)
 };
 struct vpt_renderer {
     vpt_context *ctx;
@@ -92,7 +98,7 @@ struct vpt_renderer {
     uint64_t valid_pixels;  // owned pixels inside the image
     vpt_volume *vol;
     float4 *tf; int tf_w, tf_h;
-    float4 *env; int env_w, env_h; float4 env_const;
+    float4 *env; int env_w, env_h; float4 env_const; bool env_opaque;   // env_opaque: every texel's alpha is 255
     void *frame, *acc;
     float4 *st[4];
     uint2 *render;
@@ -398,6 +404,7 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     renderer_free_buffers(r);
     r->cls.valid = false; r->cls.stale = false;            // new geometry, zeroed state: classes come back with the next reset
+    r->cls.passes = 0; r->cls.fused_passes = 0; r->cls.reset_seen = false;   // (zeroed buffers are not a reset: nothing is skipped before one)
     r->dos_cur = 0; r->dos_rect_valid = false;
     int nblocks = (r->H + r->R - 1) / r->R;                 // row blocks in the image
     int mine = (nblocks - r->g + r->G - 1) / r->G;          // blocks b with b % G == g
@@ -475,6 +482,9 @@ extern "C" int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba
                            (float)rgba[4 * i + 2] / 255.0f, (float)rgba[4 * i + 3] / 255.0f);
     VPT_TRY(upload_table(r->ctx, &r->env, t));
     r->env_w = w; r->env_h = h; r->env_const = t[0];
+    r->env_opaque = true;
+    for (size_t i = 0; i < t.size(); i++) if (rgba[4 * i + 3] != 255) { r->env_opaque = false; break; }
+    r->cls.poisoned = true;                                  // (MCS: the fixed points of the ray-missing pixels move with the environment)
     return VPT_OK;
 }
 extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int height, vpt_renderer **out) {
@@ -785,12 +795,34 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     const bool wave = wave_blocks(r);
     const unsigned xmul = wave ? 4u : 1u;
     const dim3 block(wave ? 64u : (unsigned)VPT_BLOCK);
+    const bool split = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers);
+    // (a frame rendered into caller memory — vpt_renderer_set_render_target — is consumed by work the caller enqueues on the
+    // context's stream right behind it: such passes stay on that stream unless the caller has taken the join upon itself
+    // (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join).  The gather pipeline waits for every range itself.)
+    if (r->cls.list_now) {
+        // the HIT tiles only (marcher_track): K equal parts of the list on the K streams
+        if (r->side_busy && r->last_layout != 1) VPT_TRY(join_side(r));
+        r->last_layout = 1;
+        const int k = split ? std::min(r->split, r->cls.n_hit) : 1;
+        if (k >= 2 && r->main_dirty) {
+            HIP_TRY(hipEventRecord(r->ev_fork, r->ctx->stream));
+            for (int i = 0; i + 1 < r->split; i++) HIP_TRY(hipStreamWaitEvent(r->side[i], r->ev_fork, 0));
+            r->main_dirty = false;
+        }
+        for (int i = 0; i < k; i++) {
+            const int h0 = (int)((long long)r->cls.n_hit * i / k), h1 = (int)((long long)r->cls.n_hit * (i + 1) / k);
+            PassArgs part = a;
+            part.pm.tile_list = r->cls.list + h0; part.pm.list_n = h1 - h0;
+            const unsigned blocks = wave ? (unsigned)((h1 - h0 + 7) / 8) * 32u : (unsigned)(h1 - h0);
+            launch_range(kernel, r, dim3(blocks), block, lds, i == 0 ? r->ctx->stream : r->side[i - 1], part, i);
+        }
+        if (k >= 2) r->side_busy = true;
+        r->last_ranges = k;
+        return VPT_OK;
+    }
     if (r->side_busy && r->last_layout != 0) VPT_TRY(join_side(r));     // the previous pass dealt tile LISTS to the streams
     r->last_layout = 0;
-    if (r->split >= 2 && !r->no_split && r->tiles_y >= r->split && (!r->target_is_callers || r->split_callers)) {
-        // (a frame rendered into caller memory — vpt_renderer_set_render_target — is consumed by work the caller enqueues on the
-        // context's stream right behind it: such passes stay on that stream unless the caller has taken the join upon itself
-        // (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join).  The gather pipeline waits for every range itself.)
+    if (split && r->tiles_y >= r->split) {
         dim3 g = tile_grid(r);
         const unsigned k = (unsigned)r->split;
         if (r->main_dirty) {      // whatever the context's stream did to the renderer's buffers since the last join comes first
@@ -867,7 +899,7 @@ static int mcm_materialize(vpt_renderer *r) {
     PassArgs a;
     VPT_TRY(make_args(r, nullptr, false, &a));
     memcpy(a.mvp_inv.m, r->cls.mvp, sizeof(r->cls.mvp));
-    a.pm.tile_list = r->cls.list + r->cls.n_hit;
+    a.pm.tile_list = r->cls.list + r->cls.n_hit; a.pm.list_n = r->cls.n_miss;
     if (r->cls.n_miss > 0) {
         if (r->cls.stale_fast) hipLaunchKernelGGL(k_mcm_materialize<true>, dim3((unsigned)r->cls.n_miss), dim3(VPT_BLOCK), 0, r->ctx->stream, a);
         else hipLaunchKernelGGL(k_mcm_materialize<false>, dim3((unsigned)r->cls.n_miss), dim3(VPT_BLOCK), 0, r->ctx->stream, a);
@@ -876,18 +908,18 @@ static int mcm_materialize(vpt_renderer *r) {
     r->cls.stale = false;
     return VPT_OK;
 }
-// a reset with matrix `mvp_inverse` has just been enqueued: classify the tiles for it (see classify_tiles)
-static int mcm_classify(vpt_renderer *r, const vpt_uniforms *u) {
-    r->cls.valid = false; r->cls.stale = false;               // the reset rewrote every array
-    if (!r->cls.enabled || u->blur != 0.0f) return VPT_OK;
+// classifies the tiles for `mvp_inverse` (see classify_tiles) and puts the lists on the device: HIT tiles first, then MISS tiles
+static int classes_build(vpt_renderer *r, const float *mvp_inverse) {
+    r->cls.valid = false;
     std::vector<uint8_t> cls; int tx, ty;
-    classify_tiles(r->W, r->H, r->local_h, r->G, r->g, r->R, u->mvp_inverse, cls, &tx, &ty);
+    classify_tiles(r->W, r->H, r->local_h, r->G, r->g, r->R, mvp_inverse, cls, &tx, &ty);
     if (tx != r->tiles_x || ty != r->tiles_y || tx > 0xffff || ty > 0xffff) return VPT_OK;
     std::vector<uint32_t> list(cls.size());
     int nh = 0, nm = 0;
     for (int pass = 0; pass < 2; pass++)
         for (int y = 0; y < ty; y++) for (int x = 0; x < tx; x++)
             if ((int)cls[(size_t)y * tx + x] == pass) { list[(size_t)nh + nm] = (uint32_t)x | ((uint32_t)y << 16); (pass ? nm : nh)++; }
+    VPT_TRY(join_side(r));                                      // passes in flight read the old lists
     if (r->cls.capacity < (int)list.size()) {
         HIP_TRY(hipStreamSynchronize(r->ctx->stream));
         if (r->cls.list) { HIP_TRY(hipFree(r->cls.list)); r->cls.list = nullptr; }
@@ -898,13 +930,52 @@ static int mcm_classify(vpt_renderer *r, const vpt_uniforms *u) {
         HIP_TRY(hipMalloc(&r->cls.violations, sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(r->cls.violations, 0, sizeof(unsigned long long), r->ctx->stream));
     }
-    // (the reset joined the side streams; the lists travel on the context's stream, behind the passes that read the old ones)
+    // (the lists travel on the context's stream, behind the passes that read the old ones)
     HIP_TRY(hipMemcpyAsync(r->cls.list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, r->ctx->stream));
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));              // `list` is pageable host memory about to go out of scope
     r->main_dirty = true;
     r->cls.n_hit = nh; r->cls.n_miss = nm;
-    memcpy(r->cls.mvp, u->mvp_inverse, sizeof(r->cls.mvp));
+    memcpy(r->cls.mvp, mvp_inverse, sizeof(r->cls.mvp));
     r->cls.valid = true;
+    return VPT_OK;
+}
+// an MCM reset with matrix u->mvp_inverse has just been enqueued
+static int mcm_classify(vpt_renderer *r, const vpt_uniforms *u) {
+    r->cls.valid = false; r->cls.stale = false;               // the reset rewrote every array
+    if (!r->cls.enabled || u->blur != 0.0f) return VPT_OK;
+    return classes_build(r, u->mvp_inverse);
+}
+// The accumulating ray marchers (MIP, EAM, ISO; MCS and Depth under a condition).  A pixel whose ray misses the cube contributes a
+// constant frame value — MIP 0 (MIPRenderer.glsl:57-59), EAM (0,0,0,1) (EAMRenderer.glsl:58-60), ISO "no hit" (ISORenderer.glsl:58-61),
+// Depth -1, MCS the environment along the ray (MCSRenderer.glsl:113-116) — and its accumulator sits at a fixed point of the
+// integrate pass from the reset on (MIP: max(acc, 0) = acc; EAM: (0,0,0,1) re-quantises to itself for any mix; ISO: "no hit" never
+// replaces anything) or from the first pass on, if that pass had mix == 1 (MCS: acc = env, then env + (env - env) * m = env; Depth:
+// acc = -1, then -(m + fl(1 - m)) = -1 for every m in [0, 1]).  So once one whole fused pass has run since the reset, and as long as
+// every pass since the reset used ONE matrix, the tiles none of whose rays meet the cube (classify_tiles — the same conservative
+// MISS class as MCM's) hold final values in accumulator and render buffer, and a fused pass needs to launch the HIT tiles only.
+// Called for every generate / fused pass; sets r->cls.list_now for the launch that follows.
+static int marcher_track(vpt_renderer *r, const PassArgs &a, bool fused, float first_mix) {
+    // (MCS: the alpha channel's first step is fl(fl(e - 1) + 1) from the reset's 1, which is e itself only for e = 1: opaque environments)
+    TileClasses &c = r->cls;
+    c.list_now = false;
+    const int k = r->kind;
+    if (k != VPT_RENDERER_MIP && k != VPT_RENDERER_EAM && k != VPT_RENDERER_ISO && k != VPT_RENDERER_MCS && k != VPT_RENDERER_DEPTH) return VPT_OK;
+    if (c.passes == 0) {
+        memcpy(c.mvp, a.mvp_inv.m, sizeof(c.mvp));
+        c.valid = false; c.poisoned = false;
+        c.first_mix_one = fused && first_mix == 1.0f;
+    } else if (memcmp(c.mvp, a.mvp_inv.m, sizeof(c.mvp)) != 0) {
+        c.poisoned = true;
+    }
+    c.passes++;
+    if (fused && c.enabled && !c.poisoned && !r->no_split /* not while a graph is being captured: its grid would be frozen */) {
+        const bool fixed_point = k == VPT_RENDERER_DEPTH ? c.first_mix_one : (k == VPT_RENDERER_MCS ? (c.first_mix_one && r->env_opaque) : true);
+        if (c.fused_passes >= 1 && fixed_point && c.reset_seen) {
+            if (!c.valid) VPT_TRY(classes_build(r, c.mvp));
+            c.list_now = c.valid && c.n_hit > 0 && c.n_miss > 0;
+        }
+    }
+    if (fused) c.fused_passes++;
     return VPT_OK;
 }
 // one MCM pass (integrate, or render() = integrate + renderFrame) as list launches: the HIT tiles through k_mcm_integrate on the
@@ -941,7 +1012,7 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
         // one stream: the launches follow each other; the dispatch's completion event (gather pipeline) rides on the last
         for (int i = 0; i < np; i++) {
             PassArgs part = a;
-            part.pm.tile_list = parts[i].list; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
+            part.pm.tile_list = parts[i].list; part.pm.list_n = parts[i].n; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
             if (i + 1 == np) launch_range(parts[i].kernel, r, dim3((unsigned)parts[i].n), dim3(VPT_BLOCK), parts[i].lds, r->ctx->stream, part, 0);
             else hipLaunchKernelGGL(parts[i].kernel, dim3((unsigned)parts[i].n), dim3(VPT_BLOCK), parts[i].lds, r->ctx->stream, part);
         }
@@ -954,7 +1025,7 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
         }
         for (int i = 0; i < np; i++) {
             PassArgs part = a;
-            part.pm.tile_list = parts[i].list; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
+            part.pm.tile_list = parts[i].list; part.pm.list_n = parts[i].n; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
             // profiling: the context's stream is bracketed by the caller (Timed); the first side launch gets a pair of its own
             hipEvent_t e1 = nullptr;
             if (i == 1 && r->timed_now) {
@@ -1036,7 +1107,7 @@ template <bool FUSE>
 static int launch_mcm_pass(vpt_renderer *r, const PassArgs &a) {
     bool same = false;
     VPT_TRY(mcm_before_pass(r, a, &same));
-    if (same && r->cls.enabled && mcm_classes_runnable(r, a)) return launch_mcm_classes<FUSE>(r, a);
+    if (same && r->cls.enabled && mcm_classes_runnable(r, a) && !r->no_split) return launch_mcm_classes<FUSE>(r, a);
     VPT_TRY(mcm_materialize(r));
     if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCM_PERSIST(FUSE, r, a);
     else if (r->fast_math) { if (FUSE) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM0F, r, a); }
@@ -1084,6 +1155,8 @@ extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
     HIP_TRY(hipSetDevice(r->ctx->device));
     PassArgs a;
     VPT_TRY(make_args(r, u, false, &a));
+    r->cls.passes = 0; r->cls.fused_passes = 0; r->cls.poisoned = false; r->cls.list_now = false; r->cls.reset_seen = true;
+    if (r->kind != VPT_RENDERER_MCM) r->cls.valid = false;
     switch (r->kind) {
         case VPT_RENDERER_MIP: LAUNCH(k_mip_reset, r, a, 0); break;
         case VPT_RENDERER_EAM: LAUNCH(k_eam_reset, r, a, 0); break;
@@ -1108,6 +1181,7 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
     if (r->kind == VPT_RENDERER_ISO) VPT_TRY(check_iso(u));
     PassArgs a;
     VPT_TRY(make_args(r, u, true, &a));
+    VPT_TRY(marcher_track(r, a, false, 0.0f));
     {
         Timed t(r, true);
         switch (r->kind) {
@@ -1169,13 +1243,15 @@ extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u)
 }
 // the fused render() launch of the renderer's kind (generate -> integrate -> renderFrame in one kernel)
 static int launch_fused(vpt_renderer *r, const PassArgs &a) {
+    VPT_TRY(marcher_track(r, a, true, a.mix));
+    struct ListOff { vpt_renderer *r; ~ListOff() { r->cls.list_now = false; } } list_off{ r };
     switch (r->kind) {
         case VPT_RENDERER_MIP: LAUNCH_S(K_MIP1, r, a); break;
         case VPT_RENDERER_EAM: LAUNCH_S(K_EAM1, r, a); break;
         case VPT_RENDERER_ISO: LAUNCH_S(K_ISO1, r, a); break;
         case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH1, r, a); break;
         case VPT_RENDERER_LAO: LAUNCH_S(K_LAO1, r, a); break;
-        case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;
+        case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;   // (the persistent form walks every tile)
         case VPT_RENDERER_MCM: VPT_TRY(launch_mcm_pass<true>(r, a)); break;
     }
     return VPT_OK;
@@ -1304,6 +1380,10 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
     VPT_TRY(play_args(r, base, count, &a));
     if (use_graph == VPT_PLAY_GRAPH && r->warmed) {
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
+        // a captured sequence runs whole-image kernels (a graph freezes its grids; tile lists change with every reset)
+        if (r->kind == VPT_RENDERER_MCM) { VPT_TRY(mcm_before_pass(r, a, nullptr)); VPT_TRY(mcm_materialize(r)); }
+        const float first_mix = ((const FrameVar *)frame_vars)[0].mix;
+        a.frame_base = 0;                                   // (replays index the table by the device counter; the graph's key must not move)
         PlayGraph *g = r->play_graph;
         if (!g || g->with_gather || g->count != count || !play_key_equal(g->key, a)) {
             if (g) { HIP_TRY(hipStreamSynchronize(c->stream)); play_graph_free(g); r->play_graph = nullptr; }
@@ -1313,7 +1393,9 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
             int rc = VPT_OK;
             r->no_split = true;                       // a captured sequence lives on the capturing stream alone
             for (int i = 0; i < count && rc == VPT_OK; i++) {
-                rc = launch_fused(r, a);
+                PassArgs f = a;
+                if (i == 0) f.mix = first_mix;                // (per-frame uniforms come from the table; marcher_track wants the first pass's mix)
+                rc = launch_fused(r, f);
                 hipLaunchKernelGGL(k_advance_frame, dim3(1), dim3(1), 0, c->stream, r->frame_counter);
             }
             r->no_split = false;
@@ -1322,6 +1404,11 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
             if (rc == VPT_OK) { e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0); if (e != hipSuccess) rc = fail(VPT_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
             if (rc != VPT_OK) { play_graph_free(g); return rc; }
             r->play_graph = g;
+        }
+        else {
+            // a cached graph is replayed without passing through launch_fused: the marchers' pass tracking is told by hand
+            for (int i = 0; i < count; i++) VPT_TRY(marcher_track(r, a, true, ((const FrameVar *)frame_vars)[i].mix));
+            r->cls.list_now = false;
         }
         {
             Timed t(r, true, (uint32_t)count);       // a replay is timed as a whole: events inside a graph cannot be read back
@@ -1335,6 +1422,7 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
         if (r->kind == VPT_RENDERER_LAO) return fail(VPT_ERR_UNSUPPORTED, "fused passes are pointless for the LAO renderer: its frames do not accumulate");
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
         a.multi_passes = (uint32_t)count;
+        a.mix = ((const FrameVar *)frame_vars)[0].mix;      // (the kernels take every pass's uniforms from the table; marcher_track wants the first pass's)
         {
             Timed t(r, true, (uint32_t)count);
             VPT_TRY(launch_fused(r, a));
@@ -1595,7 +1683,7 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
             if ((value != 0) != (r->fast_math != 0)) VPT_TRY(mcm_materialize(r));   // MISS-tile positions in the arithmetic that produced the directions
             r->fast_math = value != 0; return VPT_OK;
         case VPT_OPTION_TILE_CLASSES:
-            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_TILE_CLASSES: an MCM option");
+            if (r->kind == VPT_RENDERER_DOS || r->kind == VPT_RENDERER_LAO) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_TILE_CLASSES: not an option of the DOS / LAO renderers");
             r->cls.enabled = value != 0; return VPT_OK;
         case VPT_OPTION_VERIFY_TILE_CLASSES:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_VERIFY_TILE_CLASSES: an MCM option");

@@ -30,6 +30,7 @@ struct PixMap {
     // launch over a LIST of tiles instead of the whole tile grid (tile classes): workgroup b of a
     // 1-D grid takes tile tile_list[b] = tx | ty << 16; null = the 2-D grid below
     const uint32_t *tile_list;
+    int list_n;        // entries of tile_list this launch covers (one-wave workgroups pad their grid to whole groups of eight tiles)
 };
 struct Pix { int i, j, l, k; bool valid, tile; };   // tile: the workgroup maps to a tile of the buffers (valid or padding pixel)
 
@@ -53,9 +54,17 @@ VPT_DEV Pix map_pixel(const PixMap &m) {
     int tx, w, lane = (int)threadIdx.x & 63;
     if (m.tile_list) {
         // listed tiles (one scalar load): consecutive workgroups = consecutive list entries, dealt round-robin over the XCDs
-        const uint32_t e = m.tile_list[blockIdx.x];
-        tx = (int)(e & 0xffffu); ty = (int)(e >> 16);
+        int e = (int)blockIdx.x;
         w = (int)threadIdx.x >> 6;
+        if (blockDim.x == 64) {
+            // one-wave workgroups: blockIdx.x = (group * 4 + wave) * 8 + xcd, entry = group * 8 + xcd — the four waves of a tile
+            // stay on one XCD (they walk the same bricks), as in the 2-D grid's one-wave form below
+            w = ((int)blockIdx.x >> 3) & 3;
+            e = ((int)blockIdx.x >> 5) * 8 + xcd;
+        }
+        if (e >= m.list_n) { Pix q; q.i = q.j = q.l = q.k = 0; q.valid = false; q.tile = false; return q; }
+        const uint32_t t = m.tile_list[e];
+        tx = (int)(t & 0xffffu); ty = (int)(t >> 16);
     } else if (blockDim.x == 64) {
         // one-wave workgroups (the ray marchers when their LDS image is small): blockIdx.x = (group * 4 + wave) * 8 + xcd.
         // Same tile -> XCD map and the same buffer order; the unit the dispatcher balances over the CUs is a quarter
