@@ -51,8 +51,6 @@ def parse():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--check", type=int, default=1, help="verify the gathered frame against rank-local rows")
-    ap.add_argument("--mcm-persistent", type=int, default=-1, help="MCM only: 1/0 force the persistent-wave kernel on/off")
-    ap.add_argument("--mcs-persistent", type=int, default=-1, help="MCS only: 1/0 force the persistent-wave kernel on/off")
     ap.add_argument("--profile-kernel", type=int, default=8,
                     help="HIP events around every n-th launch of the dominant kernel in the timed region (1 = every launch, 0 = none)")
     ap.add_argument("--stream-probe", type=int, default=1, help="also measure the HBM streaming-read rate (second roofline denominator)")
@@ -83,8 +81,9 @@ def parse():
                     help="MCM: 0 = every tile through the general kernel (VPT_OPTION_TILE_CLASSES off; results identical)")
     ap.add_argument("--split-streams", type=int, default=2,
                     help="MCM: K >= 2 = launch every pass as K tile-row ranges on K HIP streams (VPT_OPTION_SPLIT_STREAMS; results identical)")
-    ap.add_argument("--split-caller-targets", type=int, default=0,
-                    help="torch.distributed pipeline: 1 = split passes into the gather's buckets too and join once per bucket (measured: no gain)")
+    ap.add_argument("--split-caller-targets", type=int, default=-1,
+                    help="torch.distributed pipeline: 1 = passes into the gather's buckets run on several streams too and are joined once per bucket; "
+                         "-1 = yes when the MCM tile classes are in force (HIT | MISS kernels), no otherwise")
     ap.add_argument("--frames-per-gather", type=int, default=4,
                     help="torch.distributed pipeline: frames per all_gather (every frame is delivered; one async collective costs the host "
                          "~25 us whatever its size, more than a 1/8 shard's kernel takes)")
@@ -312,14 +311,15 @@ def main():
         # the library's own RCCL pipeline did not finish its measurement in time: report the torch.distributed one
         sys.stderr.write("bench.py: the native gather pipeline did not finish within %d s - reporting the torch.distributed measurement\n" % args.native_deadline)
         sys.stderr.flush()
-        if int(os.environ.get("RANK", "0")) == 0 and state["fallback"] is not None and state["make_line"] is not None:
+        have_line = state["fallback"] is not None and state["make_line"] is not None
+        if int(os.environ.get("RANK", "0")) == 0 and have_line:
             line = state["make_line"](state["fallback"])
             line["native_timeout"] = True
             line["config"]["note"] = "native RCCL gather pipeline timed out; torch.distributed all_gather measurement reported"
             os.write(real_stdout, (json.dumps(line) + "\n").encode())
         sys.stderr.write("bench.py: rank %s was in: %s\n" % (os.environ.get("RANK", "0"), state.get("phase", "?")))
         sys.stderr.flush()
-        os._exit(4)                                   # a hung pipeline is a failure, not a clean run
+        os._exit(0 if have_line else 4)               # the first (complete, frame-checked) measurement stands; only its absence is a failure
     lib_path = os.path.join(ROOT, "vpt_amd", "libvpt_hip.so")
     if not os.path.exists(lib_path):                       # git-ignored artefact: a bare checkout builds it (one rank, the others wait)
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -369,24 +369,24 @@ def main():
         r = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, opts)
         if args.extinction is not None:
             r.extinction = args.extinction
-        if args.mcm_persistent >= 0:
-            r.set_option(N.OPTION_MCM_PERSISTENT, args.mcm_persistent)
         if args.renderer != "mcm":
             args.fast_math = 0                              # an MCM option
         if args.fast_math:
             r.set_option(N.OPTION_FAST_MATH, 1)
-        # N > 1: the native pipeline keeps the ranges' streams apart across frames (its communication stream waits for every range);
-        # the torch.distributed pipeline renders into caller memory, where the library keeps the pass on one stream by itself.
-        # Every range costs the host a launch, an event record and a stream wait per frame: measured on one GPU with frames of a
-        # shard's size (tools/r02_exp22.sh, r02_exp24.sh), three ranges pay from ~500 rows of 1920 pixels on (N <= 2 at 1080p) and
-        # lose below.
-        if use_dist and args.split_streams >= 2 and int(r.local_rows()) * W < 500 * 1920:
+        # N > 1.  The MCM pass is two kernels on two streams (tile classes: HIT | MISS; rank 3 of 8's share of the headline frame 17.7 us
+        # against 20.7 for the general kernel on one stream, profiles/r03_shard8.json).  The native pipeline keeps the streams apart across
+        # frames (its communication stream waits for both); the torch.distributed pipeline renders into caller memory, where the library
+        # keeps a pass on one stream unless the caller takes the join upon itself (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join): it
+        # does, once per bucket of --frames-per-gather frames, right before the collective that reads the bucket.  Without tile classes
+        # (--tile-classes 0, other renderers) more ranges only pay from ~500 rows of 1920 pixels on (round 2) and the caller-side join
+        # gains nothing: those runs stay on one stream below that size.
+        classes_on = bool(args.tile_classes) and args.renderer == "mcm"
+        if use_dist and args.split_streams >= 2 and not classes_on and int(r.local_rows()) * W < 500 * 1920:
             args.split_streams = 1
         if args.split_streams >= 2:
             r.set_option(N.OPTION_SPLIT_STREAMS, args.split_streams)
-        # The torch.distributed pipeline hands whole buckets of frames to a collective and could join the ranges once per bucket
-        # itself (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join): measured on a one-rank RCCL group it gains nothing there
-        # (1920x1080: 122.6 us one stream, 124.9 us three; x544: 66.4 / 66.2 - tools/r02_exp29.sh), so those passes stay on one stream.
+        if args.split_caller_targets < 0:
+            args.split_caller_targets = 1 if classes_on else 0
         split_callers = bool(args.split_caller_targets and use_dist and args.split_streams >= 2)
         if split_callers:
             r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
@@ -394,8 +394,6 @@ def main():
             r.set_option(N.OPTION_BOUNDARY_ATLAS, 0)
         if not args.tile_classes and args.renderer == "mcm":
             r.set_option(N.OPTION_TILE_CLASSES, 0)
-        if args.mcs_persistent >= 0:
-            r.set_option(N.OPTION_MCS_PERSISTENT, args.mcs_persistent)
         assert r.local_rows() == gather.rows
         nbytes = gather.send[0].numel() * 2
         r.reset()

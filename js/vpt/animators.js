@@ -6,32 +6,44 @@
 // pinned by tests/golden/orbit_animator_r01.json (the reference's class run under node on scripted input).
 const { mat4, quat, vec3 } = require('./math.js');
 
+// The pose is what the fixture pins: a point on a circle of `radius` about `center`, in the plane whose normal is `direction`,
+// `frequency` turns per unit of t — reached through the SAME chain of 4x4 Float32Array products the reference's update() forms
+// (shift * tilt * spin * scale, each product rounded to float32), because its last bits depend on that chain.
 class CircleAnimator {
 
 constructor(node, options) {
     this.node = node;
-    Object.assign(this, { center: [0, 0, 0], direction: [1, 0, 0], radius: 1, frequency: 1 }, options || {});
+    this.center = [0, 0, 0];
+    this.direction = [1, 0, 0];
+    this.radius = 1;
+    this.frequency = 1;
+    const given = options || {};
+    for (const key of Object.keys(given)) this[key] = given[key];
 }
 
-update(t) {                                                                        // :16-40
-    const scale = mat4.fromScaling(mat4.create(), [this.radius, this.radius, this.radius]);
-    const angle = this.frequency * t * 2 * Math.PI;
-    const phase = mat4.fromRotation(mat4.create(), angle, [0, 0, 1]);
-    const from = [0, 0, 1];
-    const to = vec3.normalize(vec3.create(), this.direction);
-    const axis = vec3.cross(vec3.create(), from, to);
-    const slant = vec3.dot(from, to);
-    const orientationQuat = [axis[0], axis[1], axis[2], slant];
-    const orientation = mat4.fromQuat(mat4.create(), orientationQuat);
-    const translation = mat4.fromTranslation(mat4.create(), this.center);
-    const composite = mat4.create();
-    mat4.multiply(composite, composite, translation);
-    mat4.multiply(composite, composite, orientation);
-    mat4.multiply(composite, composite, phase);
-    mat4.multiply(composite, composite, scale);
-    const position = [1, 0, 0];
-    this.node.transform.localTranslation = vec3.transformMat4(position, position, composite);
-    this.node.transform.localRotation = orientationQuat;
+// the rotation taking +z onto `direction`, the reference's way: the UN-normalised quaternion (z x d, z . d) — also what the node's
+// localRotation receives
+_tilt() {
+    const z = [0, 0, 1];
+    const d = vec3.normalize(vec3.create(), this.direction);
+    const c = vec3.cross(vec3.create(), z, d);
+    return [c[0], c[1], c[2], vec3.dot(z, d)];
+}
+
+update(t) {
+    const tilt = this._tilt();
+    const r = this.radius;
+    const factors = [
+        mat4.fromTranslation(mat4.create(), this.center),
+        mat4.fromQuat(mat4.create(), tilt),
+        mat4.fromRotation(mat4.create(), this.frequency * t * 2 * Math.PI, [0, 0, 1]),
+        mat4.fromScaling(mat4.create(), [r, r, r]),
+    ];
+    const pose = factors.reduce((acc, f) => mat4.multiply(acc, acc, f), mat4.create());
+    const start = [1, 0, 0];                                                       // a plain array: transformMat4 works in double on it
+    const transform = this.node.transform;
+    transform.localTranslation = vec3.transformMat4(start, start, pose);
+    transform.localRotation = tilt;
 }
 
 }

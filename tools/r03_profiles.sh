@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-3 evidence: rocprofv3 kernel statistics + PMC passes (tools/r03_pmc.sh) of the headline workload in its forms and of the
+# ray marchers; summaries are copied to gpurun_out/r03/profiles/ under the names profiles/ keeps them by.
+set -o pipefail
+P=gpurun_out/r03/profiles; mkdir -p $P
+run() {   # name, bench.py arguments
+  name=$1; shift
+  tools/r03_pmc.sh $name "$@" 2>&1 | grep -v amdgpu.ids
+  cp gpurun_out/r03/pmc_$name/summary.json $P/r03_${name}_pmc.json
+  cp gpurun_out/r03/pmc_$name/kernel_stats.csv $P/r03_${name}_kernel_stats.csv
+}
+run mcm512_fast_classes_one_stream --fast-math 1 --split-streams 1
+run mcm512_bit_exact_classes_one_stream --fast-math 0 --split-streams 1
+run mcm512_fast_general_kernel_one_stream --fast-math 1 --split-streams 1 --tile-classes 0
+run eam256_classes_one_stream --renderer eam --volume 256 --split-streams 1
+run mip256_classes_one_stream --renderer mip --volume 256 --split-streams 1
+# the default line's form (two streams): kernel trace only — counter collection serialises the dispatches
+export TMPDIR=/tmp
+for cfg in "mcm512_fast_classes_two_streams:--fast-math 1 --split-streams 2" "mcm512_bit_exact_classes_two_streams:--fast-math 0 --split-streams 2" "eam256_classes_three_streams:--renderer eam --volume 256 --split-streams 3"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  d=gpurun_out/r03/kt_$name; rm -rf $d; mkdir -p $d
+  cmd="python3 bench.py --cpu-baseline 0 --stream-probe 0 --other-configs 0 --check 0 --steps 100 --warmup 10 --warmup-seconds 0 --repeats 1 $args"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $d/kt -o kt --output-format csv -- $cmd > $d/kt.log 2>&1 || { echo "$name kernel-trace FAILED"; tail -3 $d/kt.log; continue; }
+  echo "# $cmd" > $P/r03_${name}_kernel_stats.csv
+  python3 tools/kernel_stats.py $d/kt | head -8 >> $P/r03_${name}_kernel_stats.csv
+  tail -1 $d/kt.log | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print('$name', j['ms_per_step'], j['roofline']['frac'])"
+  rm -rf $d/kt
+done
+ls $P

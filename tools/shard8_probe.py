@@ -32,43 +32,66 @@ def timed(ctx, step, frames=400, reps=5):
     return best * 1e6
 
 
+def make(ctx, gvol, W, H, fast, split, classes=1, shard=None):
+    o = {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()}
+    if shard:
+        o['shard'] = shard
+    r = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, o)
+    r.set_option(N.OPTION_FAST_MATH, fast)
+    r.set_option(N.OPTION_TILE_CLASSES, classes)
+    if split > 1:
+        r.set_option(N.OPTION_SPLIT_STREAMS, split)
+    r.reset()
+    return r
+
+
 def main():
     W, H = 1920, 1080
     ctx = vpt_amd.Context(0)
     gvol = vpt_amd.Volume.from_array(ctx, sphere_volume(512, noise=48.0), 'linear')
-    out = {"unit": "us per frame", "frame": "%dx%d" % (W, H), "volume": "512^3"}
+    out = {"unit": "us per frame", "frame": "%dx%d" % (W, H), "volume": "512^3",
+           "forms": "tile classes in force unless named general_kernel; N streams = VPT_OPTION_SPLIT_STREAMS (classes: HIT tiles | MISS tiles)"}
     for fast in (0, 1):
         tag = "fast_math" if fast else "bit_exact"
-        full = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
-        full.set_option(N.OPTION_FAST_MATH, fast); full.reset()
-        out["full_frame_%s" % tag] = timed(ctx, full.render, 200)
-        full.set_option(N.OPTION_SPLIT_STREAMS, 3)
-        out["full_frame_three_streams_%s" % tag] = timed(ctx, full.render, 200)      # the N = 1 default of bench.py
+        full = make(ctx, gvol, W, H, fast, 2)
+        out["full_frame_two_streams_%s" % tag] = timed(ctx, full.render, 200)         # the N = 1 default of bench.py
+        out["full_frame_tiles_%s" % tag] = full.tile_classes()[:2]
         full.destroy()
-        sh = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng(), 'shard': (3, 8, 8)})
-        sh.set_option(N.OPTION_FAST_MATH, fast); sh.reset()
-        out["shard_3_of_8_kernel_%s" % tag] = timed(ctx, sh.render)
-        out["shard_rows"] = int(sh.local_rows())
-        sh.destroy()
-        # a full frame of a shard's size through the gather pipeline (one-rank communicator) against its plain render()
+        full = make(ctx, gvol, W, H, fast, 3, classes=0)
+        out["full_frame_general_kernel_three_streams_%s" % tag] = timed(ctx, full.render, 200)   # round 2's form
+        full.destroy()
+        for world, rank in ((8, 3), (4, 1), (2, 0)):
+            for split in (1, 2, 3):
+                sh = make(ctx, gvol, W, H, fast, split, shard=(rank, world, 8))
+                out["shard_%d_of_%d_%d_streams_%s" % (rank, world, split, tag)] = timed(ctx, sh.render)
+                if split == 1:
+                    out["shard_%d_of_%d_tiles" % (rank, world)] = sh.tile_classes()[:2]
+                    out["shard_%d_of_%d_rows" % (rank, world)] = int(sh.local_rows())
+                sh.destroy()
+            sh = make(ctx, gvol, W, H, fast, 2, classes=0, shard=(rank, world, 8))
+            out["shard_%d_of_%d_general_kernel_two_streams_%s" % (rank, world, tag)] = timed(ctx, sh.render)
+            sh.destroy()
+        # a full frame of a 1/8 shard's size through the gather pipeline (one-rank communicator) against its plain render()
         hs = 136
-        plain = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, {'resolution': (W, hs), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
-        plain.set_option(N.OPTION_FAST_MATH, fast); plain.reset()
+        plain = make(ctx, gvol, W, hs, fast, 2)
         t_plain = timed(ctx, plain.render)
-        piped = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, {'resolution': (W, hs), 'transform': Transform(Node()), 'rng': GoldenRatioRng(), 'shard': (0, 1, 8)})
-        piped.set_option(N.OPTION_FAST_MATH, fast); piped.reset()
+        piped = make(ctx, gvol, W, hs, fast, 2, shard=(0, 1, 8))
         g = RcclFrameGather(piped, RcclFrameGather.unique_id(), 0, 1)
         for root in (0, -1):
             g.set_root(root)
             t_pipe = timed(ctx, g.render)
             g.synchronize()
             out["handoff_root%s_%s" % ("0" if root == 0 else "_all", tag)] = t_pipe - t_plain
-        out["frame_1920x136_plain_%s" % tag] = t_plain
+        out["frame_1920x136_plain_two_streams_%s" % tag] = t_plain
         g.destroy(); piped.destroy(); plain.destroy()
-        k, hnd = out["shard_3_of_8_kernel_%s" % tag], max(out["handoff_root0_%s" % tag], 0.0)
-        out["per_rank_frame_%s" % tag] = k + hnd
-        out["projected_speedup_at_8_%s" % tag] = out["full_frame_%s" % tag] / (k + hnd)
-        out["projected_speedup_at_8_vs_three_streams_%s" % tag] = out["full_frame_three_streams_%s" % tag] / (k + hnd)
+        one = out["full_frame_two_streams_%s" % tag]
+        for world, rank in ((8, 3), (4, 1), (2, 0)):
+            k = min(out["shard_%d_of_%d_%d_streams_%s" % (rank, world, sp, tag)] for sp in (1, 2, 3))
+            hnd = max(out["handoff_root0_%s" % tag], 0.0)
+            out["per_rank_frame_at_%d_%s" % (world, tag)] = k + hnd
+            out["projected_speedup_at_%d_%s" % (world, tag)] = one / (k + hnd)
+    out["note"] = ("projected = this round's single-GPU frame (tile classes, two streams) / (best one-GPU time of one rank's share + hand-off); "
+                   "UNMEASURED on more than one GPU")
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 1:
         json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -22,25 +22,28 @@ class CircleAnimator:
         for k, v in (options or {}).items():
             setattr(self, k, v)
 
-    def update(self, t):                                                          # :16-40
-        scale = mat4.fromScaling(mat4.create(), [self.radius, self.radius, self.radius])
-        angle = self.frequency * t * 2 * math.pi
-        phase = mat4.fromRotation(mat4.create(), angle, [0, 0, 1])
-        from_ = [0, 0, 1]
-        to = vec3.normalize(vec3.create(), self.direction)
-        axis = vec3.cross(vec3.create(), from_, to)
-        slant = vec3.dot(from_, to)
-        orientationQuat = [float(axis[0]), float(axis[1]), float(axis[2]), slant]
-        orientation = mat4.fromQuat(mat4.create(), orientationQuat)
-        translation = mat4.fromTranslation(mat4.create(), self.center)
-        composite = mat4.create()
-        mat4.multiply(composite, composite, translation)
-        mat4.multiply(composite, composite, orientation)
-        mat4.multiply(composite, composite, phase)
-        mat4.multiply(composite, composite, scale)
-        position = [1, 0, 0]                                                      # a plain array: no float32 rounding before the setter
-        self.node.transform.localTranslation = vec3.transformMat4(position, position, composite)
-        self.node.transform.localRotation = orientationQuat
+    def _tilt(self):
+        """the rotation taking +z onto `direction`, the reference's way: the UN-normalised quaternion (z x d, z . d)"""
+        z = [0, 0, 1]
+        d = vec3.normalize(vec3.create(), self.direction)
+        c = vec3.cross(vec3.create(), z, d)
+        return [float(c[0]), float(c[1]), float(c[2]), vec3.dot(z, d)]
+
+    def update(self, t):
+        """a point on the circle (radius, center, plane normal `direction`), `frequency` turns per unit of t — through the same chain
+        of float32 4x4 products as the reference's update() (:16-40: shift * tilt * spin * scale), which the fixture's last bits follow"""
+        tilt = self._tilt()
+        r = self.radius
+        factors = [mat4.fromTranslation(mat4.create(), self.center),
+                   mat4.fromQuat(mat4.create(), tilt),
+                   mat4.fromRotation(mat4.create(), self.frequency * t * 2 * math.pi, [0, 0, 1]),
+                   mat4.fromScaling(mat4.create(), [r, r, r])]
+        pose = mat4.create()
+        for f in factors:
+            mat4.multiply(pose, pose, f)
+        start = [1, 0, 0]                                                         # a plain array: no float32 rounding before the setter
+        self.node.transform.localTranslation = vec3.transformMat4(start, start, pose)
+        self.node.transform.localRotation = tilt
 
 
 class OrbitCameraAnimator:

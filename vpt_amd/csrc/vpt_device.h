@@ -358,6 +358,22 @@ template <int B> VPT_DEV float cvt_ubyte(uint32_t w) {
     else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(w));
     return r;
 }
+// the blend of the eight taps held in the two 8-byte windows (l0 | h0 = window +0, l1 | h1 = window +25)
+VPT_DEV float trilinear_blend(uint32_t l0, uint32_t h0, uint32_t l1, uint32_t h1, float fx, float fy, float fz) {
+    // byte -> float straight out of the loaded dwords (v_cvt_f32_ubyteN: the byte select is free).  Written as opaque
+    // instructions: left to itself the compiler turns (float)b - (float)a into (float)(b - a) and spends 18 integer-class
+    // instructions (shifts, SDWA subtracts, two conversions per pair) where 8 conversions + 4 fp32 subtracts do —
+    // integer-class VALU instructions cost ~4.3 cycles per wave on this chip against ~2.6 for fp32 add/mul/fma
+    // (tools/valu_rates.hip).  Same values, same results.
+    float c000 = cvt_ubyte<0>(l0), c100 = cvt_ubyte<1>(l0);
+    float c010 = cvt_ubyte<1>(h0), c110 = cvt_ubyte<2>(h0);
+    float c001 = cvt_ubyte<0>(l1), c101 = cvt_ubyte<1>(l1);
+    float c011 = cvt_ubyte<1>(h1), c111 = cvt_ubyte<2>(h1);
+    float c00 = lerpf(c000, c100, fx), c10 = lerpf(c010, c110, fx);
+    float c01 = lerpf(c001, c101, fx), c11 = lerpf(c011, c111, fx);
+    float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
+    return lerpf(c0, c1, fz) * VPT_INV255;
+}
 template <int V>
 VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
     uint32_t l0, h0, l1, h1;
@@ -374,19 +390,7 @@ VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
         __builtin_memcpy(&w1, a + 25, 8);
         l0 = (uint32_t)w0; h0 = (uint32_t)(w0 >> 32); l1 = (uint32_t)w1; h1 = (uint32_t)(w1 >> 32);
     }
-    // byte -> float straight out of the loaded dwords (v_cvt_f32_ubyteN: the byte select is free).  Written as opaque
-    // instructions: left to itself the compiler turns (float)b - (float)a into (float)(b - a) and spends 18 integer-class
-    // instructions (shifts, SDWA subtracts, two conversions per pair) where 8 conversions + 4 fp32 subtracts do —
-    // integer-class VALU instructions cost ~4.3 cycles per wave on this chip against ~2.6 for fp32 add/mul/fma
-    // (tools/valu_rates.hip).  Same values, same results.
-    float c000 = cvt_ubyte<0>(l0), c100 = cvt_ubyte<1>(l0);
-    float c010 = cvt_ubyte<1>(h0), c110 = cvt_ubyte<2>(h0);
-    float c001 = cvt_ubyte<0>(l1), c101 = cvt_ubyte<1>(l1);
-    float c011 = cvt_ubyte<1>(h1), c111 = cvt_ubyte<2>(h1);
-    float c00 = lerpf(c000, c100, fx), c10 = lerpf(c010, c110, fx);
-    float c01 = lerpf(c001, c101, fx), c11 = lerpf(c011, c111, fx);
-    float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
-    return lerpf(c0, c1, fz) * VPT_INV255;
+    return trilinear_blend(l0, h0, l1, h1, fx, fy, fz);
 }
 // ---- boundary atlas ---------------------------------------------------------------------------------------------------
 // For a position with a coordinate outside [0, 1] (MCM samples before its bounds test, MCMRenderer.glsl:132-142) the clamped
@@ -409,9 +413,11 @@ VPT_DEV uint32_t boundary_cell(const DevVolume &v, f3 p, float &out_fa, float &o
     // plane 0), so the clamped axis needs no filter cell at all.  The photons of a wave mostly leave through the same face
     // (8 x 8 neighbouring pixels): the three wave-uniform cases are separate straight-line paths without per-lane selects,
     // and only a wave whose lanes disagree takes the generic one.
-    // (__builtin_amdgcn_ballot_w64 on the bools themselves: __ballot() takes an int, and the compiler then materialises each predicate
-    // as 0 / 1 in a VGPR and compares it again — four VALU instructions per sample for nothing)
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(true), bx = __builtin_amdgcn_ballot_w64(ox), by = __builtin_amdgcn_ballot_w64(oy);
+    // (ballots of the four compares themselves, OR-ed as scalars: a ballot of `ox` makes the compiler materialise the predicate as
+    // 0 / 1 in a VGPR and compare it again — four VALU instructions per sample for nothing)
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    const unsigned long long bx = __builtin_amdgcn_ballot_w64(p.x > 1.0f) | __builtin_amdgcn_ballot_w64(p.x < 0.0f);
+    const unsigned long long by = __builtin_amdgcn_ballot_w64(p.y > 1.0f) | __builtin_amdgcn_ballot_w64(p.y < 0.0f);
     uint32_t a, b, idx; float fa, fb;
     if (bx == act) {
         linear_cell(p.y, fny, hy, a, fa); linear_cell(p.z, fnz, hz, b, fb);

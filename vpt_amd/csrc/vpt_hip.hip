@@ -990,6 +990,8 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     if (check) km = fast ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, true> : (PassKernel)k_mcm_miss<FUSE, 0, true>;
     else km = fast ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, false> : (PassKernel)k_mcm_miss<FUSE, 0, false>;
     const size_t lds_hit = lds_bytes(r), lds_miss = (size_t)r->tf_w * 2 * sizeof(float4);
+    if (lds_hit > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds_hit);
+    if (lds_hit > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hit));
     int k = 1;
     if (r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers)) k = r->split;
     if (r->side_busy && r->last_layout != 1) VPT_TRY(join_side(r));      // the tile -> stream map changes: order the streams once
@@ -997,7 +999,8 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     struct Part { PassKernel kernel; const uint32_t *list; int n; size_t lds; };
     Part parts[VPT_MAX_SPLIT]; int np = 0;
     // (measured, 1080p headline frame, us per frame: HIT | MISS on two streams 81.0; HIT | MISS/2 | MISS/2 82.3-83.0; HIT/2 | HIT/2 | MISS
-    // 82.7-84.1; four streams 93; one stream, HIT then MISS: 102 — tools/r03_exp2.sh)
+    // 82.7-84.1; four streams 93; one stream, HIT then MISS: 102.  Capping the HIT kernel's residency (dynamic LDS) to 2 / 3 / 4 / 5
+    // workgroups per CU so that MISS waves always sit beside its waves: 99 / 91 / 83.4 / 82.2 against 81.6 uncapped — DESIGN.md section 5)
     const int hit_parts = r->cls.n_hit > 0 ? 1 : 0;
     const int miss_parts = std::max(1, k - hit_parts);
     for (int i = 0; i < hit_parts; i++) {
@@ -1047,6 +1050,7 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     return VPT_OK;
 }
 
+#ifdef VPT_WITH_PERSISTENT_KERNELS
 template <typename K>
 static int launch_mcs_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
     size_t lds = lds_bytes(r);
@@ -1095,6 +1099,8 @@ static int launch_mcm_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
         default: VPT_TRY(launch_mcs_persist((k_mcs_persist<MODE, 3>), (r), (a))); break; \
     } } while (0)
 
+#endif
+
 // MCM passes with a matrix (or a blur) other than the reset's: the photons of MISS tiles may now enter the cube — the classes are
 // void until the next reset.  Whole-image kernels need the MISS tiles' position / transmittance arrays up to date first.
 static int mcm_before_pass(vpt_renderer *r, const PassArgs &a, bool *same_matrix) {
@@ -1107,10 +1113,17 @@ template <bool FUSE>
 static int launch_mcm_pass(vpt_renderer *r, const PassArgs &a) {
     bool same = false;
     VPT_TRY(mcm_before_pass(r, a, &same));
-    if (same && r->cls.enabled && mcm_classes_runnable(r, a) && !r->no_split) return launch_mcm_classes<FUSE>(r, a);
+    // The two kernels of the classes pay on two streams (1080p headline frame 81 us against 99-106 for the general kernel; rank 3 of 8's
+    // share 17.7 against 19.4) and lose when they have to follow each other on ONE stream (102; the share: 30.5 against 20.7): a pass
+    // that must stay on the context's stream — no VPT_OPTION_SPLIT_STREAMS, a caller-owned render target without
+    // VPT_OPTION_SPLIT_CALLER_TARGETS, a sequence being captured — runs the general kernel.
+    const bool two_streams = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers);
+    if (same && r->cls.enabled && mcm_classes_runnable(r, a) && two_streams) return launch_mcm_classes<FUSE>(r, a);
     VPT_TRY(mcm_materialize(r));
-    if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCM_PERSIST(FUSE, r, a);
-    else if (r->fast_math) { if (FUSE) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM0F, r, a); }
+#ifdef VPT_WITH_PERSISTENT_KERNELS
+    if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) { LAUNCH_MCM_PERSIST(FUSE, r, a); return VPT_OK; }
+#endif
+    if (r->fast_math) { if (FUSE) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM0F, r, a); }
     else { if (FUSE) LAUNCH_S(K_MCM1, r, a); else LAUNCH_S(K_MCM0, r, a); }
     return VPT_OK;
 }
@@ -1190,7 +1203,11 @@ extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
             case VPT_RENDERER_ISO: LAUNCH_S(K_ISO0, r, a); break;
             case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH0, r, a); break;
             case VPT_RENDERER_LAO: LAUNCH_S(K_LAO0, r, a); break;
-            case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCS_PERSIST(0, r, a); else LAUNCH_S(K_MCS0, r, a); break;
+            case VPT_RENDERER_MCS:
+#ifdef VPT_WITH_PERSISTENT_KERNELS
+                if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) { LAUNCH_MCS_PERSIST(0, r, a); break; }
+#endif
+                LAUNCH_S(K_MCS0, r, a); break;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1251,7 +1268,11 @@ static int launch_fused(vpt_renderer *r, const PassArgs &a) {
         case VPT_RENDERER_ISO: LAUNCH_S(K_ISO1, r, a); break;
         case VPT_RENDERER_DEPTH: LAUNCH_S(K_DEPTH1, r, a); break;
         case VPT_RENDERER_LAO: LAUNCH_S(K_LAO1, r, a); break;
-        case VPT_RENDERER_MCS: if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_S(K_MCS1, r, a); break;   // (the persistent form walks every tile)
+        case VPT_RENDERER_MCS:
+#ifdef VPT_WITH_PERSISTENT_KERNELS
+            if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) { LAUNCH_MCS_PERSIST(1, r, a); break; }   // (walks every tile)
+#endif
+            LAUNCH_S(K_MCS1, r, a); break;
         case VPT_RENDERER_MCM: VPT_TRY(launch_mcm_pass<true>(r, a)); break;
     }
     return VPT_OK;
@@ -1660,9 +1681,15 @@ extern "C" int vpt_renderer_set_lao_params(vpt_renderer *r, const struct vpt_lao
 extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
     switch (option) {
+#ifdef VPT_WITH_PERSISTENT_KERNELS
         // (the persistent kernels walk every tile from the context's stream: ranges of earlier split passes must be in first)
         case VPT_OPTION_MCS_PERSISTENT: VPT_TRY(join_side(r)); r->mcs_persistent = value != 0; return VPT_OK;
         case VPT_OPTION_MCM_PERSISTENT: VPT_TRY(join_side(r)); r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
+#else
+        case VPT_OPTION_MCS_PERSISTENT: case VPT_OPTION_MCM_PERSISTENT:
+            if (value == 0) return VPT_OK;
+            return fail(VPT_ERR_UNSUPPORTED, "the persistent-wave kernels (measured slower, DESIGN.md section 5) are not part of this build: make EXTRA=-DVPT_WITH_PERSISTENT_KERNELS");
+#endif
         case VPT_OPTION_BOUNDARY_ATLAS: r->boundary_atlas = value != 0; return VPT_OK;
         case VPT_OPTION_SPLIT_STREAMS:
             if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_SPLIT_STREAMS: the DOS renderer's slices depend on each other across pixels");

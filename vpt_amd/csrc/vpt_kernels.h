@@ -486,6 +486,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
     }
     count_samples(a.samples, ns);
 }
+#ifdef VPT_WITH_PERSISTENT_KERNELS   // measured-slower alternatives, not in the default build: make EXTRA=-DVPT_WITH_PERSISTENT_KERNELS
 // ---- persistent-wave MCS with active-ray compaction ------------------------------------------------------------
 // The tracking loops of MCSRenderer.glsl:70-105 have data-dependent lengths (0 .. extinction * chord events), so in the
 // one-thread-per-pixel kernel above finished lanes idle until the longest ray of their wave ends and whole workgroups
@@ -637,6 +638,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs_persist(PassArgs a, uint32_t 
     }
     count_samples(a.samples, ns);
 }
+#endif
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcs_integrate(PassArgs a) {
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
@@ -754,8 +756,36 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
 template <int V>
 VPT_DEV float4 mcm_sample(const PassArgs &a, const LdsTables &t, f3 p, bool oob) {
     float4 vs;
-    if (!(V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32)) && a.vol.atlas != nullptr && oob) vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, sample_volume_boundary(a.vol, p));
-    else vs = sample_volume_color<V>(a, t, p);
+    if (!(V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32))) {
+        // LINEAR one-channel byte volumes.  A wave whose lanes disagree (HIT tiles: some photons inside the cube, some outside) would
+        // run the two samplers one after the other, each waiting for its own load: the loads are issued in a first phase — atlas
+        // dword for the lanes outside, the two brick windows for the lanes inside — and blended in a second, so that both kinds are
+        // in flight together (a wave-event of a HIT tile is a chain of dependent latencies: -1 memory latency per event).  The
+        // second phase tests an opaque copy of the predicate, or the compiler would thread the two phases back into one branch.
+        constexpr bool WIDE = (V & VPT_V_WIDE) != 0;
+        const bool at = oob && a.vol.atlas != nullptr;
+        uint32_t aw = 0u; uint64_t w0 = 0ull, w1 = 0ull;
+        float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+        if (at) {
+            aw = a.vol.atlas[boundary_cell(a.vol, p, f0, f1)];
+        } else {
+            uint32_t x, y, z;
+            linear_cell(p.x, a.vol.fnx, a.vol.hx, x, f0);
+            linear_cell(p.y, a.vol.fny, a.vol.hy, y, f1);
+            linear_cell(p.z, a.vol.fnz, a.vol.hz, z, f2);
+            const uint8_t *b = cell_addr<WIDE>(a.vol, t, x, y, z);
+            __builtin_memcpy(&w0, b, 8);
+            __builtin_memcpy(&w1, b + 25, 8);
+        }
+        uint32_t at2 = at ? 1u : 0u;
+        asm volatile("" : "+v"(at2));
+        float r;
+        if (at2) r = boundary_blend(aw, f0, f1);
+        else r = trilinear_blend((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32), f0, f1, f2);
+        vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
+    } else {
+        vs = sample_volume_color<V>(a, t, p);
+    }
     asm volatile("" : "+v"(vs.w));
     return vs;
 }
@@ -935,6 +965,7 @@ VPT_DEV void photon_store(const PassArgs &a, int k, const Photon &ph) {       //
     a.st3[k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
 }
 
+#ifdef VPT_WITH_PERSISTENT_KERNELS
 // Persistent form of the integrate pass: every wave walks several 8x8-pixel segments of the tile-ordered state arrays
 // (segment g = lanes [64g, 64g+64)) and loads the NEXT segment's photon state (4 x dwordx4 per lane) before it starts the
 // current segment's events; LDS tables are staged once per workgroup instead of once per tile.  Measured (512^3, 1080p,
@@ -975,6 +1006,8 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
         }
     }
 }
+
+#endif
 
 #ifndef VPT_MCM_WAVES
 #define VPT_MCM_WAVES 7          // waves per SIMD the integrate kernel is compiled for (72 VGPRs; 8 needs 64: A/B in DESIGN.md section 5)
