@@ -1177,10 +1177,10 @@ template <int V>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_multi(PassArgs a, uint32_t npasses) {
     mcm_multi_body<V, false>(a, npasses, nullptr, 0u);
 }
-// the same with every pass's frame written to the ring: one more live address per lane, compiled for 5 waves per SIMD (96 VGPRs;
-// 5, 6 and 7 waves run the MCM events at the same rate)
+// the same with every pass's frame written to the ring: one more live address per lane (and, since the sample's loads are issued in
+// a phase of their own, two more windows in flight): compiled for 4 waves per SIMD (128 VGPRs; at 96 it spills three registers)
 template <int V>
-__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) k_mcm_frames(PassArgs a, uint32_t npasses, uint2 *ring, uint32_t slot_pixels) {
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_mcm_frames(PassArgs a, uint32_t npasses, uint2 *ring, uint32_t slot_pixels) {
     mcm_multi_body<V, true>(a, npasses, ring, slot_pixels);
 }
 __global__ void k_advance_frames(uint32_t *counter, uint32_t n) { *counter = *counter + n; }
