@@ -221,6 +221,11 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * (vpt_renderer_tile_classes' `violations`: must stay 0). */
 #define VPT_OPTION_TILE_CLASSES 6
 #define VPT_OPTION_VERIFY_TILE_CLASSES 7
+/* VPT_OPTION_HIT_KERNEL_FORM (default 0; MCM renderer with tile classes): which form of the HIT-tile kernel runs — 1 = k_mcm_integrate
+ * (72 registers, 7 waves per SIMD), 2 = k_mcm_integrate_early (the out-of-cube lanes' path end between issuing the sample's loads and
+ * consuming them; 5 waves per SIMD), 0 = the second where the HIT tiles are few enough to be resident at once at its occupancy
+ * (<= 1280: a shard's share of a frame), the first otherwise.  Results identical. */
+#define VPT_OPTION_HIT_KERNEL_FORM 8
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
 /* (extension) tiles of each class under the last reset's matrix (all HIT when no classification is in force) and the
  * VPT_OPTION_VERIFY_TILE_CLASSES counter; any pointer may be null */

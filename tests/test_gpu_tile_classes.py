@@ -29,12 +29,15 @@ def all_buffers(r):
 
 
 @pytest.mark.parametrize("fast", [0, 1])
-@pytest.mark.parametrize("split", [1, 3])
-def test_classes_on_and_off_give_identical_buffers(gpu_ctx, oracle, fast, split):
+@pytest.mark.parametrize("split,form", [(1, 0), (3, 1), (2, 2)])
+def test_classes_on_and_off_give_identical_buffers(gpu_ctx, oracle, fast, split, form):
+    """form: VPT_OPTION_HIT_KERNEL_FORM — 1 = k_mcm_integrate on the HIT tiles, 2 = k_mcm_integrate_early (path end of the out-of-cube
+    lanes under the sample's loads), 0 = chosen by the number of HIT tiles; one stream runs the general kernel on every tile"""
     sc = far_scene(gpu_ctx, oracle, env=env_map(16, 8))
 
     def run(classes):
         r = sc.renderer('mcm')
+        r.set_option(N.OPTION_HIT_KERNEL_FORM, form)
         r.set_option(N.OPTION_TILE_CLASSES, classes)
         r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
         r.set_option(N.OPTION_FAST_MATH, fast)
@@ -250,14 +253,16 @@ def test_classes_need_the_atlas_path(gpu_ctx, oracle):
     r.destroy(); sc.gvol.destroy()
 
 
-@pytest.mark.parametrize("fast", [0, 1])
-def test_full_hd_frame_classes_on_and_off(gpu_ctx, oracle, fast):
-    """the benchmark's image size and camera (1920x1080, default camera: ~77 % MISS tiles) on a 128^3 volume, three streams"""
+@pytest.mark.parametrize("fast,form", [(0, 0), (1, 0), (1, 2), (0, 2)])
+def test_full_hd_frame_classes_on_and_off(gpu_ctx, oracle, fast, form):
+    """the benchmark's image size and camera (1920x1080, default camera: ~77 % MISS tiles) on a 128^3 volume, three streams; both
+    forms of the HIT-tile kernel"""
     from vpt_amd.scene import default_camera
     sc = Scene(gpu_ctx, oracle, 128, 1920, 1080, camera=default_camera(1920 / 1080), noise=48.0)
 
     def run(classes):
         r = sc.renderer('mcm')
+        r.set_option(N.OPTION_HIT_KERNEL_FORM, form)
         r.set_option(N.OPTION_TILE_CLASSES, classes)
         r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
         r.set_option(N.OPTION_FAST_MATH, fast)

@@ -22,6 +22,7 @@ ap.add_argument("--blocks", type=int, default=5)
 ap.add_argument("--shard", default="", help="rank,world,rows: time one rank's share of the frame")
 ap.add_argument("--renderer", default="mcm")
 ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--hit-form", type=int, default=0)
 args = ap.parse_args()
 if args.lib:
     os.environ["VPT_HIP_LIBRARY"] = os.path.abspath(args.lib)
@@ -53,6 +54,8 @@ try:
     r.set_option(N.OPTION_TILE_CLASSES, args.classes)
 except vpt_amd.VptError:
     pass                                              # a build from before the option existed
+if args.hit_form:
+    r.set_option(N.OPTION_HIT_KERNEL_FORM, args.hit_form)
 if args.split > 1:
     r.set_option(N.OPTION_SPLIT_STREAMS, args.split)
 r.reset()
@@ -73,6 +76,6 @@ blocks.sort()
 med = blocks[len(blocks) // 2]
 samples = W * H * args.steps if not args.shard else None
 print("%-28s fast %d split %d classes %d%s: median %7.2f us  min %7.2f  max %7.2f%s" % (
-    args.tag or os.path.basename(args.lib) or "in-tree", args.fast, args.split, args.classes, (" shard " + args.shard) if args.shard else "",
+    (args.tag or os.path.basename(args.lib) or "in-tree") + (" hit-form %d" % args.hit_form if args.hit_form else ""), args.fast, args.split, args.classes, (" shard " + args.shard) if args.shard else "",
     med, blocks[0], blocks[-1], ("  frac %.3f" % (24.0 * samples / (med * 1e-6) / 8e12)) if samples and args.renderer == "mcm" else ""), flush=True)
 r.destroy(); gvol.destroy(); ctx.destroy()

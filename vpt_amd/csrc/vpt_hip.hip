@@ -130,6 +130,7 @@ struct vpt_renderer {
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
     struct TileClasses cls;        // MCM: HIT / MISS tile lists of the last reset's matrix (see classify_tiles)
     int last_layout;               // how the last sampling launch mapped tiles to streams: 0 = tile-row ranges, 1 = tile lists
+    int hit_form;                  // VPT_OPTION_HIT_KERNEL_FORM: 0 = by the number of HIT tiles, 1 = k_mcm_integrate, 2 = k_mcm_integrate_early
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
     void *scratch; size_t scratch_bytes;
@@ -507,7 +508,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->fast_math = 0; r->boundary_atlas = 1;
     r->frame_ring = nullptr; r->ring_frames = 0; r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
-    memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0;
+    memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0; r->hit_form = 0;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
@@ -987,8 +988,16 @@ template <bool FUSE>
 static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     const bool wide = (variant_of(r) & VPT_V_WIDE) != 0, fast = r->fast_math != 0, check = r->cls.verify;
     PassKernel kh, km;
-    if (fast) kh = wide ? (PassKernel)k_mcm_integrate<FUSE, VPT_V_WIDE | VPT_V_FAST> : (PassKernel)k_mcm_integrate<FUSE, VPT_V_FAST>;
-    else kh = wide ? (PassKernel)k_mcm_integrate<FUSE, VPT_V_WIDE> : (PassKernel)k_mcm_integrate<FUSE, 0>;
+    // the HIT tiles: few enough to be resident at once at 5 waves per SIMD (a shard's share) -> the form with the early path end,
+    // whose pass is one wave per SIMD walking a chain of dependent latencies; else the 7-waves form (VPT_OPTION_HIT_KERNEL_FORM overrides)
+    const bool early = r->hit_form == 2 || (r->hit_form == 0 && r->cls.n_hit <= 1280);
+    if (early) {
+        if (fast) kh = wide ? (PassKernel)k_mcm_integrate_early<FUSE, VPT_V_WIDE | VPT_V_FAST> : (PassKernel)k_mcm_integrate_early<FUSE, VPT_V_FAST>;
+        else kh = wide ? (PassKernel)k_mcm_integrate_early<FUSE, VPT_V_WIDE> : (PassKernel)k_mcm_integrate_early<FUSE, 0>;
+    } else {
+        if (fast) kh = wide ? (PassKernel)k_mcm_integrate<FUSE, VPT_V_WIDE | VPT_V_FAST> : (PassKernel)k_mcm_integrate<FUSE, VPT_V_FAST>;
+        else kh = wide ? (PassKernel)k_mcm_integrate<FUSE, VPT_V_WIDE> : (PassKernel)k_mcm_integrate<FUSE, 0>;
+    }
     if (check) km = fast ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, true> : (PassKernel)k_mcm_miss<FUSE, 0, true>;
     else km = fast ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, false> : (PassKernel)k_mcm_miss<FUSE, 0, false>;
     const size_t lds_hit = lds_bytes(r), lds_miss = (size_t)r->tf_w * 2 * sizeof(float4);
@@ -1714,6 +1723,10 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
         case VPT_OPTION_TILE_CLASSES:
             if (r->kind == VPT_RENDERER_DOS || r->kind == VPT_RENDERER_LAO) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_TILE_CLASSES: not an option of the DOS / LAO renderers");
             r->cls.enabled = value != 0; return VPT_OK;
+        case VPT_OPTION_HIT_KERNEL_FORM:
+            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_HIT_KERNEL_FORM: an MCM option");
+            if (value < 0 || value > 2) return fail(VPT_ERR_INVALID, "VPT_OPTION_HIT_KERNEL_FORM: 0 (automatic), 1 or 2");
+            r->hit_form = value; return VPT_OK;
         case VPT_OPTION_VERIFY_TILE_CLASSES:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_VERIFY_TILE_CLASSES: an MCM option");
             r->cls.verify = value != 0; return VPT_OK;

@@ -753,39 +753,46 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
 // degenerates to four taps on a face of the volume — fetched from the boundary atlas (vpt_device.h, sample_volume_boundary:
 // one aligned dword instead of two unaligned 8-byte gathers; bit-identical value).  At the benchmark camera 93 % of the events
 // end outside the cube (80 % of the pixels never meet it), and the pass was bound by the texture path's gather rate.
+// LINEAR one-channel byte volumes: the sample in two phases.  A wave whose lanes disagree (HIT tiles: some photons inside the cube,
+// some outside) would run the two samplers one after the other, each waiting for its own load: mcm_sample_issue puts the loads in
+// flight — the atlas dword for the lanes outside, the two brick windows for the lanes inside —, mcm_sample_finish blends them, so
+// that both kinds fly together (a wave-event of a HIT tile is a chain of dependent latencies: -1 memory latency per event), and
+// the EARLY event loops below put the out-of-cube lanes' path end between the two.  The second phase tests an opaque copy of the
+// predicate, or the compiler would thread the phases back into one branch.
+struct SampleLoads { uint32_t aw; uint64_t w0, w1; float f0, f1, f2; uint32_t atlas; };
+template <int V>
+VPT_DEV SampleLoads mcm_sample_issue(const PassArgs &a, const LdsTables &t, f3 p, bool oob) {
+    constexpr bool WIDE = (V & VPT_V_WIDE) != 0;
+    SampleLoads s;
+    s.aw = 0u; s.w0 = 0ull; s.w1 = 0ull; s.f0 = 0.0f; s.f1 = 0.0f; s.f2 = 0.0f;
+    const bool at = oob && a.vol.atlas != nullptr;
+    if (at) {
+        s.aw = a.vol.atlas[boundary_cell(a.vol, p, s.f0, s.f1)];
+    } else {
+        uint32_t x, y, z;
+        linear_cell(p.x, a.vol.fnx, a.vol.hx, x, s.f0);
+        linear_cell(p.y, a.vol.fny, a.vol.hy, y, s.f1);
+        linear_cell(p.z, a.vol.fnz, a.vol.hz, z, s.f2);
+        const uint8_t *b = cell_addr<WIDE>(a.vol, t, x, y, z);
+        __builtin_memcpy(&s.w0, b, 8);
+        __builtin_memcpy(&s.w1, b + 25, 8);
+    }
+    s.atlas = at ? 1u : 0u;
+    asm volatile("" : "+v"(s.atlas));
+    return s;
+}
+VPT_DEV float4 mcm_sample_finish(const PassArgs &a, const LdsTables &t, const SampleLoads &s) {
+    float r;
+    if (s.atlas) r = boundary_blend(s.aw, s.f0, s.f1);
+    else r = trilinear_blend((uint32_t)s.w0, (uint32_t)(s.w0 >> 32), (uint32_t)s.w1, (uint32_t)(s.w1 >> 32), s.f0, s.f1, s.f2);
+    float4 vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
+    asm volatile("" : "+v"(vs.w));
+    return vs;
+}
 template <int V>
 VPT_DEV float4 mcm_sample(const PassArgs &a, const LdsTables &t, f3 p, bool oob) {
-    float4 vs;
-    if (!(V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32))) {
-        // LINEAR one-channel byte volumes.  A wave whose lanes disagree (HIT tiles: some photons inside the cube, some outside) would
-        // run the two samplers one after the other, each waiting for its own load: the loads are issued in a first phase — atlas
-        // dword for the lanes outside, the two brick windows for the lanes inside — and blended in a second, so that both kinds are
-        // in flight together (a wave-event of a HIT tile is a chain of dependent latencies: -1 memory latency per event).  The
-        // second phase tests an opaque copy of the predicate, or the compiler would thread the two phases back into one branch.
-        constexpr bool WIDE = (V & VPT_V_WIDE) != 0;
-        const bool at = oob && a.vol.atlas != nullptr;
-        uint32_t aw = 0u; uint64_t w0 = 0ull, w1 = 0ull;
-        float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
-        if (at) {
-            aw = a.vol.atlas[boundary_cell(a.vol, p, f0, f1)];
-        } else {
-            uint32_t x, y, z;
-            linear_cell(p.x, a.vol.fnx, a.vol.hx, x, f0);
-            linear_cell(p.y, a.vol.fny, a.vol.hy, y, f1);
-            linear_cell(p.z, a.vol.fnz, a.vol.hz, z, f2);
-            const uint8_t *b = cell_addr<WIDE>(a.vol, t, x, y, z);
-            __builtin_memcpy(&w0, b, 8);
-            __builtin_memcpy(&w1, b + 25, 8);
-        }
-        uint32_t at2 = at ? 1u : 0u;
-        asm volatile("" : "+v"(at2));
-        float r;
-        if (at2) r = boundary_blend(aw, f0, f1);
-        else r = trilinear_blend((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32), f0, f1, f2);
-        vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
-    } else {
-        vs = sample_volume_color<V>(a, t, p);
-    }
+    if (!(V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32))) return mcm_sample_finish(a, t, mcm_sample_issue<V>(a, t, p, oob));
+    float4 vs = sample_volume_color<V>(a, t, p);
     asm volatile("" : "+v"(vs.w));
     return vs;
 }
@@ -818,6 +825,44 @@ VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float
             ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
             ph.direction = sample_hg(state, a.anisotropy, ph.direction);
             ph.bounces++;
+        }
+    }
+}
+// The same events with the out-of-cube lanes' path end (deposit + resetPhoton: they need the random stream only, and whether a
+// position is out of bounds is known before its sample) placed BETWEEN issuing the sample's loads and consuming them.  Same draws in
+// the same order, same arithmetic: bit-identical.  It costs ~12 more live registers, so it is the form of the HIT-tile kernel where
+// occupancy is not what limits it — a shard's few tiles, whose pass is one wave per SIMD walking a chain of dependent latencies
+// (DESIGN.md section 8).  LINEAR one-channel byte volumes only (the tile classes' precondition).
+template <int V>
+VPT_DEV void mcm_events_early(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
+    const f3 from0 = unproject_near(px, py, a);
+    uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    for (uint32_t s = 0u; s < a.steps; s++) {
+        float dist = random_exponential(state, a.inv_extinction);
+        ph.position = madd3(ph.position, dist, ph.direction);
+        f3 q = ph.position;
+        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+        const SampleLoads ld = mcm_sample_issue<V>(a, t, q, oob);
+        const uint32_t bounces = ph.bounces;                       // (the scattering probability reads the count before the path end)
+        float wheel = random_uniform(state);
+        if (oob) {
+            float4 env = sample_environment(a.env, ph.direction);
+            photon_deposit(ph, f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z });
+            reset_photon(state, ph, px, py, a, from0);
+        }
+        float4 vs = mcm_sample_finish(a, t, ld);
+        float p_null = 1.0f - vs.w;
+        float p_scat = (bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
+        float p_abs = 1.0f - p_null - p_scat;
+        if (!oob) {
+            if (wheel < p_abs) {
+                photon_deposit(ph, f3{ 0.0f, 0.0f, 0.0f });
+                reset_photon(state, ph, px, py, a, from0);
+            } else if (wheel < p_abs + p_scat) {
+                ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
+                ph.direction = sample_hg(state, a.anisotropy, ph.direction);
+                ph.bounces++;
+            }
         }
     }
 }
@@ -934,6 +979,38 @@ VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, 
         }
     }
 }
+template <int V>
+VPT_DEV void mcm_events_fast_early(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {     // see mcm_events_early
+    const FastPixel c = fast_pixel(a, px, py);
+    const float ld = -0.6931471805599453f * a.inv_extinction, ld32 = -32.0f * ld;
+    uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    for (uint32_t s = 0u; s < a.steps; s++) {
+        float dist = fmaf(hw_log2(pcg_float(state)), ld, ld32);
+        ph.position = madd3(ph.position, dist, ph.direction);
+        f3 q = ph.position;
+        bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+        const SampleLoads lds = mcm_sample_issue<V>(a, t, q, oob);
+        const uint32_t bounces = ph.bounces;
+        float wheel = pcg_float(state) * 0x1p-32f;
+        if (oob) {
+            float4 env = sample_environment(a.env, ph.direction);
+            fast_path_end(a, c, state, ph, f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z }, px, py);
+        }
+        float4 vs = mcm_sample_finish(a, t, lds);
+        float p_null = 1.0f - vs.w;
+        float p_scat = (bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
+        float p_abs = 1.0f - p_null - p_scat;
+        if (!oob) {
+            if (wheel < p_abs) {
+                fast_path_end(a, c, state, ph, f3{ 0.0f, 0.0f, 0.0f }, px, py);
+            } else if (wheel < p_abs + p_scat) {
+                ph.transmittance.x *= vs.x; ph.transmittance.y *= vs.y; ph.transmittance.z *= vs.z;
+                ph.direction = sample_hg_fast(state, a.anisotropy, ph.direction);
+                ph.bounces++;
+            }
+        }
+    }
+}
 // Photon state in HBM (MCMRenderer.js:214-263 keeps four RGBA32F attachments: [pos, 0] [dir, bounces] [T, 0] [radiance, samples]):
 // the two constant zeros are not stored — position and transmittance are 12-byte texels (one dwordx3 per lane, a wave's
 // 64 texels one contiguous 768-byte segment), direction+bounces and radiance+samples 16-byte texels: 56 bytes per pixel each
@@ -1029,6 +1106,25 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     Photon ph = photon_unpack(st);
     if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
     else mcm_events<V>(a, t, ph, px, py);
+    photon_store(a, p.k, ph);
+    if (FUSE_RENDER)
+        store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+}
+// the HIT-tile kernel with the early path end (mcm_events_early), compiled for 5 waves per SIMD: selected by the library for tile lists
+// short enough to be resident at once at that occupancy (shards)
+template <bool FUSE_RENDER, int V>
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) k_mcm_integrate_early(PassArgs a) {
+    apply_frame_table(a);
+    Pix p = map_pixel(a.pm);
+    PhotonState st;
+    if (p.tile) st = photon_load(a, p.k);
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    if (!p.valid) return;
+    float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
+    Photon ph = photon_unpack(st);
+    if (V & VPT_V_FAST) mcm_events_fast_early<V & ~VPT_V_FAST>(a, t, ph, px, py);
+    else mcm_events_early<V>(a, t, ph, px, py);
     photon_store(a, p.k, ph);
     if (FUSE_RENDER)
         store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
