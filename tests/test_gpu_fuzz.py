@@ -93,6 +93,10 @@ def random_case(seed):
 _SEEDS = range(*[int(v) for v in os.environ.get("VPT_FUZZ_SEEDS", "0:40").split(":")])
 # VPT_FUZZ_SPLIT=K: every case with VPT_OPTION_SPLIT_STREAMS = K; 1: none; default (-1): every third seed with three streams
 _SPLIT = int(os.environ.get("VPT_FUZZ_SPLIT", "-1"))
+# VPT_FUZZ_LAZY=1: every case compares its buffers after the LAST pass only (0: after every pass); default (-1): every third seed.
+# Between two reads the MCM tile classes leave the position / transmittance arrays of the cube-missing tiles behind and the ray marchers
+# launch the cube-crossing tiles only: a lazy case checks that what is read in the end is right all the same.
+_LAZY = int(os.environ.get("VPT_FUZZ_LAZY", "-1"))
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -165,9 +169,13 @@ def test_random_scene(gpu_ctx, oracle, kind, seed):
             same_rows(r.read(b), s, what + " reset buffer %d" % b)
     else:
         o.reset(oracle.make_frame(w, h, m))
-    for k in range(3):
+    lazy = _LAZY == 1 or (_LAZY < 0 and seed % 3 == 2)
+    npasses = 5 if lazy else 3
+    for k in range(npasses):
         r.render()
         o.render(frame_of(r._u))
+        if lazy and k + 1 < npasses:
+            continue
         if kind == "mcm":
             for b, s in zip(MCM_BUFFERS, o.state):
                 same_rows(r.read(b), s, what + " state %d pass %d" % (b, k))
