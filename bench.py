@@ -437,7 +437,7 @@ def main():
                 avg_ms = res["dt"] / args.steps * 1e3
             bps = B_ALG_MCM if args.renderer == "mcm" else 8.0
             achieved = bps * per_launch_samples / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            traffic, valu_busy, traffic_source = None, None, None
+            traffic, valu_busy, traffic_source, bound_override, bound_note = None, None, None, None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             classes = res.get("tile_classes")
             classified = bool(classes and classes[1] > 0)
@@ -447,6 +447,7 @@ def main():
                     key = "%s_%d_%dx%d_n%d%s%s" % (args.renderer, args.volume, W, H, world, "_fast" if args.fast_math else "", "_classes" if classified else "")
                     traffic = tj.get(key)
                     valu_busy = tj.get(key + "_valu_busy_frac")
+                    bound_override, bound_note = tj.get(key + "_bound"), tj.get(key + "_bound_source")
                     if traffic is not None:
                         traffic_source = tj.get(key + "_source", "profiles/traffic.json: committed rocprofv3 --pmc passes of this configuration (not measured in this run)")
                 except Exception:
@@ -513,10 +514,10 @@ def main():
                            "block_ms_median": res["dt"] * 1e3, "timed_block": "median of `repeats` blocks of `steps` steps"},
                 # `frac` prices the kernel against the HBM roofline by ALGORITHMIC bytes, as the metric is defined; what actually
                 # limits it is read off the PMC passes (profiles/): VALU issue (VALUBusy) for the MCM pass, not HBM
-                "roofline": {"bound": ("valu" if (valu_busy or 0) >= 0.7 else "hbm"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "roofline": {"bound": bound_override or ("valu" if (valu_busy or 0) >= 0.7 else "hbm"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "valu_busy_frac": valu_busy,
-                             "bound_source": "VALUBusy of the committed PMC passes (profiles/traffic.json): >= 0.7 reads as VALU-issue bound, the HBM roofline "
-                                             "is what `frac` prices the step against either way",
+                             "bound_source": bound_note or ("VALUBusy of the committed PMC passes (profiles/traffic.json): >= 0.7 reads as VALU-issue bound, the HBM "
+                                                            "roofline is what `frac` prices the step against either way"),
                              "peak_measured_stream_read": stream_gbs,
                              "frac_of_measured": (achieved / stream_gbs) if stream_gbs else None,
                              "kernel": kernel_name, "kernels": kernels,
