@@ -1158,42 +1158,55 @@ VPT_DEV const float4 *stage_tf(float4 *lds, const PassArgs &a) {
 }
 // the executed-and-discarded sample of an out-of-cube event: texture(uVolume, clamp(p)) through the boundary atlas, then the
 // transfer function (MCMRenderer.glsl:85-89,132).  Precondition (the tile class): p has a coordinate outside [0, 1].
+// In two phases, like mcm_sample: miss_sample_issue puts the atlas gather in flight, miss_sample_finish blends it and looks the
+// transfer function up; the event's path end (which needs the random stream only) sits between the two, under the load's latency.
+struct MissLoad { uint32_t aw; float fa, fb; };
 template <bool CHECK>
-VPT_DEV void miss_sample(const PassArgs &a, const float4 *tf, f3 q, unsigned long long *violations) {
-    float4 vs = sample_tf(tf, a.tf_fw, a.tf_hi, sample_volume_boundary(a.vol, q));
-    asm volatile("" : "+v"(vs.w));
+VPT_DEV MissLoad miss_sample_issue(const PassArgs &a, f3 q, unsigned long long *violations) {
+    MissLoad l;
+    l.aw = a.vol.atlas[boundary_cell(a.vol, q, l.fa, l.fb)];
     if (CHECK) {
         const bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
         if (!oob) atomicAdd(violations, 1ull);
     }
+    return l;
 }
-template <int V, bool CHECK>
+VPT_DEV void miss_sample_finish(const PassArgs &a, const float4 *tf, const MissLoad &l) {
+    float4 vs = sample_tf(tf, a.tf_fw, a.tf_hi, boundary_blend(l.aw, l.fa, l.fb));
+    asm volatile("" : "+v"(vs.w));
+}
+// LATE: the sample is consumed after the path end (under whose arithmetic its load flies) instead of right where the shader samples
+template <int V, bool CHECK, bool LATE>
 VPT_DEV void mcm_events_miss(const PassArgs &a, const float4 *tf, Photon &ph, float px, float py, f3 from0) {
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
     for (uint32_t s = 0u; s < a.steps; s++) {
         float dist = random_exponential(state, a.inv_extinction);
         ph.position = madd3(ph.position, dist, ph.direction);
-        miss_sample<CHECK>(a, tf, ph.position, a.violations);
+        const MissLoad l = miss_sample_issue<CHECK>(a, ph.position, a.violations);
+        if (!LATE) miss_sample_finish(a, tf, l);
         random_uniform(state);                                     // the wheel draw (its value decides nothing out of bounds)
         float4 env = sample_environment(a.env, ph.direction);      // transmittance is (1, 1, 1): radiance = 1 * env, exactly env
         photon_deposit(ph, f3{ env.x, env.y, env.z });
         reset_photon<true>(state, ph, px, py, a, from0);
+        if (LATE) miss_sample_finish(a, tf, l);
     }
 }
-template <int V, bool CHECK>
+template <int V, bool CHECK, bool LATE>
 VPT_DEV void mcm_events_miss_fast(const PassArgs &a, const float4 *tf, const FastPixel &c, Photon &ph, float px, float py) {
     const float ld = -0.6931471805599453f * a.inv_extinction, ld32 = -32.0f * ld;
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
     for (uint32_t s = 0u; s < a.steps; s++) {
         float dist = fmaf(hw_log2(pcg_float(state)), ld, ld32);
         ph.position = madd3(ph.position, dist, ph.direction);
-        miss_sample<CHECK>(a, tf, ph.position, a.violations);
+        const MissLoad l = miss_sample_issue<CHECK>(a, ph.position, a.violations);
+        if (!LATE) miss_sample_finish(a, tf, l);
         state = pcg(state);                                        // the wheel draw
         float4 env = sample_environment(a.env, ph.direction);
         fast_path_end<true>(a, c, state, ph, f3{ env.x, env.y, env.z }, px, py);
+        if (LATE) miss_sample_finish(a, tf, l);
     }
 }
-template <bool FUSE_RENDER, int V, bool CHECK>
+template <bool FUSE_RENDER, int V, bool CHECK, bool LATE>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_mcm_miss(PassArgs a) {
     apply_frame_table(a);
     Pix p = map_pixel(a.pm);
@@ -1216,11 +1229,11 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     if (V & VPT_V_FAST) {
         const FastPixel c = fast_pixel(a, px, py);
         ph.position = a.miss_load_pos ? s0 : photon_start_fast(c.from0, ph.direction);
-        mcm_events_miss_fast<V & ~VPT_V_FAST, CHECK>(a, tf, c, ph, px, py);
+        mcm_events_miss_fast<V & ~VPT_V_FAST, CHECK, LATE>(a, tf, c, ph, px, py);
     } else {
         const f3 from0 = unproject_near(px, py, a);
         ph.position = a.miss_load_pos ? s0 : photon_start(from0, ph.direction);
-        mcm_events_miss<V, CHECK>(a, tf, ph, px, py, from0);
+        mcm_events_miss<V, CHECK, LATE>(a, tf, ph, px, py, from0);
     }
     a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
     a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
