@@ -53,6 +53,9 @@ extern "C" {
                                   * blocks are uploaded as float32 */
 #define VPT_FORMAT_RG8 1         /* format RG, internalFormat RG8, type UNSIGNED_BYTE: two interleaved channels, texture(uVolume, p).rg
                                   * has both and the transfer function is looked up in 2-D (MIPRenderer.glsl:45-49) */
+#define VPT_FORMAT_RG32F 3       /* format RG, internalFormat RG32F (or RG16F widened on upload), type FLOAT / HALF_FLOAT: two interleaved float
+                                  * channels (Volume.js:58-60 allocates whatever internalFormat the manifest names); blocks are uploaded as
+                                  * interleaved float32 pairs */
 
 /* Buffers readable through vpt_renderer_read (SingleBuffer.js / DoubleBuffer.js attachments) */
 #define VPT_BUFFER_RENDER 0      /* RGBA16F, 8 B/pixel  (AbstractRenderer.js:142-155, getTexture() :114-116) */

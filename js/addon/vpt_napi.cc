@@ -456,7 +456,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     CONST(VPT_PLAY_EAGER); CONST(VPT_PLAY_GRAPH); CONST(VPT_PLAY_FUSED); CONST(VPT_PLAY_FRAMES); CONST(VPT_FRAME_SLOTS);
     CONST(VPT_RENDERER_MIP); CONST(VPT_RENDERER_EAM); CONST(VPT_RENDERER_MCS); CONST(VPT_RENDERER_MCM);
     CONST(VPT_RENDERER_ISO); CONST(VPT_RENDERER_DEPTH); CONST(VPT_RENDERER_LAO); CONST(VPT_RENDERER_DOS); CONST(VPT_BUFFER_DOS_OCCLUSION);
-    CONST(VPT_FILTER_NEAREST); CONST(VPT_FILTER_LINEAR); CONST(VPT_FORMAT_R8); CONST(VPT_FORMAT_RG8); CONST(VPT_FORMAT_R32F);
+    CONST(VPT_FILTER_NEAREST); CONST(VPT_FILTER_LINEAR); CONST(VPT_FORMAT_R8); CONST(VPT_FORMAT_RG8); CONST(VPT_FORMAT_R32F); CONST(VPT_FORMAT_RG32F);
     CONST(VPT_BUFFER_RENDER); CONST(VPT_BUFFER_FRAME); CONST(VPT_BUFFER_ACCUM);
     CONST(VPT_BUFFER_MCM_POSITION); CONST(VPT_BUFFER_MCM_DIRECTION); CONST(VPT_BUFFER_MCM_TRANSMITTANCE); CONST(VPT_BUFFER_MCM_RADIANCE);
     napi_set_named_property(env, exports, "UNIFORMS_BYTES", number(env, (double)sizeof(vpt_uniforms)));

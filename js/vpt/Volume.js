@@ -22,8 +22,9 @@ function deviceFormat(N, modality) {
         const n = f === GL_RED ? 1 : (f === GL_RG ? 2 : (f === GL_RGB ? 3 : 4));
         return { fmt: n === 1 ? N.VPT_FORMAT_R8 : N.VPT_FORMAT_RG8, channels: n, kind: 'u8' };
     }
-    if ((t === GL_FLOAT || t === GL_HALF_FLOAT) && f === GL_RED) {
-        return { fmt: N.VPT_FORMAT_R32F, channels: 1, kind: t === GL_FLOAT ? 'f32' : 'f16' };
+    if ((t === GL_FLOAT || t === GL_HALF_FLOAT) && (f === GL_RED || f === GL_RG || f === GL_RGB || f === GL_RGBA)) {
+        const n = f === GL_RED ? 1 : (f === GL_RG ? 2 : (f === GL_RGB ? 3 : 4));
+        return { fmt: n === 1 ? N.VPT_FORMAT_R32F : N.VPT_FORMAT_RG32F, channels: n, kind: t === GL_FLOAT ? 'f32' : 'f16' };
     }
     throw new Error('Unknown volume datatype: ' + t);
 }
@@ -37,10 +38,20 @@ function blockBytes(data, df) {
         for (let i = 0; i < n; i++) { out[2 * i] = u8[df.channels * i]; out[2 * i + 1] = u8[df.channels * i + 1]; }
         return out;
     }
-    if (df.kind === 'f32') { return u8; }
-    const h = new Uint16Array(u8.buffer.slice(u8.byteOffset, u8.byteOffset + u8.byteLength));
-    const f = new Float32Array(h.length);
-    for (let i = 0; i < h.length; i++) { f[i] = halfToFloat(h[i]); }
+    // float texels: float32 (half widened exactly), at most two channels (the shaders read .rg)
+    let f;
+    if (df.kind === 'f32') {
+        f = new Float32Array(u8.buffer.slice(u8.byteOffset, u8.byteOffset + u8.byteLength));
+    } else {
+        const h = new Uint16Array(u8.buffer.slice(u8.byteOffset, u8.byteOffset + u8.byteLength));
+        f = new Float32Array(h.length);
+        for (let i = 0; i < h.length; i++) { f[i] = halfToFloat(h[i]); }
+    }
+    if (df.channels > 2) {
+        const n = f.length / df.channels, out = new Float32Array(2 * n);
+        for (let i = 0; i < n; i++) { out[2 * i] = f[df.channels * i]; out[2 * i + 1] = f[df.channels * i + 1]; }
+        f = out;
+    }
     return new Uint8Array(f.buffer);
 }
 

@@ -74,6 +74,9 @@ def random_case(seed):
         vol = (vol.astype(np.float32) / np.float32(255.0) * np.float32(frng.uniform(0.5, 1.6)) + np.float32(frng.uniform(-0.3, 0.2))).astype(np.float32)
         if frng.uniform() < 0.5:
             vol = vol.astype(np.float16).astype(np.float32)
+        if seed % 10 == 7:                             # two float channels (RG32F): both filtered, the transfer function looked up in 2-D
+            second = (frng.uniform(-0.2, 1.3, size=vol.shape)).astype(np.float32)
+            vol = np.ascontiguousarray(np.stack([vol, second], axis=-1))
     w, h = int(rng.integers(1, 200)), int(rng.integers(1, 140))
     tf_w, tf_h = int(rng.choice([1, 2, 3, 7, 64, 256])), int(rng.choice([1, 1, 3, 16]))
     tf = rng.integers(0, 256, size=(tf_h, tf_w, 4), dtype=np.uint8)

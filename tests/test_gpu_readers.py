@@ -166,11 +166,12 @@ def make_bvp_typed(arr, fmt, ifmt, gltype, cuts):
     return bio.getvalue()
 
 
-@pytest.mark.parametrize("case", ["r32f", "r16f", "rgba8", "rgb8"])
+@pytest.mark.parametrize("case", ["r32f", "r16f", "rgba8", "rgb8", "rg32f", "rgba16f"])
 def test_float_and_multichannel_manifests(gpu_ctx, oracle, case):
     """Volume.js:58-60 allocates whatever internalFormat the manifest names, :84-105 maps the GL type: R32F / R16F volumes
-    (FLOAT / HALF_FLOAT, filtered LINEAR) and RGBA8 / RGB8 (the shaders read .rg) through a BVP with partial blocks must render
-    exactly like the same texels uploaded as one array — and like the oracle"""
+    (FLOAT / HALF_FLOAT, filtered LINEAR), RGBA8 / RGB8 (the shaders read .rg) and two- / four-channel float volumes (RG32F;
+    RGBA16F keeps its first two channels, widened) through a BVP with partial blocks must render exactly like the same texels
+    uploaded as one array — and like the oracle"""
     from vpt_amd.readers import GL_RED, GL_R32F, GL_R16F, GL_FLOAT, GL_HALF_FLOAT, GL_RGBA, GL_RGBA8, GL_RGB, GL_RGB8, GL_UNSIGNED_BYTE
     rng = np.random.default_rng(11)
     base = sphere_volume(0, noise=35.0, dims=(19, 26, 23))
@@ -182,6 +183,17 @@ def test_float_and_multichannel_manifests(gpu_ctx, oracle, case):
         else:
             stored = texels = f
             archive = make_bvp_typed(stored, GL_RED, GL_R32F, GL_FLOAT, ((9,), (11, 20), (7,)))
+    elif case in ("rg32f", "rgba16f"):
+        nch = 2 if case == "rg32f" else 4
+        f = (base.astype(np.float32) / np.float32(255) * np.float32(1.3) - np.float32(0.1)).astype(np.float32)
+        stored = rng.uniform(-0.2, 1.2, size=base.shape + (nch,)).astype(np.float32)
+        stored[..., 0] = f
+        if case == "rgba16f":
+            stored = stored.astype(np.float16)
+            archive = make_bvp_typed(stored, GL_RGBA, 0x881A, GL_HALF_FLOAT, ((9,), (11, 20), (7,)))        # RGBA16F
+        else:
+            archive = make_bvp_typed(stored, 0x8227, 0x8230, GL_FLOAT, ((9,), (11, 20), (7,)))              # RG, RG32F
+        texels = np.ascontiguousarray(stored[..., :2].astype(np.float32))
     else:
         nch = 4 if case == "rgba8" else 3
         stored = rng.integers(0, 256, size=base.shape + (nch,), dtype=np.uint8)

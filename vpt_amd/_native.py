@@ -21,7 +21,7 @@ PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED, PLAY_FRAMES = 0, 1, 2, 3
 FRAME_SLOTS = 16
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO, RENDERER_DOS = 0, 1, 2, 3, 4, 5, 6, 7
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
-FORMAT_R8, FORMAT_RG8, FORMAT_R32F = 0, 1, 2
+FORMAT_R8, FORMAT_RG8, FORMAT_R32F, FORMAT_RG32F = 0, 1, 2, 3
 BUFFER_RENDER, BUFFER_FRAME, BUFFER_ACCUM = 0, 1, 2
 BUFFER_MCM_POSITION, BUFFER_MCM_DIRECTION, BUFFER_MCM_TRANSMITTANCE, BUFFER_MCM_RADIANCE = 3, 4, 5, 6
 BUFFER_DOS_OCCLUSION = 7

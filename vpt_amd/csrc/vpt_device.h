@@ -461,19 +461,27 @@ VPT_DEV f2 sample_volume_rg(const DevVolume &v, const LdsTables &t, f3 p) {
         // x -> y -> z lerps, the value is used as it is (no normalisation)
         if (V & VPT_V_NEAREST) {
             uint32_t x = nearest_cell(p.x, v.fnx, v.hx), y = nearest_cell(p.y, v.fny, v.hy), z = nearest_cell(p.z, v.fnz, v.hz);
-            return f2{ *(const float *)cell_addr<WIDE>(v, t, x, y, z), 0.0f };
+            const float *b = (const float *)cell_addr<WIDE>(v, t, x, y, z);
+            return f2{ b[0], RG ? b[128] : 0.0f };                          // (two channels: the G brick sits 128 floats behind the R brick)
         }
         uint32_t x, y, z; float fx, fy, fz;
         linear_cell(p.x, v.fnx, v.hx, x, fx);
         linear_cell(p.y, v.fny, v.hy, y, fy);
         linear_cell(p.z, v.fnz, v.hz, z, fz);
-        const float *b = (const float *)cell_addr<WIDE>(v, t, x, y, z);
-        // (the taps are dword-aligned, not 8-byte aligned: loaded through memcpy — still one global_load_dwordx2 each)
-        float2 r00, r10, r01, r11;
-        __builtin_memcpy(&r00, b, 8); __builtin_memcpy(&r10, b + 5, 8); __builtin_memcpy(&r01, b + 25, 8); __builtin_memcpy(&r11, b + 30, 8);
-        float c00 = lerpf(r00.x, r00.y, fx), c10 = lerpf(r10.x, r10.y, fx);
-        float c01 = lerpf(r01.x, r01.y, fx), c11 = lerpf(r11.x, r11.y, fx);
-        return f2{ lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz), 0.0f };
+        const float *b0 = (const float *)cell_addr<WIDE>(v, t, x, y, z);
+        f2 out = { 0.0f, 0.0f };
+#pragma unroll
+        for (int c = 0; c < (RG ? 2 : 1); c++) {
+            const float *b = b0 + 128 * c;
+            // (the taps are dword-aligned, not 8-byte aligned: loaded through memcpy — still one global_load_dwordx2 each)
+            float2 r00, r10, r01, r11;
+            __builtin_memcpy(&r00, b, 8); __builtin_memcpy(&r10, b + 5, 8); __builtin_memcpy(&r01, b + 25, 8); __builtin_memcpy(&r11, b + 30, 8);
+            float c00 = lerpf(r00.x, r00.y, fx), c10 = lerpf(r10.x, r10.y, fx);
+            float c01 = lerpf(r01.x, r01.y, fx), c11 = lerpf(r11.x, r11.y, fx);
+            const float val = lerpf(lerpf(c00, c10, fy), lerpf(c01, c11, fy), fz);
+            if (c == 0) out.x = val; else out.y = val;
+        }
+        return out;
     }
     if (V & VPT_V_NEAREST) {
         uint32_t x = nearest_cell(p.x, v.fnx, v.hx), y = nearest_cell(p.y, v.fny, v.hy), z = nearest_cell(p.z, v.fnz, v.hz);

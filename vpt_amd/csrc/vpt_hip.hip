@@ -218,17 +218,18 @@ extern "C" int vpt_context_synchronize(vpt_context *c) {
 // ---------------------------------------------------------------------------------------------
 extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format, vpt_volume **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
-    if (format != VPT_FORMAT_R8 && format != VPT_FORMAT_RG8 && format != VPT_FORMAT_R32F) return fail(VPT_ERR_UNSUPPORTED, "Unknown volume datatype: %d", format);  // Volume.js:103
+    if (format != VPT_FORMAT_R8 && format != VPT_FORMAT_RG8 && format != VPT_FORMAT_R32F && format != VPT_FORMAT_RG32F) return fail(VPT_ERR_UNSUPPORTED, "Unknown volume datatype: %d", format);  // Volume.js:103
     if (w < 1 || h < 1 || d < 1 || w > 4096 || h > 4096 || d > 4096)
         return fail(VPT_ERR_INVALID, "volume dimensions %dx%dx%d out of range [1,4096]", w, h, d);
     HIP_TRY(hipSetDevice(c->device));
     vpt_volume *v = new vpt_volume();
     memset(v, 0, sizeof(*v));
     v->ctx = c; v->nx = w; v->ny = h; v->nz = d;
-    v->channels = format == VPT_FORMAT_RG8 ? 2 : 1;
-    v->f32 = format == VPT_FORMAT_R32F;
+    v->channels = (format == VPT_FORMAT_RG8 || format == VPT_FORMAT_RG32F) ? 2 : 1;
+    v->f32 = format == VPT_FORMAT_R32F || format == VPT_FORMAT_RG32F;
     v->vox_bytes = v->channels * (v->f32 ? 4 : 1);
-    const int slot_shift = v->f32 ? 9 : (v->channels == 2 ? 8 : 7);   // RG8: 256-byte slots (R brick at +0, G brick at +128); R32F: 512-byte slots
+    // RG8: 256-byte slots (R brick at +0, G brick at +128); R32F: 512-byte slots; RG32F: 1024-byte slots (G brick at +512)
+    const int slot_shift = (v->f32 ? 9 : 7) + (v->channels == 2 ? 1 : 0);
     const uint64_t eb = v->f32 ? 4 : 1;                  // bytes per texel channel
     v->filter = VPT_FILTER_LINEAR;                       // Volume.js:53-54
     int nbx = (w + 3) / 4, nby = (h + 3) / 4, nbz = (d + 3) / 4;
@@ -332,7 +333,7 @@ extern "C" int vpt_volume_finalize(vpt_volume *v) {
     // one-channel volumes with dword-aligned rows go through the LDS-staged kernel (dword loads and stores)
     int fast = (v->channels == 1 && v->nx % 4 == 0) ? strips : 0;
     if (v->f32) {
-        hipLaunchKernelGGL(k_brickify_f32, dim3((unsigned)strips, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, (const float *)v->linear, (float *)v->bricks, v->nx, v->ny, v->nz, v->tabc);
+        hipLaunchKernelGGL(k_brickify_f32, dim3((unsigned)strips, (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, (const float *)v->linear, (float *)v->bricks, v->nx, v->ny, v->nz, v->channels, v->tabc);
         fast = strips;                                    // nothing left for the byte kernels
     } else if (fast > 0)
         hipLaunchKernelGGL(k_brickify_strip, dim3((unsigned)fast, (unsigned)((nby + VPT_BRICKIFY_ROWS - 1) / VPT_BRICKIFY_ROWS), (unsigned)((nbz + VPT_BRICKIFY_ROWS - 1) / VPT_BRICKIFY_ROWS)), dim3(256), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->tabc);
@@ -726,7 +727,7 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         a->vol.hx = (float)(v->nx - 1); a->vol.hy = (float)(v->ny - 1); a->vol.hz = (float)(v->nz - 1);
         a->vol.tab32 = v->tab32; a->vol.tabc = v->tabc;
         a->vol.filter = v->filter;
-        a->vol.channels = v->channels; a->vol.slot_shift = v->f32 ? 9u : (v->channels == 2 ? 8u : 7u);
+        a->vol.channels = v->channels; a->vol.slot_shift = (v->f32 ? 9u : 7u) + (v->channels == 2 ? 1u : 0u);
         a->vol.elem_shift = v->f32 ? 2u : 0u;
         a->vol.atlas = r->boundary_atlas ? v->atlas : nullptr;
         a->vol.atlas_face = v->atlas_face; a->vol.atlas_shift = v->atlas_shift;
@@ -863,7 +864,11 @@ static int variant_of(const vpt_renderer *r) {
         case 32: VPT_TRY(launch_sampling(KT(32), (r), (a), g_)); break; \
         case 33: VPT_TRY(launch_sampling(KT(33), (r), (a), g_)); break; \
         case 34: VPT_TRY(launch_sampling(KT(34), (r), (a), g_)); break; \
-        default: VPT_TRY(launch_sampling(KT(35), (r), (a), g_)); break; \
+        case 35: VPT_TRY(launch_sampling(KT(35), (r), (a), g_)); break; \
+        case 40: VPT_TRY(launch_sampling(KT(40), (r), (a), g_)); break; \
+        case 41: VPT_TRY(launch_sampling(KT(41), (r), (a), g_)); break; \
+        case 42: VPT_TRY(launch_sampling(KT(42), (r), (a), g_)); break; \
+        default: VPT_TRY(launch_sampling(KT(43), (r), (a), g_)); break; \
     } } while (0)
 // (dword-aligned 12-byte taps + v_alignbyte for MIP / EAM — re-measured in round 3 on the HIT tiles only, 256^3 1080p: EAM 63.7 us
 // aligned against 72.3 unaligned on one stream, 52.1 / 63.3 on three; MIP 56.3 / 72.0, 45.1 / 64.1)
@@ -1401,7 +1406,11 @@ static int launch_mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses
         case 32: return ring ? launch_frames(k_mcm_frames<32 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<32 | F>, r, a, npasses); \
         case 33: return ring ? launch_frames(k_mcm_frames<33 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<33 | F>, r, a, npasses); \
         case 34: return ring ? launch_frames(k_mcm_frames<34 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<34 | F>, r, a, npasses); \
-        default: return ring ? launch_frames(k_mcm_frames<35 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<35 | F>, r, a, npasses); }
+        case 35: return ring ? launch_frames(k_mcm_frames<35 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<35 | F>, r, a, npasses); \
+        case 40: return ring ? launch_frames(k_mcm_frames<40 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<40 | F>, r, a, npasses); \
+        case 41: return ring ? launch_frames(k_mcm_frames<41 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<41 | F>, r, a, npasses); \
+        case 42: return ring ? launch_frames(k_mcm_frames<42 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<42 | F>, r, a, npasses); \
+        default: return ring ? launch_frames(k_mcm_frames<43 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<43 | F>, r, a, npasses); }
     if (r->fast_math) MULTI_CASES(VPT_V_FAST)
     MULTI_CASES(0)
 #undef MULTI_CASES
@@ -1653,7 +1662,11 @@ static int launch_dos(vpt_renderer *r, PassArgs &a, const int rect[4]) {
         case 32: return launch_dos_slice(k_dos_slice<32>, r, a, rect);
         case 33: return launch_dos_slice(k_dos_slice<33>, r, a, rect);
         case 34: return launch_dos_slice(k_dos_slice<34>, r, a, rect);
-        default: return launch_dos_slice(k_dos_slice<35>, r, a, rect);
+        case 35: return launch_dos_slice(k_dos_slice<35>, r, a, rect);
+        case 40: return launch_dos_slice(k_dos_slice<40>, r, a, rect);
+        case 41: return launch_dos_slice(k_dos_slice<41>, r, a, rect);
+        case 42: return launch_dos_slice(k_dos_slice<42>, r, a, rect);
+        default: return launch_dos_slice(k_dos_slice<43>, r, a, rect);
     }
 }
 // _integrateFrame of the DOS renderer (DOSRenderer.js:199-259): `count` full-screen passes, pass s with
@@ -1866,7 +1879,11 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
             case 32: hipLaunchKernelGGL(k_probe_sample<32>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
             case 33: hipLaunchKernelGGL(k_probe_sample<33>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
             case 34: hipLaunchKernelGGL(k_probe_sample<34>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            default: hipLaunchKernelGGL(k_probe_sample<35>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 35: hipLaunchKernelGGL(k_probe_sample<35>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 40: hipLaunchKernelGGL(k_probe_sample<40>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 41: hipLaunchKernelGGL(k_probe_sample<41>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 42: hipLaunchKernelGGL(k_probe_sample<42>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            default: hipLaunchKernelGGL(k_probe_sample<43>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
         }
         e = hipGetLastError();
     }

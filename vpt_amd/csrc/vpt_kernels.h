@@ -1424,9 +1424,10 @@ __global__ void __launch_bounds__(256) k_brickify_strip(const uint8_t *lin, uint
     }
 }
 
-// FLOAT volumes: linear floats -> 5^3-float apron bricks in 512-byte slots (slot = brick code << 9); VPT_BRICKIFY_RUN bricks of a
-// brick row per workgroup, thread t < 125 carries local voxel t of each
-__global__ void __launch_bounds__(128) k_brickify_f32(const float *lin, float *bricks, int nx, int ny, int nz, const uint32_t *codes) {
+// FLOAT volumes: linear floats -> 5^3-float apron bricks in 512-byte slots (slot = brick code << 9; two channels: 1024-byte slots,
+// the G brick 512 bytes behind the R brick); VPT_BRICKIFY_RUN bricks of a brick row per workgroup, thread t < 125 carries local
+// voxel t of each
+__global__ void __launch_bounds__(128) k_brickify_f32(const float *lin, float *bricks, int nx, int ny, int nz, int ch, const uint32_t *codes) {
     const int by = (int)blockIdx.y, bz = (int)blockIdx.z, t = (int)threadIdx.x;
     if (t >= 125) return;
     const int nbx = (nx + VPT_BRICK - 1) / VPT_BRICK;
@@ -1434,11 +1435,13 @@ __global__ void __launch_bounds__(128) k_brickify_f32(const float *lin, float *b
     const int y = min(by * VPT_BRICK + ly, ny - 1), z = min(bz * VPT_BRICK + lz, nz - 1);
     const size_t row = ((size_t)z * ny + y) * nx;
     const uint32_t cyz = codes[nx + 4 * by] + codes[nx + ny + 4 * bz];
+    const int shift = ch == 2 ? 8 : 7;                                          // floats per slot: 128 or 256
     for (int u = 0; u < VPT_BRICKIFY_RUN; u++) {
         int bx = (int)blockIdx.x * VPT_BRICKIFY_RUN + u;
         if (bx >= nbx) break;
         int x = min(bx * VPT_BRICK + lx, nx - 1);
-        bricks[((size_t)(codes[4 * bx] + cyz) << 7) + t] = lin[row + x];       // 128 floats per slot
+        const size_t slot = (size_t)(codes[4 * bx] + cyz) << shift;
+        for (int c = 0; c < ch; c++) bricks[slot + (size_t)c * 128 + t] = lin[(row + x) * ch + c];
     }
 }
 

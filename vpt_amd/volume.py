@@ -14,15 +14,16 @@ from .readers import (RAWReader, GL_RED, GL_R8, GL_RG, GL_RG8, GL_UNSIGNED_BYTE,
 def device_format(modality):
     """(native format, channels in the file, numpy dtype of a block) for a manifest's (format, type) — Volume.js:58-60 allocates whatever
     internalFormat the manifest names and :84-105 `_typize` maps the GL type to a typed array.  What a WebGL2 sampler3D can
-    filter is what is taken here: UNSIGNED_BYTE with 1-4 channels (the shaders read .rg: channels past the second are
-    dropped on upload) and FLOAT / HALF_FLOAT with one channel (R32F / R16F; half widens to float exactly).  Integer and
-    16-bit normalised types cannot be sampled through a float sampler in WebGL2 and raise the reference's error."""
+    filter is what is taken here: UNSIGNED_BYTE and FLOAT / HALF_FLOAT (half widens to float exactly) with 1-4 channels — the
+    shaders read .rg, so channels past the second are dropped on upload (R8, RG8; R32F, RG32F).  Integer and 16-bit normalised
+    types cannot be sampled through a float sampler in WebGL2 and raise the reference's error."""
     t, f = modality['type'], modality['format']
     if t == GL_UNSIGNED_BYTE and f in (GL_RED, GL_RG, GL_RGB, GL_RGBA):
         n = {GL_RED: 1, GL_RG: 2, GL_RGB: 3, GL_RGBA: 4}[f]
         return (N.FORMAT_R8 if n == 1 else N.FORMAT_RG8), n, np.uint8
-    if t in (GL_FLOAT, GL_HALF_FLOAT) and f == GL_RED:
-        return N.FORMAT_R32F, 1, (np.float32 if t == GL_FLOAT else np.float16)
+    if t in (GL_FLOAT, GL_HALF_FLOAT) and f in (GL_RED, GL_RG, GL_RGB, GL_RGBA):
+        n = {GL_RED: 1, GL_RG: 2, GL_RGB: 3, GL_RGBA: 4}[f]
+        return (N.FORMAT_R32F if n == 1 else N.FORMAT_RG32F), n, (np.float32 if t == GL_FLOAT else np.float16)
     raise RuntimeError('Unknown volume datatype: %s' % t)                   # Volume.js:103
 
 
@@ -100,19 +101,20 @@ class Volume(EventTarget):
     # ---- extension: whole-array upload (one block) for synthetic volumes ----
     @classmethod
     def from_array(cls, gl, array, filter='linear'):
-        """Upload a [depth][height][width] (R8; float16 / float32: R32F) or [depth][height][width][2] (RG8) array (host -> HBM once)."""
+        """Upload a [depth][height][width] (uint8: R8; float16 / float32: R32F) or [depth][height][width][2] (RG8 / RG32F) array (host -> HBM once)."""
         array = np.asarray(array)
         f32 = array.dtype.kind == 'f'
         array = np.ascontiguousarray(array, dtype=np.float32 if f32 else np.uint8)
-        if array.ndim == 4 and (array.shape[3] != 2 or f32):
-            raise ValueError('a two-channel volume is [depth][height][width][2] uint8')
+        if array.ndim == 4 and array.shape[3] != 2:
+            raise ValueError('a two-channel volume is [depth][height][width][2]')
         d, h, w = array.shape[:3]
         channels = 2 if array.ndim == 4 else 1
         vox = channels * (4 if f32 else 1)
         vol = cls(gl, RAWReader(array.view(np.uint8), {'width': w * vox, 'height': h, 'depth': d}))      # slices of w * vox bytes
         L = N.lib()
         hnd = C.c_void_p()
-        N.check(L.vpt_volume_create(gl._h, w, h, d, N.FORMAT_R32F if f32 else (N.FORMAT_RG8 if channels == 2 else N.FORMAT_R8), C.byref(hnd)))
+        fmt = (N.FORMAT_RG32F if channels == 2 else N.FORMAT_R32F) if f32 else (N.FORMAT_RG8 if channels == 2 else N.FORMAT_R8)
+        N.check(L.vpt_volume_create(gl._h, w, h, d, fmt, C.byref(hnd)))
         vol.texture = hnd
         # chunk along z so one call stays < 2 GiB
         zs = max(1, (1 << 30) // (w * h * vox))
@@ -125,7 +127,9 @@ class Volume(EventTarget):
         vol.modality = vol.metadata['modalities'][0]
         if vox > 1:                                         # the slices were handed over as w * vox bytes wide: restore the description
             vol.modality['dimensions']['width'] = w
-            if f32:
+            if f32 and channels == 2:
+                vol.modality['format'], vol.modality['internalFormat'], vol.modality['type'] = GL_RG, 0x8230, GL_FLOAT      # RG32F
+            elif f32:
                 vol.modality['format'], vol.modality['internalFormat'], vol.modality['type'] = GL_RED, GL_R32F, GL_FLOAT
             else:
                 vol.modality['format'], vol.modality['internalFormat'] = GL_RG, GL_RG8
