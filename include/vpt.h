@@ -169,6 +169,10 @@ VPT_API int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u);
 VPT_API int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int mode);
 /* frame `slot` of the last VPT_PLAY_FRAMES call ([local rows][width][4] RGBA16F), and the ring's device address (extensions: the
  * reference renders one frame per animation tick, AbstractRenderer.js:60-70, and has no frame sequences) */
+/* (extension) `count` eager render() passes by one call, frame i written to caller-owned device memory at first_target + i * stride_bytes
+ * (e.g. the slots of a bucket one collective will move); frame_vars as for vpt_renderer_play.  Equivalent to `count` times
+ * { vpt_renderer_set_render_target; vpt_renderer_render }; the same stream rules apply (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join) */
+VPT_API int vpt_renderer_play_into(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, void *first_target, size_t stride_bytes);
 VPT_API int vpt_renderer_read_frame_slot(vpt_renderer *r, int slot, void *host_dst, size_t nbytes);
 VPT_API int vpt_renderer_frame_ring_device(vpt_renderer *r, void **device_ptr, size_t *slot_bytes);
 

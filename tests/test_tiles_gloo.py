@@ -57,6 +57,30 @@ WORKER = textwrap.dedent("""
                 assert (img[:, :, 2] == frame).all(), (F, frame)
                 assert (g.last_sent()[torch.as_tensor(lrow)[mine], :, 2] == frame).all()
         g.flush(); g.wait_all()
+    # whole buckets at once (acquire_bucket / commit_bucket: what bench.py pairs with vpt_renderer_play_into), mixed with single frames
+    F = 4
+    g = FrameGather(dist, torch, W, H, torch.device("cpu"), frames_per_gather=F)
+    owner, lrow = row_owner(H, world, 8)
+    mine = torch.as_tensor(np.nonzero(owner == rank)[0])
+    rows_mine = torch.as_tensor(lrow)[mine]
+    frame = 0
+    for step in range(5):
+        bucket = g.acquire_bucket()
+        assert bucket is not None and bucket.shape == (F, g.rows, W, 4)
+        bucket.zero_()
+        for j in range(F):
+            bucket[j][rows_mine, :, 0] = mine.to(torch.float16)[:, None]
+            bucket[j][rows_mine, :, 2] = frame + j
+        g.commit_bucket()
+        frame += F
+        img = g.last_frame()
+        assert (img[:, :, 0] == torch.arange(H, dtype=torch.float16)[:, None]).all() and (img[:, :, 2] == frame - 1).all(), step
+        if step == 2:                                         # two single frames open a bucket: no whole bucket until it is flushed
+            for _ in range(2):
+                t = g.acquire(); t.zero_(); t[rows_mine, :, 2] = frame; g.commit(); frame += 1
+            assert g.acquire_bucket() is None
+            assert (g.last_frame()[:, :, 2] == frame - 1).all()     # (flushes the partial bucket)
+    g.flush(); g.wait_all()
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Host cost per frame of the torch.distributed gather pipeline (the N > 1 default of bench.py) on a one-rank RCCL group, with
-frames of a 1/8 shard's size: where do the microseconds of the host loop go?"""
+"""Host cost of the torch.distributed gather pipeline (the N > 1 default of bench.py) on a one-rank RCCL group, with frames of a 1/8
+shard's size and whole frames, bucket by bucket as bench.py drives it (acquire_bucket -> vpt_renderer_play_into -> join ->
+all_gather of the bucket): where do the microseconds of the host loop go?"""
 import json
 import os
 import sys
@@ -23,38 +24,40 @@ def main():
     device = torch.device("cuda", 0)
     dist.init_process_group("nccl", device_id=device)
     out = {}
-    for H in (136, 1080):
-        W = 1920
-        ctx = vpt_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-        gvol = vpt_amd.Volume.from_array(ctx, sphere_volume(512, noise=48.0), 'linear')
-        r = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng(), 'shard': (0, 1, 8)})
-        r.set_option(N.OPTION_FAST_MATH, 1); r.reset()
-        gather = FrameGather(dist, torch, W, H, device, always_collective=True)
-        nbytes = gather.send[0].numel() * 2
-        acc = {"wait": 0.0, "target": 0.0, "render": 0.0, "gather": 0.0}
-        n = 600
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        for H in (136, 1080):
+            W, F = 1920, int(os.environ.get("VPT_PROBE_F", "4"))
+            ctx = vpt_amd.Context(0, stream=stream.cuda_stream)
+            gvol = vpt_amd.Volume.from_array(ctx, sphere_volume(512, noise=48.0), 'linear')
+            r = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng(), 'shard': (0, 1, 8)})
+            r.set_option(N.OPTION_FAST_MATH, 1); r.set_option(N.OPTION_SPLIT_STREAMS, 2); r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
+            r.reset()
+            gather = FrameGather(dist, torch, W, H, device, always_collective=True, frames_per_gather=F)
+            nbytes = gather.send[0].numel() * 2
+            acc = {"acquire": 0.0, "play_into": 0.0, "join": 0.0, "commit": 0.0}
+            n = 300
 
-        def frame(k, timing):
-            b = k & 1
-            t0 = time.perf_counter(); gather.wait(b)
-            t1 = time.perf_counter(); r.set_render_target(gather.send[b].data_ptr(), nbytes)
-            t2 = time.perf_counter(); r.render()
-            t3 = time.perf_counter(); gather.gather(b)
-            t4 = time.perf_counter()
-            if timing:
-                acc["wait"] += t1 - t0; acc["target"] += t2 - t1; acc["render"] += t3 - t2; acc["gather"] += t4 - t3
-        for k in range(100):
-            frame(k, False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(n):
-            frame(k, True)
-        host = time.perf_counter() - t0
-        gather.wait(0); gather.wait(1); torch.cuda.synchronize()
-        total = time.perf_counter() - t0
-        out["H%d" % H] = {"us_per_frame_total": total / n * 1e6, "us_per_frame_host_loop": host / n * 1e6,
-                          **{"host_us_" + k: v / n * 1e6 for k, v in acc.items()}}
-        r.set_render_target(0, 0); r.destroy(); gvol.destroy(); ctx.destroy()
+            def bucket(timing):
+                t0 = time.perf_counter(); b = gather.acquire_bucket()
+                t1 = time.perf_counter(); r.play_into(F, b.data_ptr(), nbytes)
+                t2 = time.perf_counter(); r.join()
+                t3 = time.perf_counter(); gather.commit_bucket()
+                t4 = time.perf_counter()
+                if timing:
+                    acc["acquire"] += t1 - t0; acc["play_into"] += t2 - t1; acc["join"] += t3 - t2; acc["commit"] += t4 - t3
+            for k in range(50):
+                bucket(False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(n):
+                bucket(True)
+            host = time.perf_counter() - t0
+            gather.wait_all(); torch.cuda.synchronize()
+            total = time.perf_counter() - t0
+            out["H%d" % H] = {"frames_per_bucket": F, "us_per_frame_total": total / (n * F) * 1e6, "us_per_frame_host_loop": host / (n * F) * 1e6,
+                              **{"host_us_per_bucket_" + k: v / n * 1e6 for k, v in acc.items()}}
+            r.set_render_target(0, 0); r.destroy(); gvol.destroy(); ctx.destroy()
     print(json.dumps(out, indent=1))
     dist.destroy_process_group()
 

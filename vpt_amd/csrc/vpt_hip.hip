@@ -1509,6 +1509,34 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
     return VPT_OK;
 }
 
+// `count` eager render() passes, frame i into caller memory at first_target + i * stride_bytes (the slots of a bucket a collective
+// will move): what `count` x { vpt_renderer_set_render_target; vpt_renderer_render } do, by one call — the host loop around those
+// two cost more per frame than a 1/8 share's kernels take (torch.distributed pipeline).  The last target stays
+// the renderer's render target.
+extern "C" int vpt_renderer_play_into(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, void *first_target, size_t stride_bytes) {
+    if (!r || !base || !frame_vars || !first_target) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "frame sequences are not defined for the DOS renderer: drive it slice by slice");
+    const size_t need = (size_t)r->W * r->local_h * 8;
+    if (stride_bytes < need) return fail(VPT_ERR_INVALID, "target stride too small: %zu < %zu", stride_bytes, need);
+    if (!r->split_callers) VPT_TRY(join_side(r));
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    PassArgs a;
+    VPT_TRY(play_args(r, base, count, &a));
+    const FrameVar *v = (const FrameVar *)frame_vars;
+    r->target_is_callers = true;
+    for (int i = 0; i < count; i++) {
+        r->render_target = (uint2 *)((char *)first_target + (size_t)i * stride_bytes);
+        PassArgs f = frame_args(a, v[i]);
+        f.render = r->render_target;
+        Timed t(r, true);
+        VPT_TRY(launch_fused(r, f));
+    }
+    HIP_TRY(hipGetLastError());
+    r->warmed = true;
+    if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)base->steps * (uint64_t)count;
+    return VPT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // read-back, counters, profiling
 // ---------------------------------------------------------------------------------------------

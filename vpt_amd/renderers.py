@@ -285,6 +285,12 @@ class AbstractRenderer(PropertyBag):
         mode = N.PLAY_FRAMES if frames else (N.PLAY_FUSED if fused else (N.PLAY_GRAPH if use_graph else N.PLAY_EAGER))
         N.check(N.lib().vpt_renderer_play(self._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), count, mode))
 
+    def play_into(self, count, first_target, stride_bytes):
+        """`count` eager render() passes by one native call, frame i into caller-owned device memory at first_target + i * stride_bytes"""
+        self._bind_volume()
+        u, vars_ = self._collect_frames(count)
+        N.check(N.lib().vpt_renderer_play_into(self._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), count, C.c_void_p(first_target), stride_bytes))
+
     def read_frame_slot(self, slot):
         """frame `slot` of the last play(frames=True) call: [local rows][W][4] float16"""
         out = np.empty((self.local_rows(), self._size()[0], 4), dtype=np.float16)
@@ -519,6 +525,18 @@ class MCMRenderer(AbstractRenderer):
 
     def _prepare_frame_uniforms(self):
         return self._prepare_integrate()
+
+    def _collect_frames(self, count):
+        """the same draws as `count` _prepare_integrate() calls — one rng() per frame, MCMRenderer.js:156 — without rebuilding the
+        uniform block each time (the host loop of a frame sequence must stay below a 1/8 shard's 16 us of kernels)"""
+        if type(self)._prepare_integrate is not MCMRenderer._prepare_integrate:
+            return super()._collect_frames(count)              # a subclass changed what a frame draws
+        u = self._prepare_integrate()
+        seeds = [u.rand_seed] + [_f32(self.rng()) for _ in range(count - 1)]
+        vars_ = np.zeros((count, 8), dtype=np.float32)
+        vars_[:, 0] = seeds
+        u.rand_seed = seeds[-1]                                # (the base block is the last frame's, as the generic path returns it)
+        return u, vars_
 
     def _renderFused(self):
         self._bind_volume()

@@ -106,6 +106,23 @@ class FrameGather:
             self.wait(b)
         return self._send[b][j]
 
+    def acquire_bucket(self):
+        """at a bucket boundary: the [F][rows][W][4] tensor the next F frames are rendered into, slot by slot (waits for the gather
+        that last read it); None inside an open bucket"""
+        if self._next % self.F:
+            return None
+        b = (self._next // self.F) % self.nbuf
+        self.wait(b)
+        return self._send[b]
+
+    def commit_bucket(self):
+        """the F frames of the bucket handed out by acquire_bucket() have been enqueued: send it"""
+        b = (self._next // self.F) % self.nbuf
+        self._next += self.F
+        self._last_slot = (b, self.F - 1)
+        self._pending = 0
+        self.gather(b)
+
     def bucket_closes(self):
         """True when commit() of the frame acquired last will send the bucket"""
         return self._next % self.F == self.F - 1
