@@ -65,9 +65,13 @@ def parse():
     ap.add_argument("--gather-root", default="auto",
                     help="native gather: rank that receives every frame (grouped ncclSend/ncclRecv); -1 = every rank (all_gather); "
                          "auto = time both during the warm-up (rank 0 receives the frame either way) and keep the faster")
-    ap.add_argument("--gather", default="torch", choices=["native", "torch"],
-                    help="frame gather for N > 1: 'torch' = torch.distributed all_gather_into_tensor (default: the path that has run with "
-                         "more than one rank), 'native' = RCCL pipeline below the C ABI (vpt_gather_*; one-rank communicators only so far)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "native", "torch"],
+                    help="frame gather for N > 1: 'torch' = torch.distributed all_gather_into_tensor in buckets of --frames-per-gather frames; "
+                         "'native' = RCCL pipeline below the C ABI (vpt_gather_*), measured AFTER a complete torch.distributed measurement and "
+                         "under --native-deadline (the faster line is printed); 'auto' (default) = native only if a PREFLIGHT passes: every rank "
+                         "starts tests/two_rank_worker.py in a fresh child process — a small scene through the native pipeline with this world "
+                         "size (gather to rank 0, all_gather, gather to the last rank; the gathered frames bit-compared with unsharded ones) — "
+                         "so that a fault of the never-before-run multi-rank path costs a child, not the measurement; else torch")
     ap.add_argument("--safe-first", type=int, default=1,
                     help="N > 1 with the native gather: measure over torch.distributed's all_gather first, then the native pipeline "
                          "under --native-deadline; print the faster (or the first, if the native phase does not finish)")
@@ -291,6 +295,39 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
     return out
 
 
+def native_preflight(dist, torch, device, rank, world, local_rank, timeout=180):
+    """Every rank runs tests/two_rank_worker.py in a fresh child process (its own process group on a port agreed here): the native RCCL
+    gather pipeline on a small scene with THIS world size, bit-compared with unsharded frames.  Returns "ok" on every rank only if every
+    child exited 0 in time; a child that hangs is killed (by its PID), one that crashes takes nothing with it."""
+    import socket
+    import subprocess
+    port = [None]
+    if rank == 0:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0)); port[0] = s_.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    verdict = "ok"
+    try:
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        try:
+            out, _ = p.communicate(timeout=timeout)
+            if p.returncode != 0:
+                verdict = "child of rank %d exited %d: %s" % (rank, p.returncode, out.decode(errors="replace")[-300:].replace("\n", " | "))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            verdict = "child of rank %d did not finish in %d s" % (rank, timeout)
+    except OSError as e:
+        verdict = "child of rank %d could not start: %r" % (rank, e)
+    flag = torch.tensor([1 if verdict == "ok" else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag[0]) == 0 and verdict == "ok":
+        verdict = "another rank's child failed"
+    return verdict
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line, the JSON: RCCL prints its version banner to stdout when a communicator comes up,
@@ -401,6 +438,13 @@ def main():
         nbytes = gather.send[0].numel() * 2
         r.reset()
         native = None
+        preflight = None
+        if use_dist and args.gather == "auto":
+            preflight = native_preflight(dist, torch, device, rank, world, local_rank) if (world > 1 or args.force_dist > 1) else "skipped: one rank"
+            args.gather = "native" if preflight == "ok" else "torch"
+            if rank == 0:
+                print("native gather preflight: %s -> --gather %s" % (preflight, args.gather), file=sys.stderr)
+        state["preflight"] = preflight
         if use_dist and args.gather == "native":
             # bootstrap the library's own RCCL communicator through torch.distributed; every rank must agree that it
             # came up, otherwise all of them fall back to the torch.distributed gather
@@ -500,7 +544,7 @@ def main():
                                        "default camera, default 2x1 transfer function, extinction %g, anisotropy 0, bounces 8, "
                                        "steps 8 per pass, 1 pass per step" % (args.renderer.upper(), args.volume, W, H, float(r.extinction) if hasattr(r, 'extinction') else 0.0),
                            "parallelism": par,
-                           "gather_calibration": res["gather_choice"],
+                           "gather_calibration": res["gather_choice"], "native_preflight": state.get("preflight"),
                            "frames_per_gather": (gather.F if (use_dist and not res["native"]) else None),
                            "frames_per_launch": f, "hipgraph": bool(args.graph) and f > 1 and not res["native"] and not args.fused_passes,
                            "fused_passes": bool(args.fused_passes) and f > 1, "every_frame_written": (args.fused_passes == 2 and f > 1) or not (bool(args.fused_passes) and f > 1),

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Worker of tests/test_gpu_two_ranks.py: one rank of a 2-rank run of the NATIVE RCCL gather pipeline (vpt_gather_*).
+"""Worker of tests/test_gpu_two_ranks.py and of bench.py's native-gather preflight: one rank of an N-rank run of the NATIVE RCCL gather
+pipeline (vpt_gather_*).
 Started as a fresh process per rank (RANK / WORLD_SIZE / MASTER_* in the environment) before anything touches a GPU.
 For root = 0 and root = -1 (all_gather): more than two turns of the buffer ring, the gathered frame of several frames compared
 bit for bit with the same frames rendered UNSHARDED on this rank's GPU; the per-rank verdicts are all-reduced (MIN), so one bad
@@ -19,14 +20,16 @@ def main():
     from vpt_amd.scene import default_camera, Transform, Node
     from vpt_amd.synthetic import sphere_volume, GoldenRatioRng
     from vpt_amd.tiles import RcclFrameGather
+    from vpt_amd import _native as N
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(rank)
-    device = torch.device("cuda", rank)
+    gpu = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(gpu)
+    device = torch.device("cuda", gpu)
     dist.init_process_group("nccl", device_id=device)
     W, H = 200, 136
     vol = sphere_volume(48, noise=40.0)
-    ctx = vpt_amd.Context(rank)
+    ctx = vpt_amd.Context(gpu)
     gvol = vpt_amd.Volume.from_array(ctx, vol, 'linear')
     cam, tr = default_camera(W / H), Transform(Node())
 
@@ -36,6 +39,10 @@ def main():
             o['shard'] = shard
         r = vpt_amd.MCMRenderer(ctx, gvol, cam, None, o)
         r.extinction = 4
+        # the form bench.py runs: fast arithmetic; the sharded renderer with its pass on two streams (tile classes: HIT | MISS kernels)
+        r.set_option(N.OPTION_FAST_MATH, 1)
+        if shard:
+            r.set_option(N.OPTION_SPLIT_STREAMS, 2)
         r.reset()
         return r
 

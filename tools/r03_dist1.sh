@@ -1,15 +1,15 @@
 #!/bin/bash
 # the N > 1 code paths of bench.py on ONE rank (one-rank RCCL group): torch.distributed pipeline, then torch-first + native
 mkdir -p gpurun_out/r03
-for args in "--gather torch" "--gather native --safe-first 2" "--gather torch --height 136 --steps 400"; do
-  timeout -k 10 400 python bench.py --force-dist 1 --other-configs 0 --cpu-baseline 0 --stream-probe 0 $args > gpurun_out/r03/dist1.json 2> gpurun_out/r03/dist1.err; rc=$?
+for args in "--gather auto --force-dist 2" "--gather torch --force-dist 1" "--gather native --safe-first 2 --force-dist 1"; do
+  timeout -k 10 400 python bench.py --other-configs 0 --cpu-baseline 0 --stream-probe 0 $args > gpurun_out/r03/dist1.json 2> gpurun_out/r03/dist1.err; rc=$?
   echo "== $args (rc $rc)"
   [ $rc -ne 0 ] && tail -5 gpurun_out/r03/dist1.err
   python3 - <<'PY'
 import json
 try:
     j=json.load(open("gpurun_out/r03/dist1.json"))
-    print(j["ms_per_step"], j["frame_check"], j["config"]["parallelism"], j["config"].get("other_pipeline_ms_per_step"), j["config"]["split_streams"], j["config"]["tile_classes"])
+    print(j["ms_per_step"], j["frame_check"], j["config"]["parallelism"], j["config"].get("other_pipeline_ms_per_step"), j["config"]["split_streams"], j["config"].get("native_preflight"))
 except Exception as e:
     print("no line:", e)
 PY
