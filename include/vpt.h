@@ -329,6 +329,12 @@ VPT_API int vpt_tonemapper_output_device(vpt_tonemapper *t, void **ptr, size_t *
 #define VPT_TONEMAPPER_TABLE_NEVER   0
 #define VPT_TONEMAPPER_TABLE_ALWAYS  1
 #define VPT_TONEMAPPER_TABLE_AUTO    2
+/* VPT_TONEMAPPER_OPTION_FUSE (default 1; extension): once vpt_tonemapper_render() has run in its table form on a bound renderer, that renderer's
+ * fused render() passes write the tone-mapped RGBA8 texel (same table, same lookups: bit-identical) next to every RGBA16F texel they store, and
+ * the following vpt_tonemapper_render() calls with unchanged parameters find their output ready and launch nothing — RenderingContext.render()
+ * (RenderingContext.js:196-197: renderer.render(); toneMapper.render()) then costs one pass instead of two.  Any pass that writes the render
+ * buffer another way (the separate hooks, frame sequences, a caller's render target), new parameters or a resize fall back to the separate pass. */
+#define VPT_TONEMAPPER_OPTION_FUSE   1
 VPT_API int vpt_tonemapper_set_option(vpt_tonemapper *t, int option, int value);
 
 /* ---- multi-GPU frame gather (no reference counterpart).  One process per GPU; the image plane is sharded

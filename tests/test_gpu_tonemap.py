@@ -361,3 +361,79 @@ def test_tonemapper_random_parameters(gpu_ctx, oracle, seed):
             tm.render()
             same(tm.getTexture(), want, "%s %r mode %d" % (kind, full, mode))
         tm.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# VPT_TONEMAPPER_OPTION_FUSE: once the tone mapper has run in its table form on a bound renderer, the renderer's fused passes write
+# the tone-mapped texel next to every RGBA16F texel they store and the tone mapper's later render() calls launch nothing
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rkind", ["mcm", "eam", "mip", "mcs", "iso", "depth", "lao"])
+@pytest.mark.parametrize("tkind", ["artistic", "range", "reinhard"])
+def test_fused_tone_mapping_equals_the_separate_pass(gpu_ctx, oracle, rkind, tkind):
+    from vpt_amd import _native as N
+    w, h = 208, 144
+    vol = sphere_volume(24, noise=40.0)
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, 'linear')
+    from conftest import orbit_camera
+
+    def run(fuse):
+        cam = orbit_camera(w / h, 0.7, -0.3, 3.0)
+        r = vpt_amd.RendererFactory(rkind)(gpu_ctx, gvol, cam, None, {'resolution': (w, h), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+        r.setTransferFunction(colour_tf(64, 1))
+        if rkind in ('mcs', 'mcm'):
+            r.extinction = 6
+        r.set_option(N.OPTION_SPLIT_STREAMS, 2)
+        r.reset()
+        tm = vpt_amd.ToneMapperFactory(tkind)(gpu_ctx, r, {'resolution': (w, h)})
+        tm.set_option(N.TONEMAPPER_OPTION_TABLE, N.TONEMAPPER_TABLE_ALWAYS)         # (small image: AUTO would take the direct form)
+        tm.set_option(N.TONEMAPPER_OPTION_FUSE, fuse)
+        outs = []
+
+        def shot(what):
+            tm.render()
+            got = tm.getTexture().copy()
+            same(got, oracle.tonemap(tkind, r.getTexture(), **{p['name']: getattr(tm, p['name']) for p in tm.properties}), "%s -> %s fuse=%d: %s" % (rkind, tkind, fuse, what))
+            outs.append(got)
+        for k in range(3):
+            r.render(); shot("frame %d" % k)
+        r.render(); r.render(); shot("two frames without a tone-map call in between")
+        name = {'artistic': 'high', 'range': 'max', 'reinhard': 'exposure'}[tkind]
+        setattr(tm, name, getattr(tm, name) * 0.7)                                  # new parameters: the table is rebuilt
+        shot("new parameters, same frame")
+        r.render(); shot("new parameters, next frame")
+        r.fused = False
+        r.render(); shot("a hook-by-hook frame")                                   # the hook kernels do not tone-map
+        r.fused = True
+        r.render(); shot("fused again")
+        r.reset(); r.render(); shot("after a reset")
+        if rkind != "lao":
+            r.play(3, use_graph=False); shot("an eager sequence")
+        if rkind == "mcm":
+            r.play(3, fused=True); shot("a fused-pass sequence")
+            r.render(); shot("and a frame after it")
+        tm.destroy(); r.destroy()
+        return outs
+
+    a, b = run(0), run(1)
+    assert len(a) == len(b)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert (x == y).all(), (rkind, tkind, k)
+    gvol.destroy()
+
+
+def test_fused_tone_mapping_full_hd_mcm_tile_classes(gpu_ctx, oracle):
+    """the displayed-frame path of RenderingContext.render() at the headline size: MCM (fast-math, tile classes on two streams) + the default
+    Artistic tone mapper; AUTO takes the table form at this size, so the fusion is what runs"""
+    from vpt_amd import _native as N
+    w, h = 1920, 1080
+    vol = sphere_volume(128, noise=48.0)
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, 'linear')
+    r = vpt_amd.MCMRenderer(gpu_ctx, gvol, default_camera(w / h), None, {'resolution': (w, h), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+    r.set_option(N.OPTION_FAST_MATH, 1); r.set_option(N.OPTION_SPLIT_STREAMS, 2)
+    r.reset()
+    tm = vpt_amd.ToneMapperFactory('artistic')(gpu_ctx, r, {'resolution': (w, h)})
+    for k in range(6):
+        r.render(); tm.render()
+        if k in (0, 1, 5):
+            same(tm.getTexture(), oracle.tonemap('artistic', r.getTexture(), **{p['name']: p['value'] for p in tm.properties}), "frame %d" % k)
+    tm.destroy(); r.destroy(); gvol.destroy()

@@ -29,6 +29,7 @@ ERR_INVALID, ERR_HIP, ERR_NO_VOLUME, ERR_UNSUPPORTED = -1, -2, -3, -4
 (PROBE_LOG, PROBE_SIN, PROBE_COS, PROBE_ASIN, PROBE_ATAN2, PROBE_PCG, PROBE_UNIFORM, PROBE_F16,
  PROBE_RCP, PROBE_RSQRT, PROBE_MIN, PROBE_MAX, PROBE_LOG_UNIFORM, PROBE_RCPZ, PROBE_SQRT, PROBE_EXP, PROBE_POW) = range(17)
 TONEMAPPER_OPTION_TABLE, TONEMAPPER_TABLE_NEVER, TONEMAPPER_TABLE_ALWAYS, TONEMAPPER_TABLE_AUTO = 0, 0, 1, 2
+TONEMAPPER_OPTION_FUSE = 1
 (TONEMAPPER_ARTISTIC, TONEMAPPER_RANGE, TONEMAPPER_REINHARD, TONEMAPPER_REINHARD2, TONEMAPPER_UNCHARTED2, TONEMAPPER_FILMIC,
  TONEMAPPER_UNREAL, TONEMAPPER_ACES, TONEMAPPER_LOTTES, TONEMAPPER_UCHIMURA) = range(10)
 

@@ -130,6 +130,9 @@ struct vpt_renderer {
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
     struct TileClasses cls;        // MCM: HIT / MISS tile lists of the last reset's matrix (see classify_tiles)
     int last_layout;               // how the last sampling launch mapped tiles to streams: 0 = tile-row ranges, 1 = tile lists
+    // tone mapping fused into the fused passes' frame store: the armed tone mapper (null: none), whether its output holds the tone-mapped
+    // image of what the render buffer holds now, and the store's arguments (PassArgs.tm_*)
+    struct vpt_tonemapper *tm_owner; bool tm_valid; const uint8_t *tm_table; uint32_t *tm_out; int tm_mode; float tm_low, tm_range, tm_oms;
     int hit_form;                  // VPT_OPTION_HIT_KERNEL_FORM: 0 = by the number of HIT tiles, 1 = k_mcm_integrate, 2 = k_mcm_integrate_early
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
@@ -401,6 +404,7 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     vpt_context *c = r->ctx;
     if (r->play_graph) { hipStreamSynchronize(c->stream); play_graph_free(r->play_graph); r->play_graph = nullptr; }
     r->render_target = nullptr; r->target_is_callers = false;   // an external target was sized for the old geometry
+    r->tm_owner = nullptr; r->tm_valid = false; r->tm_mode = 0;  // a fused tone mapper's output was sized for it too: it re-arms itself
     if (r->frame_ring) { hipFree(r->frame_ring); r->frame_ring = nullptr; } r->ring_frames = 0;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -510,6 +514,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_ring = nullptr; r->ring_frames = 0; r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0; r->hit_form = 0;
+    r->tm_owner = nullptr; r->tm_valid = false; r->tm_table = nullptr; r->tm_out = nullptr; r->tm_mode = 0; r->tm_low = r->tm_range = r->tm_oms = 0.0f;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
@@ -753,6 +758,10 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
         a->st1 = nullptr; a->st2 = r->st[2 + r->dos_cur]; a->st3 = r->st[3 - r->dos_cur];
     }
     a->render = r->render_target ? r->render_target : r->render;
+    if (r->tm_owner && r->tm_mode && !r->render_target) {
+        a->tm_table = r->tm_table; a->tm_out = r->tm_out; a->tm_mode = r->tm_mode;
+        a->tm_low = r->tm_low; a->tm_range = r->tm_range; a->tm_one_minus_saturation = r->tm_oms;
+    }
     a->samples = r->samples;
     return VPT_OK;
 }
@@ -1263,6 +1272,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
 extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
     VPT_TRY(join_side(r));
+    r->tm_valid = false;                                       // (the hook kernels do not tone-map: the next vpt_tonemapper_render runs its own pass)
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind == VPT_RENDERER_ISO && !u) return fail(VPT_ERR_INVALID, "ISO renderFrame needs uniforms (uLight, uGradientStep)");
     PassArgs a;
@@ -1282,6 +1292,9 @@ extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u)
 }
 // the fused render() launch of the renderer's kind (generate -> integrate -> renderFrame in one kernel)
 static int launch_fused(vpt_renderer *r, const PassArgs &a) {
+    // (a fused pass writes the armed tone mapper's output with every texel it writes; a pass whose arguments carry no tone map — a caller's
+    // render target, the gather ring, a multi-pass or captured sequence — leaves that output behind the render buffer)
+    r->tm_valid = r->tm_valid && a.tm_mode != 0 && a.multi_passes <= 1 && !r->no_split;
     VPT_TRY(marcher_track(r, a, true, a.mix));
     struct ListOff { vpt_renderer *r; ~ListOff() { r->cls.list_now = false; } } list_off{ r };
     switch (r->kind) {
@@ -1391,6 +1404,7 @@ static int launch_frames(K kernel, vpt_renderer *r, const PassArgs &a, uint32_t 
     return VPT_OK;
 }
 static int launch_mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses, uint2 *ring = nullptr) {
+    r->tm_valid = false;
     VPT_TRY(mcm_before_pass(r, a, nullptr));
     VPT_TRY(mcm_materialize(r));                      // a whole-image kernel: every tile's full photon state
     if (r->side_busy) VPT_TRY(join_side(r));
@@ -1461,7 +1475,7 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
             Timed t(r, true, (uint32_t)count);       // a replay is timed as a whole: events inside a graph cannot be read back
             HIP_TRY(hipGraphLaunch(g->exec, c->stream));
         }
-        g->ran = true;
+        g->ran = true; r->tm_valid = false;
     } else if (use_graph == VPT_PLAY_FRAMES && r->kind != VPT_RENDERER_MCM) {
         return fail(VPT_ERR_UNSUPPORTED, "VPT_PLAY_FRAMES is implemented for the MCM renderer");
     } else if (use_graph == VPT_PLAY_FUSED && r->kind != VPT_RENDERER_MCM) {
@@ -1528,6 +1542,7 @@ extern "C" int vpt_renderer_play_into(vpt_renderer *r, const vpt_uniforms *base,
         r->render_target = (uint2 *)((char *)first_target + (size_t)i * stride_bytes);
         PassArgs f = frame_args(a, v[i]);
         f.render = r->render_target;
+        f.tm_mode = 0; f.tm_table = nullptr; f.tm_out = nullptr;      // (a fused tone mapper follows the renderer's own buffer only)
         Timed t(r, true);
         VPT_TRY(launch_fused(r, f));
     }
@@ -1934,12 +1949,17 @@ struct vpt_tonemapper {
     int rows;                      // rows of the last render
     int table_mode;                // VPT_TONEMAPPER_TABLE_*
     uint8_t *table; bool table_valid; TonemapParams table_params;   // byte table of the current parameters (vpt_tonemap.h)
+    bool fuse;                     // VPT_TONEMAPPER_OPTION_FUSE (default on): arm the bound renderer's fused passes with this table and output
 };
+static void tonemapper_disarm(vpt_tonemapper *t) {
+    if (t && t->source && t->source->tm_owner == t) { t->source->tm_owner = nullptr; t->source->tm_mode = 0; t->source->tm_valid = false; }
+}
 static void renderers_unbind(vpt_context *c, vpt_volume *v) {
     for (vpt_renderer *r : c->renderers) if (r->vol == v) r->vol = nullptr;
 }
 static void tonemappers_unbind(vpt_context *c, vpt_renderer *r) {
     for (vpt_tonemapper *t : c->tonemappers) if (t->source == r) t->source = nullptr;
+    r->tm_owner = nullptr; r->tm_mode = 0;
 }
 extern "C" int vpt_tonemapper_create(vpt_context *c, int kind, int width, int height, vpt_tonemapper **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
@@ -1947,7 +1967,7 @@ extern "C" int vpt_tonemapper_create(vpt_context *c, int kind, int width, int he
     if (width < 1 || height < 1) return fail(VPT_ERR_INVALID, "bad resolution %dx%d", width, height);
     vpt_tonemapper *t = new vpt_tonemapper();
     memset(t, 0, sizeof(*t));
-    t->ctx = c; t->kind = kind; t->W = width; t->H = height; t->table_mode = VPT_TONEMAPPER_TABLE_AUTO;
+    t->ctx = c; t->kind = kind; t->W = width; t->H = height; t->table_mode = VPT_TONEMAPPER_TABLE_AUTO; t->fuse = true;
     c->tonemappers.push_back(t);
     *out = t;
     return VPT_OK;
@@ -1955,6 +1975,8 @@ extern "C" int vpt_tonemapper_create(vpt_context *c, int kind, int width, int he
 extern "C" int vpt_tonemapper_destroy(vpt_tonemapper *t) {
     if (!t) return VPT_OK;
     hipSetDevice(t->ctx->device);
+    if (t->source) join_side(t->source);
+    tonemapper_disarm(t);
     hipStreamSynchronize(t->ctx->stream);
     if (t->image) hipFree(t->image);
     if (t->out) hipFree(t->out);
@@ -1967,6 +1989,7 @@ extern "C" int vpt_tonemapper_destroy(vpt_tonemapper *t) {
 extern "C" int vpt_tonemapper_resize(vpt_tonemapper *t, int width, int height) {
     if (!t) return fail(VPT_ERR_INVALID, "tone mapper is null");
     if (width < 1 || height < 1) return fail(VPT_ERR_INVALID, "bad resolution %dx%d", width, height);
+    tonemapper_disarm(t);
     t->W = width; t->H = height; t->rows = 0;
     return VPT_OK;
 }
@@ -1975,6 +1998,8 @@ extern "C" int vpt_tonemapper_set_source(vpt_tonemapper *t, vpt_renderer *r) {
     if (r && r->ctx->device != t->ctx->device) return fail(VPT_ERR_INVALID, "renderer and tone mapper live on different devices");
     HIP_TRY(hipSetDevice(t->ctx->device));
     if (t->image) { HIP_TRY(hipStreamSynchronize(t->ctx->stream)); HIP_TRY(hipFree(t->image)); t->image = nullptr; }
+    if (t->source) VPT_TRY(join_side(t->source));
+    tonemapper_disarm(t);
     t->source = r;
     return VPT_OK;
 }
@@ -1989,6 +2014,7 @@ extern "C" int vpt_tonemapper_set_source_image(vpt_tonemapper *t, const void *rg
     HIP_TRY(hipMalloc(&t->image, bytes));
     HIP_TRY(hipMemcpyAsync(t->image, rgba16f, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    tonemapper_disarm(t);
     t->image_w = width; t->image_rows = rows; t->source = nullptr;
     return VPT_OK;
 }
@@ -2002,10 +2028,25 @@ static void launch_tonemap(vpt_tonemapper *t, const uint2 *src, size_t n, const 
     bool use_table = (KIND != VPT_TM_ARTISTIC || p.saturation == 1.0f) &&
                      (t->table_mode == VPT_TONEMAPPER_TABLE_ALWAYS || (t->table_mode == VPT_TONEMAPPER_TABLE_AUTO && (current || n >= 4 * 65536)));
     if (use_table && !t->table && hipMalloc(&t->table, VPT_TM_TABLE_ENTRIES + 63) != hipSuccess) { t->table = nullptr; use_table = false; (void)hipGetLastError(); }
+    vpt_renderer *fr = (t->fuse && t->source && src == t->source->render) ? t->source : nullptr;     // the renderer whose fused passes may carry this map
     if (!use_table) {
+        tonemapper_disarm(t);
         hipLaunchKernelGGL(k_tonemap<KIND>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, p);
         return;
     }
+    // VPT_TONEMAPPER_OPTION_FUSE: the renderer's fused passes have been writing this output, with this table, along with the render buffer
+    if (fr && current && fr->tm_owner == t && fr->tm_valid && fr->tm_out == t->out) return;
+    struct Arm {      // after this pass the output matches the render buffer: from now on the renderer's fused passes keep it so
+        vpt_tonemapper *t; vpt_renderer *r; TonemapParams p;
+        ~Arm() {
+            if (!r) return;
+            r->tm_owner = t; r->tm_table = t->table; r->tm_out = t->out;
+            r->tm_mode = KIND == VPT_TM_ARTISTIC ? 3 : (KIND == VPT_TM_RANGE ? 2 : 1);
+            r->tm_low = p.low; r->tm_range = p.high - p.low; r->tm_oms = 1.0f - p.saturation;
+            r->tm_valid = true;
+            r->main_dirty = true;       // side streams of split passes must see the table this stream has just (re)built
+        }
+    } arm{ t, fr, p };
     if (!current) {
         if (KIND == VPT_TM_ARTISTIC) hipLaunchKernelGGL(k_tonemap_table_artistic, dim3(256), dim3(256), 0, t->ctx->stream, t->table, p);
         else hipLaunchKernelGGL(k_tonemap_table<KIND>, dim3(256), dim3(256), 0, t->ctx->stream, t->table, p);
@@ -2034,6 +2075,12 @@ static void launch_tonemap(vpt_tonemapper *t, const uint2 *src, size_t n, const 
 }
 extern "C" int vpt_tonemapper_set_option(vpt_tonemapper *t, int option, int value) {
     if (!t) return fail(VPT_ERR_INVALID, "tone mapper is null");
+    if (option == VPT_TONEMAPPER_OPTION_FUSE) {
+        if (t->source) VPT_TRY(join_side(t->source));
+        if (!value) tonemapper_disarm(t);
+        t->fuse = value != 0;
+        return VPT_OK;
+    }
     if (option != VPT_TONEMAPPER_OPTION_TABLE) return fail(VPT_ERR_INVALID, "unknown tone mapper option %d", option);
     if (value < VPT_TONEMAPPER_TABLE_NEVER || value > VPT_TONEMAPPER_TABLE_AUTO) return fail(VPT_ERR_INVALID, "bad value %d", value);
     t->table_mode = value;
@@ -2044,11 +2091,21 @@ __global__ void k_fill_u32(uint32_t *dst, size_t n, uint32_t v) {
 }
 extern "C" int vpt_tonemapper_render(vpt_tonemapper *t, const struct vpt_tonemap_params *params) {
     if (!t || !params) return fail(VPT_ERR_INVALID, "null argument");
+    static_assert(sizeof(TonemapParams) == sizeof(vpt_tonemap_params), "parameter block layout");
+    TonemapParams p; memcpy(&p, params, sizeof(p));
+    // VPT_TONEMAPPER_OPTION_FUSE: the bound renderer's fused passes have been writing this output, with the table of these parameters,
+    // along with its render buffer — nothing to launch, and no reason to join the streams of a split pass (vpt_tonemapper_read does)
+    if (t->fuse && t->source && t->table && t->table_valid && memcmp(&t->table_params, &p, sizeof(p)) == 0) {
+        vpt_renderer *r = t->source;
+        if (r->tm_owner == t && r->tm_valid && r->tm_out == t->out && !r->render_target && r->W == t->W && r->H == t->H &&
+            (t->kind != VPT_TONEMAPPER_ARTISTIC || p.saturation == 1.0f) && t->table_mode != VPT_TONEMAPPER_TABLE_NEVER) {
+            t->rows = r->local_h;
+            return VPT_OK;
+        }
+    }
     VPT_TRY(join_side(t->source));
     vpt_context *c = t->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    static_assert(sizeof(TonemapParams) == sizeof(vpt_tonemap_params), "parameter block layout");
-    TonemapParams p; memcpy(&p, params, sizeof(p));
     const uint2 *src = nullptr; int w = t->W, rows = t->H;
     uint2 *white = nullptr;
     if (t->source) {
@@ -2063,6 +2120,7 @@ extern "C" int vpt_tonemapper_render(vpt_tonemapper *t, const struct vpt_tonemap
                                          "(the reference keeps them equal, RenderingContext.js:219-228)", w, t->source ? t->source->H : rows, t->W, t->H);
     size_t n = (size_t)w * rows;
     if (t->out_pixels < n) {
+        tonemapper_disarm(t);                                  // (the armed renderer holds the old output's address)
         if (t->out) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(t->out)); t->out = nullptr; t->out_pixels = 0; }
         HIP_TRY(hipMalloc(&t->out, n * 4));
         t->out_pixels = n;
@@ -2103,6 +2161,8 @@ extern "C" int vpt_tonemapper_read(vpt_tonemapper *t, void *dst, size_t nbytes) 
     size_t need = (size_t)t->W * t->rows * 4;
     if (nbytes < need) return fail(VPT_ERR_INVALID, "destination too small: %zu < %zu", nbytes, need);
     HIP_TRY(hipSetDevice(t->ctx->device));
+    VPT_TRY(join_side(t->source));                             // (a fused renderer's split passes write the output from their own streams)
+    if (t->source && t->source->ctx->stream != t->ctx->stream) HIP_TRY(hipStreamSynchronize(t->source->ctx->stream));
     HIP_TRY(hipMemcpyAsync(dst, t->out, need, hipMemcpyDeviceToHost, t->ctx->stream));
     HIP_TRY(hipStreamSynchronize(t->ctx->stream));
     return VPT_OK;
@@ -2110,6 +2170,7 @@ extern "C" int vpt_tonemapper_read(vpt_tonemapper *t, void *dst, size_t nbytes) 
 extern "C" int vpt_tonemapper_output_device(vpt_tonemapper *t, void **ptr, size_t *nbytes) {
     if (!t || !ptr || !nbytes) return fail(VPT_ERR_INVALID, "null argument");
     if (!t->rows) return fail(VPT_ERR_INVALID, "nothing rendered yet");
+    VPT_TRY(join_side(t->source));
     *ptr = t->out; *nbytes = (size_t)t->W * t->rows * 4;
     return VPT_OK;
 }

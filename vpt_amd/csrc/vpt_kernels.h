@@ -125,6 +125,10 @@ struct PassArgs {
     // by a device-side frame counter, so one captured launch sequence serves every replay
     const struct FrameVar *frame_table;     // ring of frame_mask + 1 entries
     const uint32_t *frame_counter;          // frames played so far (monotonic); entry = counter & frame_mask
+    // tone mapping fused into the fused passes' frame store (VPT_TONEMAPPER_OPTION_FUSE): the armed tone mapper's byte table
+    // (vpt_tonemap.h: 65 536 entries indexed by the half bits of a channel + the constant alpha), its RGBA8 output (row-major local rows,
+    // like `render`), tm_mode 0 = none, 1 = the eight curve mappers, 2 = Range (alpha through the table), 3 = Artistic at saturation 1
+    const uint8_t *tm_table; uint32_t *tm_out; int tm_mode; float tm_low, tm_range, tm_one_minus_saturation;
     uint32_t frame_mask;
     uint32_t frame_base;                    // fused sequences (multi_passes > 1): index of the sequence's first frame, BY VALUE — a pass split over
                                             // streams must not read the device counter, which the context's stream advances behind its own range only
@@ -208,6 +212,28 @@ VPT_DEV uint2 pack_half4(float x, float y, float z, float w) {
 VPT_DEV void store_frame_texel(uint2 *dst, uint2 v) {
     __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x, (unsigned long long *)dst);
 }
+// the frame store of the fused passes: the RGBA16F texel into the render buffer, and — when a tone mapper is armed on this renderer —
+// its tone-mapped RGBA8 texel into the tone mapper's output as well (the same table lookups as k_tonemap_apply_table*, vpt_tonemap.h:
+// bit-identical to the separate pass by construction), which saves that pass and its launch per displayed frame
+VPT_DEV void store_frame(const PassArgs &a, const Pix &p, uint2 v) {
+    const size_t idx = (size_t)p.l * a.pm.W + p.i;
+    store_frame_texel(&a.render[idx], v);
+    if (a.tm_mode) {                                            // wave-uniform
+        const uint8_t *table = a.tm_table;
+        uint32_t rgb = (uint32_t)table[v.x & 0xffffu] | ((uint32_t)table[v.x >> 16] << 8) | ((uint32_t)table[v.y & 0xffffu] << 16);
+        uint32_t out;
+        if (a.tm_mode == 3) {                                   // k_tonemap_apply_table_artistic: the grey term must be finite
+            float4 c = half4_to_float4(v);
+            f3 w = { (c.x - a.tm_low) / a.tm_range, (c.y - a.tm_low) / a.tm_range, (c.z - a.tm_low) / a.tm_range };
+            const float gray = 0.57735026918962576f;
+            float z = (dot3(w, f3{ gray, gray, gray }) * gray) * a.tm_one_minus_saturation;
+            out = ((z == 0.0f) ? rgb : 0u) | 0xff000000u;
+        } else {
+            out = rgb | ((uint32_t)table[a.tm_mode == 2 ? (v.y >> 16) : 65536u] << 24);
+        }
+        a.tm_out[idx] = out;
+    }
+}
 
 // =============================================================================================
 // MIP — MIPRenderer.glsl
@@ -273,7 +299,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mip(PassArgs a) {
             }
             acc[p.k] = (uint8_t)m;
             float v = from_unorm8(m);
-            store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(v, v, v, 1.0f));
+            store_frame(a, p, pack_half4(v, v, v, 1.0f));
         }
     }
     count_samples(a.samples, ns);
@@ -375,7 +401,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_eam(PassArgs a) {
                 m = eam_mix(m, eam_pixel<V>(a, t, p, ns), a.mix);
             }
             acc[p.k] = m;
-            store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], eam_to_half4(m));
+            store_frame(a, p, eam_to_half4(m));
         }
     }
     count_samples(a.samples, ns);
@@ -481,7 +507,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
                 m = mcs_mix(m, mcs_pixel<V>(a, t, p, ns), a.mix);
             }
             acc[p.k] = m;
-            store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(m.x, m.y, m.z, m.w));
+            store_frame(a, p, pack_half4(m.x, m.y, m.z, m.w));
         }
     }
     count_samples(a.samples, ns);
@@ -1107,8 +1133,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
     else mcm_events<V>(a, t, ph, px, py);
     photon_store(a, p.k, ph);
-    if (FUSE_RENDER)
-        store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+    if (FUSE_RENDER) store_frame(a, p, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
 }
 // the HIT-tile kernel with the early path end (mcm_events_early), compiled for 5 waves per SIMD: selected by the library for tile lists
 // short enough to be resident at once at that occupancy (shards)
@@ -1126,8 +1151,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     if (V & VPT_V_FAST) mcm_events_fast_early<V & ~VPT_V_FAST>(a, t, ph, px, py);
     else mcm_events_early<V>(a, t, ph, px, py);
     photon_store(a, p.k, ph);
-    if (FUSE_RENDER)
-        store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+    if (FUSE_RENDER) store_frame(a, p, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
 }
 // =============================================================================================
 // Tile classes (round 3).  The host classifies every 16x16 tile against the cube once per reset (vpt_hip.hip classify_tiles:
@@ -1237,8 +1261,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     }
     a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
     a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
-    if (FUSE_RENDER)
-        store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+    if (FUSE_RENDER) store_frame(a, p, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
 }
 // brings the position / transmittance arrays of the MISS tiles up to date: position = photon_start(from0, direction) in the
 // arithmetic of the variant that ran the last pass, transmittance = (1, 1, 1)

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 }
             }
             acc[p.k] = m;
-            a.render[(size_t)p.l * a.pm.W + p.i] = iso_shade<V>(a, t, m, ns);
+            store_frame(a, p, iso_shade<V>(a, t, m, ns));
         }
     }
     count_samples(a.samples, ns);
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_depth(PassArgs a) {
                 m = mixf(m, depth_pixel<V>(a, t, p, ns), a.mix);     // DepthRenderer.glsl:114-118
             }
             acc[p.k] = m;
-            a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(m, m, m, 1.0f);    // :150-153
+            store_frame(a, p, pack_half4(m, m, m, 1.0f));    // :150-153
         }
     }
     count_samples(a.samples, ns);
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_lao(PassArgs a) {
             ((uint32_t *)a.frame)[p.k] = q;
         } else {
             ((uint32_t *)a.acc)[p.k] = q;
-            a.render[(size_t)p.l * a.pm.W + p.i] = eam_to_half4(q);
+            store_frame(a, p, eam_to_half4(q));
         }
     }
     count_samples(a.samples, ns);
