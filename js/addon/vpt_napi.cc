@@ -443,7 +443,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("rendererSetOcclusionSamples", RendererSetOcclusionSamples); EXPORT("rendererIntegrateSlices", RendererIntegrateSlices); EXPORT("rendererPlay", RendererPlay);
     EXPORT("tonemapperCreate", TonemapperCreate); EXPORT("tonemapperDestroy", TonemapperDestroy); EXPORT("tonemapperResize", TonemapperResize);
     EXPORT("tonemapperSetSource", TonemapperSetSource); EXPORT("tonemapperSetSourceImage", TonemapperSetSourceImage);
-    EXPORT("tonemapperSetOption", TonemapperSetOption); CONST(VPT_TONEMAPPER_OPTION_TABLE); CONST(VPT_TONEMAPPER_TABLE_NEVER);
+    EXPORT("tonemapperSetOption", TonemapperSetOption); CONST(VPT_TONEMAPPER_OPTION_TABLE); CONST(VPT_TONEMAPPER_OPTION_FUSE); CONST(VPT_TONEMAPPER_TABLE_NEVER);
     CONST(VPT_TONEMAPPER_TABLE_ALWAYS); CONST(VPT_TONEMAPPER_TABLE_AUTO);
     EXPORT("tonemapperRender", TonemapperRender); EXPORT("tonemapperRows", TonemapperRows); EXPORT("tonemapperRead", TonemapperRead);
     CONST(VPT_TONEMAPPER_ARTISTIC); CONST(VPT_TONEMAPPER_RANGE); CONST(VPT_TONEMAPPER_REINHARD); CONST(VPT_TONEMAPPER_REINHARD2);

@@ -132,7 +132,7 @@ struct vpt_renderer {
     int last_layout;               // how the last sampling launch mapped tiles to streams: 0 = tile-row ranges, 1 = tile lists
     // tone mapping fused into the fused passes' frame store: the armed tone mapper (null: none), whether its output holds the tone-mapped
     // image of what the render buffer holds now, and the store's arguments (PassArgs.tm_*)
-    struct vpt_tonemapper *tm_owner; bool tm_valid; const uint8_t *tm_table; uint32_t *tm_out; int tm_mode; float tm_low, tm_range, tm_oms;
+    struct vpt_tonemapper *tm_owner; bool tm_valid; const uint8_t *tm_table; uint32_t *tm_out; int tm_mode;
     int hit_form;                  // VPT_OPTION_HIT_KERNEL_FORM: 0 = by the number of HIT tiles, 1 = k_mcm_integrate, 2 = k_mcm_integrate_early
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
@@ -514,7 +514,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_ring = nullptr; r->ring_frames = 0; r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0; r->hit_form = 0;
-    r->tm_owner = nullptr; r->tm_valid = false; r->tm_table = nullptr; r->tm_out = nullptr; r->tm_mode = 0; r->tm_low = r->tm_range = r->tm_oms = 0.0f;
+    r->tm_owner = nullptr; r->tm_valid = false; r->tm_table = nullptr; r->tm_out = nullptr; r->tm_mode = 0;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
     if (rc == VPT_OK) {
@@ -759,8 +759,7 @@ static int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, P
     }
     a->render = r->render_target ? r->render_target : r->render;
     if (r->tm_owner && r->tm_mode && !r->render_target) {
-        a->tm_table = r->tm_table; a->tm_out = r->tm_out; a->tm_mode = r->tm_mode;
-        a->tm_low = r->tm_low; a->tm_range = r->tm_range; a->tm_one_minus_saturation = r->tm_oms;
+        a->tm_table = r->tm_table;
     }
     a->samples = r->samples;
     return VPT_OK;
@@ -1294,7 +1293,7 @@ extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u)
 static int launch_fused(vpt_renderer *r, const PassArgs &a) {
     // (a fused pass writes the armed tone mapper's output with every texel it writes; a pass whose arguments carry no tone map — a caller's
     // render target, the gather ring, a multi-pass or captured sequence — leaves that output behind the render buffer)
-    r->tm_valid = r->tm_valid && a.tm_mode != 0 && a.multi_passes <= 1 && !r->no_split;
+    r->tm_valid = r->tm_valid && a.tm_table != nullptr && a.multi_passes <= 1 && !r->no_split;
     VPT_TRY(marcher_track(r, a, true, a.mix));
     struct ListOff { vpt_renderer *r; ~ListOff() { r->cls.list_now = false; } } list_off{ r };
     switch (r->kind) {
@@ -1542,7 +1541,7 @@ extern "C" int vpt_renderer_play_into(vpt_renderer *r, const vpt_uniforms *base,
         r->render_target = (uint2 *)((char *)first_target + (size_t)i * stride_bytes);
         PassArgs f = frame_args(a, v[i]);
         f.render = r->render_target;
-        f.tm_mode = 0; f.tm_table = nullptr; f.tm_out = nullptr;      // (a fused tone mapper follows the renderer's own buffer only)
+        f.tm_table = nullptr;      // (a fused tone mapper follows the renderer's own buffer only)
         Timed t(r, true);
         VPT_TRY(launch_fused(r, f));
     }
@@ -1950,6 +1949,7 @@ struct vpt_tonemapper {
     int table_mode;                // VPT_TONEMAPPER_TABLE_*
     uint8_t *table; bool table_valid; TonemapParams table_params;   // byte table of the current parameters (vpt_tonemap.h)
     bool fuse;                     // VPT_TONEMAPPER_OPTION_FUSE (default on): arm the bound renderer's fused passes with this table and output
+    TmFuse fuse_args; bool fuse_args_valid;   // what the block behind the table holds (vpt_tonemap.h)
 };
 static void tonemapper_disarm(vpt_tonemapper *t) {
     if (t && t->source && t->source->tm_owner == t) { t->source->tm_owner = nullptr; t->source->tm_mode = 0; t->source->tm_valid = false; }
@@ -2027,8 +2027,9 @@ static void launch_tonemap(vpt_tonemapper *t, const uint2 *src, size_t n, const 
     bool current = t->table && t->table_valid && memcmp(&t->table_params, &p, sizeof(p)) == 0;
     bool use_table = (KIND != VPT_TM_ARTISTIC || p.saturation == 1.0f) &&
                      (t->table_mode == VPT_TONEMAPPER_TABLE_ALWAYS || (t->table_mode == VPT_TONEMAPPER_TABLE_AUTO && (current || n >= 4 * 65536)));
-    if (use_table && !t->table && hipMalloc(&t->table, VPT_TM_TABLE_ENTRIES + 63) != hipSuccess) { t->table = nullptr; use_table = false; (void)hipGetLastError(); }
-    vpt_renderer *fr = (t->fuse && t->source && src == t->source->render) ? t->source : nullptr;     // the renderer whose fused passes may carry this map
+    if (use_table && !t->table && hipMalloc(&t->table, VPT_TM_TABLE_BYTES) != hipSuccess) { t->table = nullptr; use_table = false; (void)hipGetLastError(); }
+    // the renderer whose fused passes may carry this map (one context: its streams are ordered against this one by events)
+    vpt_renderer *fr = (t->fuse && t->source && src == t->source->render && t->source->ctx == t->ctx) ? t->source : nullptr;
     if (!use_table) {
         tonemapper_disarm(t);
         hipLaunchKernelGGL(k_tonemap<KIND>, dim3((unsigned)blocks), dim3(256), 0, t->ctx->stream, src, t->out, n, p);
@@ -2040,9 +2041,12 @@ static void launch_tonemap(vpt_tonemapper *t, const uint2 *src, size_t n, const 
         vpt_tonemapper *t; vpt_renderer *r; TonemapParams p;
         ~Arm() {
             if (!r) return;
-            r->tm_owner = t; r->tm_table = t->table; r->tm_out = t->out;
-            r->tm_mode = KIND == VPT_TM_ARTISTIC ? 3 : (KIND == VPT_TM_RANGE ? 2 : 1);
-            r->tm_low = p.low; r->tm_range = p.high - p.low; r->tm_oms = 1.0f - p.saturation;
+            TmFuse f = { t->out, KIND == VPT_TM_ARTISTIC ? 3 : (KIND == VPT_TM_RANGE ? 2 : 1), p.low, p.high - p.low, 1.0f - p.saturation };
+            if (!t->fuse_args_valid || memcmp(&f, &t->fuse_args, sizeof(f)) != 0) {       // the block behind the table (vpt_tonemap.h)
+                hipLaunchKernelGGL(k_tonemap_fuse_args, dim3(1), dim3(1), 0, t->ctx->stream, t->table, f);
+                t->fuse_args = f; t->fuse_args_valid = true;
+            }
+            r->tm_owner = t; r->tm_table = t->table; r->tm_out = t->out; r->tm_mode = f.mode;
             r->tm_valid = true;
             r->main_dirty = true;       // side streams of split passes must see the table this stream has just (re)built
         }
@@ -2460,6 +2464,7 @@ static int gather_enqueue_frame(vpt_gather *g, PassArgs &a, hipEvent_t t0 = null
     r->stop_events = fused_passes ? nullptr : g->rendered[st.rendered_event]; r->stop_used = false;
     a.render = st.in_place ? (uint2 *)((char *)g->recv[b] + st.render_offset) : (uint2 *)g->send[b];
     r->render_target = a.render;                                             // vpt_renderer_read(RENDER) returns the last frame's rows
+    a.tm_table = nullptr; r->tm_valid = false;                               // (a fused tone mapper follows the renderer's own buffer only)
     if (t0) HIP_TRY(hipEventRecord(t0, cs));
     if (fused_passes) {
         VPT_TRY(launch_mcm_multi(r, a, fused_passes));

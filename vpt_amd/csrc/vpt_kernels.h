@@ -126,9 +126,9 @@ struct PassArgs {
     const struct FrameVar *frame_table;     // ring of frame_mask + 1 entries
     const uint32_t *frame_counter;          // frames played so far (monotonic); entry = counter & frame_mask
     // tone mapping fused into the fused passes' frame store (VPT_TONEMAPPER_OPTION_FUSE): the armed tone mapper's byte table
-    // (vpt_tonemap.h: 65 536 entries indexed by the half bits of a channel + the constant alpha), its RGBA8 output (row-major local rows,
-    // like `render`), tm_mode 0 = none, 1 = the eight curve mappers, 2 = Range (alpha through the table), 3 = Artistic at saturation 1
-    const uint8_t *tm_table; uint32_t *tm_out; int tm_mode; float tm_low, tm_range, tm_one_minus_saturation;
+    // (vpt_tonemap.h: 65 536 entries indexed by the half bits of a channel + the constant alpha) with the TmFuse block behind it — the RGBA8
+    // output (row-major local rows, like `render`), the mapper's form and Artistic's uniforms; null = no tone mapper armed
+    const uint8_t *tm_table;
     uint32_t frame_mask;
     uint32_t frame_base;                    // fused sequences (multi_passes > 1): index of the sequence's first frame, BY VALUE — a pass split over
                                             // streams must not read the device counter, which the context's stream advances behind its own range only
@@ -218,20 +218,24 @@ VPT_DEV void store_frame_texel(uint2 *dst, uint2 v) {
 VPT_DEV void store_frame(const PassArgs &a, const Pix &p, uint2 v) {
     const size_t idx = (size_t)p.l * a.pm.W + p.i;
     store_frame_texel(&a.render[idx], v);
-    if (a.tm_mode) {                                            // wave-uniform
+    if (a.tm_table) {                                           // wave-uniform
         const uint8_t *table = a.tm_table;
+        typedef const TmFuse __attribute__((address_space(4))) *FuseArgs;       // constant address space: scalar loads
+        const FuseArgs f = (FuseArgs)(uintptr_t)(table + VPT_TM_FUSE_OFFSET);
+        const int mode = f->mode;
         uint32_t rgb = (uint32_t)table[v.x & 0xffffu] | ((uint32_t)table[v.x >> 16] << 8) | ((uint32_t)table[v.y & 0xffffu] << 16);
         uint32_t out;
-        if (a.tm_mode == 3) {                                   // k_tonemap_apply_table_artistic: the grey term must be finite
+        if (mode == 3) {                                        // k_tonemap_apply_table_artistic: the grey term must be finite
+            const float low = f->low, range = f->range;
             float4 c = half4_to_float4(v);
-            f3 w = { (c.x - a.tm_low) / a.tm_range, (c.y - a.tm_low) / a.tm_range, (c.z - a.tm_low) / a.tm_range };
+            f3 w = { (c.x - low) / range, (c.y - low) / range, (c.z - low) / range };
             const float gray = 0.57735026918962576f;
-            float z = (dot3(w, f3{ gray, gray, gray }) * gray) * a.tm_one_minus_saturation;
+            float z = (dot3(w, f3{ gray, gray, gray }) * gray) * f->one_minus_saturation;
             out = ((z == 0.0f) ? rgb : 0u) | 0xff000000u;
         } else {
-            out = rgb | ((uint32_t)table[a.tm_mode == 2 ? (v.y >> 16) : 65536u] << 24);
+            out = rgb | ((uint32_t)table[mode == 2 ? (v.y >> 16) : 65536u] << 24);
         }
-        a.tm_out[idx] = out;
+        f->out[idx] = out;
     }
 }
 

@@ -121,6 +121,12 @@ VPT_DEV uint32_t tonemap_texel(uint2 texel, const TonemapParams &p) {
 // the pass into byte gathers — bit-identical by construction, and HBM-bound instead of VALU-bound.
 // table[h] = the colour-channel byte for input half h; entry 65 536 = the alpha byte of the curve mappers.
 #define VPT_TM_TABLE_ENTRIES 65537
+// Behind the table (VPT_TONEMAPPER_OPTION_FUSE): what a renderer's fused frame store needs besides the table itself, so that its kernels
+// carry ONE pointer (two SGPRs for the life of the wave) and fetch the rest with scalar loads where they store
+#define VPT_TM_FUSE_OFFSET 65600
+struct TmFuse { uint32_t *out; int mode; float low, range, one_minus_saturation; };   // mode 1 = the eight curve mappers, 2 = Range, 3 = Artistic (saturation 1)
+#define VPT_TM_TABLE_BYTES (VPT_TM_FUSE_OFFSET + sizeof(TmFuse))
+__global__ void k_tonemap_fuse_args(uint8_t *table, TmFuse f) { *(TmFuse *)(table + VPT_TM_FUSE_OFFSET) = f; }
 template <int KIND>
 __global__ void __launch_bounds__(256) k_tonemap_table(uint8_t *table, TonemapParams p) {
     uint32_t h = blockIdx.x * 256u + threadIdx.x;             // 256 workgroups
