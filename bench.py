@@ -85,6 +85,13 @@ def parse():
                     help="MCM: 0 = every tile through the general kernel (VPT_OPTION_TILE_CLASSES off; results identical)")
     ap.add_argument("--split-streams", type=int, default=2,
                     help="MCM: K >= 2 = launch every pass as K tile-row ranges on K HIP streams (VPT_OPTION_SPLIT_STREAMS; results identical)")
+    ap.add_argument("--bucket-kernel", type=int, default=0,
+                    help="torch.distributed pipeline, MCM with tile classes: 1 = the line's pipeline runs every bucket of --frames-per-gather frames by ONE launch "
+                         "per tile class (VPT_OPTION_BUCKET_KERNEL: photon state in registers across the bucket, launch gap and staging once per bucket); "
+                         "0 = one launch per frame and class, as at N = 1 (the default: like for like with the single-GPU line)")
+    ap.add_argument("--bucket-form", type=int, default=1,
+                    help="N > 1: 1 = after the line's measurement, measure the torch.distributed pipeline once more with VPT_OPTION_BUCKET_KERNEL and report "
+                         "it beside the line (config.bucket_kernel_form); never the line's `value` unless --bucket-kernel 1")
     ap.add_argument("--split-caller-targets", type=int, default=-1,
                     help="torch.distributed pipeline: 1 = passes into the gather's buckets run on several streams too and are joined once per bucket; "
                          "-1 = yes when the MCM tile classes are in force (HIT | MISS kernels), no otherwise")
@@ -434,6 +441,9 @@ def main():
             r.set_option(N.OPTION_BOUNDARY_ATLAS, 0)
         if not args.tile_classes and args.renderer == "mcm":
             r.set_option(N.OPTION_TILE_CLASSES, 0)
+        bucket_capable = bool(use_dist and classes_on and split_callers and gather.F > 1 and args.fused)
+        if args.bucket_kernel and bucket_capable:
+            r.set_option(N.OPTION_BUCKET_KERNEL, 1)
         assert r.local_rows() == gather.rows
         nbytes = gather.send[0].numel() * 2
         r.reset()
@@ -465,6 +475,7 @@ def main():
                 if rank == 0:
                     print("native RCCL gather unavailable (%s); using torch.distributed all_gather" % err, file=sys.stderr)
 
+        bucket_on = [bool(args.bucket_kernel and bucket_capable)]
         fpl = args.frames_per_launch or 1             # measured: sequences do not beat frame-by-frame enqueue
         if fpl > 1 and native is None and use_dist:
             fpl = 1                                   # the torch.distributed gather is driven frame by frame
@@ -580,6 +591,9 @@ def main():
                 line["frame_check_kind"] = res["frame_check_kind"]
             if "other_pipeline_ms_per_step" in res:
                 line["config"]["other_pipeline_ms_per_step"] = res["other_pipeline_ms_per_step"]
+            line["config"]["bucket_kernel"] = bool(res.get("bucket_kernel"))
+            if state.get("bucket_form"):
+                line["config"]["bucket_kernel_form"] = state["bucket_form"]
             return line
         state["make_line"] = make_line
 
@@ -691,7 +705,8 @@ def main():
         def measure():
             """W warm-up steps (and >= --warmup-seconds), then --repeats blocks of EXACTLY K timed steps between barriers; the median
             block, max over ranks; the frame checked (N = 1: oracle band; N > 1: the gathered frame)"""
-            res = {"native": use_native[0], "gather_choice": None}
+            res = {"native": use_native[0], "gather_choice": None, "bucket_kernel": bucket_on[0] and not use_native[0]}
+            launches0 = r.bucket_launches() if args.renderer == "mcm" else 0
             r.set_profiling(args.profile_kernel)          # before the warm-up so that a captured graph carries its timing events
             if use_native[0] and args.gather_root == "auto":
                 # which exchange is faster on this node is a property of RCCL's p2p and collective paths: measure both
@@ -810,7 +825,23 @@ def main():
             torch.cuda.synchronize()
             res["ok"] = ok
             res["root"] = native.root if use_native[0] else -1
+            res["bucket_launches"] = (r.bucket_launches() - launches0) if args.renderer == "mcm" else 0
             return res
+
+        def measure_bucket_form():
+            """the torch.distributed pipeline once more with VPT_OPTION_BUCKET_KERNEL: reported beside the line, never as its value"""
+            was = use_native[0]
+            use_native[0] = False
+            r.set_option(N.OPTION_BUCKET_KERNEL, 1); bucket_on[0] = True
+            b = measure()
+            r.set_option(N.OPTION_BUCKET_KERNEL, 0); bucket_on[0] = False
+            use_native[0] = was
+            state["bucket_form"] = {
+                "ms_per_step": b["dt_max"] / args.steps * 1e3, "value": b["samples"] / b["dt_max"], "frames_per_launch": gather.F,
+                "frame_check": b["ok"], "bucket_launches": b["bucket_launches"],
+                "what": "the torch.distributed pipeline with VPT_OPTION_BUCKET_KERNEL: the %d frames of a bucket by ONE launch per tile class (photon state in "
+                        "registers across the bucket; every frame rendered, written to its slot and gathered; frames bit-identical).  Not the line's "
+                        "`value`: the single-GPU line launches once per frame, and so does the pipeline it is compared with" % gather.F}
 
         # N > 1 with the native pipeline: FIRST a complete measurement over torch.distributed's own all_gather (the
         # well-trodden path), so that a result exists whatever the library's RCCL pipeline does on this node; THEN the
@@ -821,6 +852,8 @@ def main():
             use_native[0] = False
             results.append(measure())
             state["fallback"] = results[0]
+            if args.bucket_form and bucket_capable and not args.bucket_kernel:
+                measure_bucket_form()
             deadline = threading.Timer(args.native_deadline, _native_gave_up)
             deadline.daemon = True
             deadline.start()
@@ -830,6 +863,10 @@ def main():
             state["fallback"] = None
         else:
             results.append(measure())
+            if args.bucket_form and bucket_capable and not args.bucket_kernel and not use_native[0]:
+                state["fallback"] = results[0]
+                measure_bucket_form()
+                state["fallback"] = None
         res = min(results, key=lambda x: x["dt_max"])
         if len(results) > 1:
             res["other_pipeline_ms_per_step"] = [x["dt_max"] / args.steps * 1e3 for x in results if x is not res][0]

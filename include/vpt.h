@@ -233,7 +233,15 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * consuming them; 5 waves per SIMD), 0 = the second where the HIT tiles are few enough to be resident at once at its occupancy
  * (<= 1280: a shard's share of a frame), the first otherwise.  Results identical. */
 #define VPT_OPTION_HIT_KERNEL_FORM 8
+/* VPT_OPTION_BUCKET_KERNEL (default 0; MCM renderer; extension): vpt_renderer_play_into() runs up to 16 frames of its bucket by ONE launch
+ * per tile class — the photon state stays in registers from the first frame to the last, launch gap, table staging and state traffic are
+ * paid once per bucket instead of once per frame (what a rank's small share of a sharded frame mostly pays for) — where the tile classes
+ * are in force (VPT_OPTION_TILE_CLASSES with VPT_OPTION_SPLIT_STREAMS >= 2 and VPT_OPTION_SPLIT_CALLER_TARGETS); elsewhere frame by
+ * frame as without the option.  Every frame is rendered and written to its slot either way; results identical. */
+#define VPT_OPTION_BUCKET_KERNEL 9
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
+/* (extension) how many buckets of frames vpt_renderer_play_into has run through the bucket kernels so far (VPT_OPTION_BUCKET_KERNEL) */
+VPT_API int vpt_renderer_bucket_launches(vpt_renderer *r, uint64_t *launches);
 /* (extension) tiles of each class under the last reset's matrix (all HIT when no classification is in force) and the
  * VPT_OPTION_VERIFY_TILE_CLASSES counter; any pointer may be null */
 VPT_API int vpt_renderer_tile_classes(vpt_renderer *r, int *hit_tiles, int *miss_tiles, uint64_t *violations);

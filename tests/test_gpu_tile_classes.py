@@ -282,3 +282,74 @@ def test_full_hd_frame_classes_on_and_off(gpu_ctx, oracle, fast, form):
     for k, (x, y) in enumerate(zip(run(0), run(1))):
         assert_same_bits(y, x, "output %d" % k)
     sc.gvol.destroy()
+
+
+def _frame_ring(r):
+    import ctypes as C
+    p, n = C.c_void_p(), C.c_size_t()
+    N.check(N.lib().vpt_renderer_frame_ring_device(r._h, C.byref(p), C.byref(n)))
+    return p.value, n.value
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("shard,form", [(None, 0), ((1, 3, 8), 0), (None, 1)])
+def test_bucket_kernel_equals_frame_by_frame(gpu_ctx, oracle, fast, shard, form):
+    """VPT_OPTION_BUCKET_KERNEL: vpt_renderer_play_into runs its frames by one launch per tile class (k_mcm_bucket_hit | k_mcm_bucket_miss,
+    seeds by value, state in registers).  Every frame of every bucket, all four state buffers and the sample count identical to the
+    frame-by-frame form; buckets of 1, 7 and 16 frames and one of 21 (two launches), render() calls in between, a camera that moves
+    without a reset (the classes are void: frame by frame from there on) and a second reset.  The renderer's own frame ring stands in
+    for the caller's bucket memory."""
+    env = env_map(16, 8)
+
+    def run(bucket):
+        sc = far_scene(gpu_ctx, oracle, w=200, h=184, env=env)
+        r = sc.renderer('mcm', shard=shard) if shard else sc.renderer('mcm')
+        r.set_option(N.OPTION_FAST_MATH, fast)
+        r.set_option(N.OPTION_HIT_KERNEL_FORM, form)
+        r.set_option(N.OPTION_SPLIT_STREAMS, 2)
+        r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
+        r.set_option(N.OPTION_BUCKET_KERNEL, bucket)
+        r.extinction = 4; r.steps = 4; r.anisotropy = 0.2
+        r.reset()
+        r.render()
+        r.play(16, frames=True)                             # allocates the ring (and lets read_frame_slot reach all 16 slots)
+        ring, slot = _frame_ring(r)
+        outs = []
+
+        def bucket_of(n):
+            done = 0
+            while done < n:                                 # the ring holds 16 slots: 21 frames = 16 + 5
+                m = min(16, n - done)
+                r.play_into(m, ring, slot)
+                for k in (0, m // 2, m - 1):
+                    outs.append(r.read_frame_slot(k).copy())
+                done += m
+
+        bucket_of(1); bucket_of(7)
+        r.set_render_target(0, 0)
+        r.render(); r.render()
+        outs.extend(all_buffers(r))
+        bucket_of(16); bucket_of(21)
+        r.set_render_target(0, 0)
+        outs.extend(all_buffers(r))
+        sc.camera.transform.localTranslation = [0.3, 0.2, 1.6]       # no reset: the classes are void, the bucket goes frame by frame
+        sc.camera.transform.localRotation = [0, 0, 0, 1]
+        bucket_of(5)
+        r.set_render_target(0, 0)
+        r.reset()
+        bucket_of(6)
+        r.set_render_target(0, 0)
+        r.render()
+        outs.extend(all_buffers(r))
+        count = r.sample_count()
+        # buckets of 1, 7, 16, 16 + 5 and (after the second reset) 6 frames went through the bucket kernels; the 5 behind the moved camera did not
+        assert r.bucket_launches() == (6 if bucket else 0)
+        if not shard:
+            assert count == sc.w * sc.h * 4 * (1 + 16 + 1 + 7 + 2 + 16 + 21 + 5 + 6 + 1)
+        r.destroy(); sc.gvol.destroy()
+        return outs, count
+
+    (a, na), (b, nb) = run(0), run(1)
+    assert len(a) == len(b) and na == nb
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert_same_bits(y, x, "bucket kernel vs frame by frame, output %d" % k)

@@ -10,6 +10,8 @@ import json
 try:
     j=json.load(open("gpurun_out/r03/dist1.json"))
     print(j["ms_per_step"], j["frame_check"], j["config"]["parallelism"], j["config"].get("other_pipeline_ms_per_step"), j["config"]["split_streams"], j["config"].get("native_preflight"))
+    b = j["config"].get("bucket_kernel_form")
+    if b: print("   bucket kernel form:", b["ms_per_step"], b["frame_check"], b["bucket_launches"], "frames per launch", b["frames_per_launch"])
 except Exception as e:
     print("no line:", e)
 PY

@@ -51,7 +51,7 @@ def main():
     gvol = vpt_amd.Volume.from_array(ctx, sphere_volume(512, noise=48.0), 'linear')
     out = {"unit": "us per frame", "frame": "%dx%d" % (W, H), "volume": "512^3",
            "forms": "tile classes in force unless named general_kernel; N streams = VPT_OPTION_SPLIT_STREAMS (classes: HIT tiles | MISS tiles)"}
-    for fast in (0, 1):
+    for fast in ((1, 0) if os.environ.get('VPT_PROBE_FAST_FIRST') else (0, 1)):
         tag = "fast_math" if fast else "bit_exact"
         full = make(ctx, gvol, W, H, fast, 2)
         out["full_frame_two_streams_%s" % tag] = timed(ctx, full.render, 200)         # the N = 1 default of bench.py
@@ -60,7 +60,7 @@ def main():
         full = make(ctx, gvol, W, H, fast, 3, classes=0)
         out["full_frame_general_kernel_three_streams_%s" % tag] = timed(ctx, full.render, 200)   # round 2's form
         full.destroy()
-        for world, rank in ((8, 3), (4, 1), (2, 0)):
+        for world, rank in (() if os.environ.get('VPT_PROBE_HANDOFF_ONLY') else ((8, 3), (4, 1), (2, 0))):
             for split in (1, 2, 3):
                 sh = make(ctx, gvol, W, H, fast, split, shard=(rank, world, 8))
                 out["shard_%d_of_%d_%d_streams_%s" % (rank, world, split, tag)] = timed(ctx, sh.render)
@@ -71,6 +71,22 @@ def main():
             sh = make(ctx, gvol, W, H, fast, 2, classes=0, shard=(rank, world, 8))
             out["shard_%d_of_%d_general_kernel_two_streams_%s" % (rank, world, tag)] = timed(ctx, sh.render)
             sh.destroy()
+        # VPT_OPTION_BUCKET_KERNEL: buckets of F frames through vpt_renderer_play_into (the renderer's frame ring stands in for the bucket)
+        import ctypes as C
+        for world, rank in (() if os.environ.get('VPT_PROBE_HANDOFF_ONLY') else ((8, 3), (4, 1), (2, 0), (1, 0))):
+            for bucket in (0, 1):
+                sh = make(ctx, gvol, W, H, fast, 2, shard=(rank, world, 8) if world > 1 else None)
+                sh.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
+                sh.set_option(N.OPTION_BUCKET_KERNEL, bucket)
+                sh.play(16, frames=True)
+                p, n = C.c_void_p(), C.c_size_t()
+                N.check(N.lib().vpt_renderer_frame_ring_device(sh._h, C.byref(p), C.byref(n)))
+                for F in (8, 16):
+                    t = timed(ctx, lambda: sh.play_into(F, p.value, n.value), 50) / F
+                    name = "shard_%d_of_%d" % (rank, world) if world > 1 else "full_frame"
+                    out["%s_buckets_of_%d_%s_%s" % (name, F, "bucket_kernel" if bucket else "frame_by_frame", tag)] = t
+                sh.set_render_target(0, 0)
+                sh.destroy()
         # a full frame of a 1/8 shard's size through the gather pipeline (one-rank communicator) against its plain render()
         hs = 136
         plain = make(ctx, gvol, W, hs, fast, 2)
@@ -85,13 +101,21 @@ def main():
         out["frame_1920x136_plain_two_streams_%s" % tag] = t_plain
         g.destroy(); piped.destroy(); plain.destroy()
         one = out["full_frame_two_streams_%s" % tag]
-        for world, rank in ((8, 3), (4, 1), (2, 0)):
+        for world, rank in (() if os.environ.get('VPT_PROBE_HANDOFF_ONLY') else ((8, 3), (4, 1), (2, 0))):
             k = min(out["shard_%d_of_%d_%d_streams_%s" % (rank, world, sp, tag)] for sp in (1, 2, 3))
             hnd = max(out["handoff_root0_%s" % tag], 0.0)
             out["per_rank_frame_at_%d_%s" % (world, tag)] = k + hnd
             out["projected_speedup_at_%d_%s" % (world, tag)] = one / (k + hnd)
+            kb = out["shard_%d_of_%d_buckets_of_8_bucket_kernel_%s" % (rank, world, tag)]
+            out["projected_speedup_at_%d_bucket_kernel_%s" % (world, tag)] = {
+                "per_rank_frame": kb + hnd, "against_the_single_gpu_frame_launched_frame_by_frame": one / (kb + hnd),
+                "against_the_single_gpu_frame_in_buckets_too": out["full_frame_buckets_of_8_bucket_kernel_%s" % tag] / (kb + hnd)}
     out["note"] = ("projected = this round's single-GPU frame (tile classes, two streams) / (best one-GPU time of one rank's share + hand-off); "
-                   "UNMEASURED on more than one GPU")
+                   "UNMEASURED on more than one GPU.  bucket_kernel = VPT_OPTION_BUCKET_KERNEL (8 frames of a bucket by one launch per tile class; every "
+                   "frame rendered and written); the frame gather itself is bound by xGMI (2.07 MB per link and 1080p RGBA16F frame: ~14 us at 153 GB/s), "
+                   "which no projection here includes.  hand-off = one frame through the native pipeline on a one-rank communicator minus the plain render() of the same frame, "
+                   "both one call per frame from Python: a difference of two host-paced 18-23 us measurements, 1.5-6.2 us from box to box; 16 frames per "
+                   "vpt_gather_play call are SLOWER (29-38 us per frame: with the host far ahead every stream wait becomes a barrier packet)")
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 1:
         json.dump(out, open(sys.argv[1], "w"), indent=1)

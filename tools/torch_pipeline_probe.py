@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Host cost of the torch.distributed gather pipeline (the N > 1 default of bench.py) on a one-rank RCCL group, with frames of a 1/8
-shard's size and whole frames, bucket by bucket as bench.py drives it (acquire_bucket -> vpt_renderer_play_into -> join ->
-all_gather of the bucket): where do the microseconds of the host loop go?"""
+"""Host cost of the torch.distributed gather pipeline (the N > 1 default of bench.py) on a one-rank RCCL group, with rank 3 of 8's share of
+the headline frame (1920 x 136 rows) and whole frames, bucket by bucket as bench.py drives it (acquire_bucket -> vpt_renderer_play_into ->
+join -> all_gather of the bucket): where do the microseconds of the host loop go?  VPT_PROBE_F = frames per bucket (default 8),
+VPT_PROBE_BUCKET = 1: VPT_OPTION_BUCKET_KERNEL (one launch per tile class and bucket)."""
 import json
 import os
 import sys
@@ -27,11 +28,16 @@ def main():
     stream = torch.cuda.Stream(device=device)
     with torch.cuda.stream(stream):
         for H in (136, 1080):
-            W, F = 1920, int(os.environ.get("VPT_PROBE_F", "4"))
+            W, F = 1920, int(os.environ.get("VPT_PROBE_F", "8"))
+            bucket_kernel = int(os.environ.get("VPT_PROBE_BUCKET", "0"))
             ctx = vpt_amd.Context(0, stream=stream.cuda_stream)
             gvol = vpt_amd.Volume.from_array(ctx, sphere_volume(512, noise=48.0), 'linear')
-            r = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng(), 'shard': (0, 1, 8)})
+            # H = 136: the rows rank 3 of 8 renders of the 1080-row frame (interleaved 8-row blocks); the one-rank gather moves frames of that size
+            shard, full_h = ((3, 8, 8), 1080) if H == 136 else ((0, 1, 8), H)
+            r = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / full_h), None, {'resolution': (W, full_h), 'transform': Transform(Node()), 'rng': GoldenRatioRng(), 'shard': shard})
+            assert int(r.local_rows()) == H
             r.set_option(N.OPTION_FAST_MATH, 1); r.set_option(N.OPTION_SPLIT_STREAMS, 2); r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
+            r.set_option(N.OPTION_BUCKET_KERNEL, bucket_kernel)
             r.reset()
             gather = FrameGather(dist, torch, W, H, device, always_collective=True, frames_per_gather=F)
             nbytes = gather.send[0].numel() * 2
@@ -55,7 +61,7 @@ def main():
             host = time.perf_counter() - t0
             gather.wait_all(); torch.cuda.synchronize()
             total = time.perf_counter() - t0
-            out["H%d" % H] = {"frames_per_bucket": F, "us_per_frame_total": total / (n * F) * 1e6, "us_per_frame_host_loop": host / (n * F) * 1e6,
+            out["H%d" % H] = {"frames_per_bucket": F, "bucket_kernel": bool(bucket_kernel), "bucket_launches": r.bucket_launches(), "us_per_frame_total": total / (n * F) * 1e6, "us_per_frame_host_loop": host / (n * F) * 1e6,
                               **{"host_us_per_bucket_" + k: v / n * 1e6 for k, v in acc.items()}}
             r.set_render_target(0, 0); r.destroy(); gvol.destroy(); ctx.destroy()
     print(json.dumps(out, indent=1))

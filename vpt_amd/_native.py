@@ -17,6 +17,7 @@ OPTION_SPLIT_CALLER_TARGETS = 5
 OPTION_TILE_CLASSES = 6
 OPTION_VERIFY_TILE_CLASSES = 7
 OPTION_HIT_KERNEL_FORM = 8
+OPTION_BUCKET_KERNEL = 9
 PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED, PLAY_FRAMES = 0, 1, 2, 3
 FRAME_SLOTS = 16
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO, RENDERER_DOS = 0, 1, 2, 3, 4, 5, 6, 7
@@ -45,7 +46,7 @@ SYMBOLS = [
     "vpt_renderer_set_environment", "vpt_renderer_resize",
     "vpt_renderer_reset", "vpt_renderer_generate", "vpt_renderer_integrate", "vpt_renderer_render_frame",
     "vpt_renderer_render", "vpt_renderer_play", "vpt_renderer_play_into", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
-    "vpt_renderer_set_render_target", "vpt_renderer_join", "vpt_renderer_read_frame_slot", "vpt_renderer_frame_ring_device",
+    "vpt_renderer_set_render_target", "vpt_renderer_join", "vpt_renderer_bucket_launches", "vpt_renderer_read_frame_slot", "vpt_renderer_frame_ring_device",
     "vpt_renderer_set_option", "vpt_renderer_set_lao_params", "vpt_renderer_set_occlusion_samples", "vpt_renderer_integrate_slices", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile", "vpt_renderer_profile_side", "vpt_renderer_tile_classes", "vpt_classify_tiles",
     "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play", "vpt_gather_set_root",
@@ -152,7 +153,7 @@ def lib():
         "vpt_renderer_read": [P, I, P, SZ], "vpt_renderer_play": [P, UP, P, I, I], "vpt_renderer_play_into": [P, UP, P, I, P, SZ],
         "vpt_gather_play": [P, UP, P, I, I], "vpt_gather_set_root": [P, I],
         "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
-        "vpt_renderer_set_render_target": [P, P, SZ], "vpt_renderer_join": [P], "vpt_renderer_read_frame_slot": [P, I, P, SZ], "vpt_renderer_frame_ring_device": [P, PP, C.POINTER(SZ)],
+        "vpt_renderer_set_render_target": [P, P, SZ], "vpt_renderer_join": [P], "vpt_renderer_bucket_launches": [P, C.POINTER(C.c_uint64)], "vpt_renderer_read_frame_slot": [P, I, P, SZ], "vpt_renderer_frame_ring_device": [P, PP, C.POINTER(SZ)],
         "vpt_renderer_set_option": [P, I, I],
         "vpt_renderer_set_lao_params": [P, C.POINTER(LaoParams)],
         "vpt_renderer_set_occlusion_samples": [P, P, I], "vpt_renderer_integrate_slices": [P, UP, P, I],

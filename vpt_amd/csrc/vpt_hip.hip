@@ -133,6 +133,8 @@ struct vpt_renderer {
     // tone mapping fused into the fused passes' frame store: the armed tone mapper (null: none), whether its output holds the tone-mapped
     // image of what the render buffer holds now, and the store's arguments (PassArgs.tm_*)
     struct vpt_tonemapper *tm_owner; bool tm_valid; const uint8_t *tm_table; uint32_t *tm_out; int tm_mode;
+    uint64_t bucket_launches;      // buckets of frames run by k_mcm_bucket_* so far (vpt_renderer_bucket_launches)
+    bool bucket_kernel;            // VPT_OPTION_BUCKET_KERNEL: vpt_renderer_play_into runs a bucket's frames by one launch per tile class
     int hit_form;                  // VPT_OPTION_HIT_KERNEL_FORM: 0 = by the number of HIT tiles, 1 = k_mcm_integrate, 2 = k_mcm_integrate_early
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
@@ -513,7 +515,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->fast_math = 0; r->boundary_atlas = 1;
     r->frame_ring = nullptr; r->ring_frames = 0; r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
-    memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0; r->hit_form = 0;
+    memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0; r->hit_form = 0; r->bucket_kernel = false; r->bucket_launches = 0;
     r->tm_owner = nullptr; r->tm_valid = false; r->tm_table = nullptr; r->tm_out = nullptr; r->tm_mode = 0;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -1080,6 +1082,62 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     return VPT_OK;
 }
 
+// VPT_OPTION_BUCKET_KERNEL: frames [0, count) of a bucket (frame f -> ring + f * slot_pixels texels) by one launch per tile class —
+// k_mcm_bucket_hit on the context's stream, k_mcm_bucket_miss on the first side stream.  *ready = false: the preconditions of the tile
+// classes do not hold (launch_mcm_pass) and the caller plays the frames one by one.
+typedef void (*BucketKernel)(PassArgs, FrameSeeds, uint32_t, uint2 *, uint32_t);
+static int mcm_before_pass(vpt_renderer *r, const PassArgs &a, bool *same_matrix);
+static int mcm_bucket_ready(vpt_renderer *r, const PassArgs &a, bool *ready) {
+    bool same = false;
+    VPT_TRY(mcm_before_pass(r, a, &same));
+    const bool two_streams = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers);
+    *ready = same && r->cls.enabled && mcm_classes_runnable(r, a) && two_streams && !r->cls.verify;
+    return VPT_OK;
+}
+static int launch_mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar *v, int count, uint2 *ring, uint32_t slot_pixels) {
+    if (count < 1 || count > VPT_BUCKET_FRAMES) return fail(VPT_ERR_INVALID, "a bucket launch holds 1..%d frames", VPT_BUCKET_FRAMES);
+    const bool wide = (variant_of(r) & VPT_V_WIDE) != 0, fast = r->fast_math != 0;
+    // HIT tiles few enough to be resident at once at the kernel's four waves per SIMD: the form with the early path end (launch_mcm_classes)
+    const bool early = r->hit_form == 2 || (r->hit_form == 0 && r->cls.n_hit <= 1024);
+    BucketKernel kh, km;
+    if (early) {
+        if (fast) kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE | VPT_V_FAST, true> : (BucketKernel)k_mcm_bucket_hit<VPT_V_FAST, true>;
+        else kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE, true> : (BucketKernel)k_mcm_bucket_hit<0, true>;
+    } else {
+        if (fast) kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE | VPT_V_FAST, false> : (BucketKernel)k_mcm_bucket_hit<VPT_V_FAST, false>;
+        else kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE, false> : (BucketKernel)k_mcm_bucket_hit<0, false>;
+    }
+    const bool late = !(fast && early);
+    km = fast ? (late ? (BucketKernel)k_mcm_bucket_miss<VPT_V_FAST, true> : (BucketKernel)k_mcm_bucket_miss<VPT_V_FAST, false>) : (BucketKernel)k_mcm_bucket_miss<0, true>;
+    const size_t lds_hit = lds_bytes(r), lds_miss = (size_t)r->tf_w * 2 * sizeof(float4);
+    if (lds_hit > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds_hit);
+    if (lds_hit > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hit));
+    if (r->side_busy && r->last_layout != 1) VPT_TRY(join_side(r));
+    r->last_layout = 1;
+    if (r->main_dirty) {
+        HIP_TRY(hipEventRecord(r->ev_fork, r->ctx->stream));
+        for (int i = 0; i + 1 < r->split; i++) HIP_TRY(hipStreamWaitEvent(r->side[i], r->ev_fork, 0));
+        r->main_dirty = false;
+    }
+    FrameSeeds fs;
+    for (int f = 0; f < VPT_BUCKET_FRAMES; f++) fs.seed[f] = f < count ? v[f].seed : 0.0f;
+    PassArgs part = a;
+    part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations; part.tm_table = nullptr;
+    if (r->cls.n_hit > 0) {
+        part.pm.tile_list = r->cls.list; part.pm.list_n = r->cls.n_hit;
+        hipLaunchKernelGGL(kh, dim3((unsigned)r->cls.n_hit), dim3(VPT_BLOCK), lds_hit, r->ctx->stream, part, fs, (uint32_t)count, ring, slot_pixels);
+    }
+    if (r->cls.n_miss > 0) {
+        part.pm.tile_list = r->cls.list + r->cls.n_hit; part.pm.list_n = r->cls.n_miss;
+        hipLaunchKernelGGL(km, dim3((unsigned)r->cls.n_miss), dim3(VPT_BLOCK), lds_miss, r->side[0], part, fs, (uint32_t)count, ring, slot_pixels);
+    }
+    r->side_busy = true; r->last_ranges = 2;
+    r->cls.stale = r->cls.n_miss > 0; r->cls.stale_fast = fast;
+    r->tm_valid = false;
+    r->bucket_launches++;
+    return VPT_OK;
+}
+
 #ifdef VPT_WITH_PERSISTENT_KERNELS
 template <typename K>
 static int launch_mcs_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
@@ -1537,7 +1595,20 @@ extern "C" int vpt_renderer_play_into(vpt_renderer *r, const vpt_uniforms *base,
     VPT_TRY(play_args(r, base, count, &a));
     const FrameVar *v = (const FrameVar *)frame_vars;
     r->target_is_callers = true;
-    for (int i = 0; i < count; i++) {
+    int i0 = 0;
+    // VPT_OPTION_BUCKET_KERNEL: up to VPT_BUCKET_FRAMES frames per launch of each tile class
+    while (r->kind == VPT_RENDERER_MCM && r->bucket_kernel && stride_bytes % 8 == 0 && stride_bytes / 8 <= 0xffffffffull && i0 < count) {
+        const int n = std::min(count - i0, VPT_BUCKET_FRAMES);
+        bool ready = false;
+        VPT_TRY(mcm_bucket_ready(r, a, &ready));
+        if (!ready) break;
+        uint2 *ring = (uint2 *)((char *)first_target + (size_t)i0 * stride_bytes);
+        Timed t(r, true, (uint32_t)n);
+        VPT_TRY(launch_mcm_bucket(r, a, v + i0, n, ring, (uint32_t)(stride_bytes / 8)));
+        i0 += n;
+        r->render_target = (uint2 *)((char *)first_target + (size_t)(i0 - 1) * stride_bytes);
+    }
+    for (int i = i0; i < count; i++) {
         r->render_target = (uint2 *)((char *)first_target + (size_t)i * stride_bytes);
         PassArgs f = frame_args(a, v[i]);
         f.render = r->render_target;
@@ -1624,6 +1695,11 @@ extern "C" int vpt_renderer_render_buffer_device(vpt_renderer *r, void **ptr, si
     if (!r || !ptr || !nbytes) return fail(VPT_ERR_INVALID, "null argument");
     VPT_TRY(join_side(r));
     *ptr = r->render_target ? r->render_target : r->render; *nbytes = (size_t)r->W * r->local_h * 8;
+    return VPT_OK;
+}
+extern "C" int vpt_renderer_bucket_launches(vpt_renderer *r, uint64_t *launches) {
+    if (!r || !launches) return fail(VPT_ERR_INVALID, "null argument");
+    *launches = r->bucket_launches;
     return VPT_OK;
 }
 extern "C" int vpt_renderer_join(vpt_renderer *r) {
@@ -1788,6 +1864,9 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_HIT_KERNEL_FORM: an MCM option");
             if (value < 0 || value > 2) return fail(VPT_ERR_INVALID, "VPT_OPTION_HIT_KERNEL_FORM: 0 (automatic), 1 or 2");
             r->hit_form = value; return VPT_OK;
+        case VPT_OPTION_BUCKET_KERNEL:
+            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_BUCKET_KERNEL: an MCM option");
+            r->bucket_kernel = value != 0; return VPT_OK;
         case VPT_OPTION_VERIFY_TILE_CLASSES:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_VERIFY_TILE_CLASSES: an MCM option");
             r->cls.verify = value != 0; return VPT_OK;

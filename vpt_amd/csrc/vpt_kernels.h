@@ -1320,6 +1320,86 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     mcm_multi_body<V, true>(a, npasses, ring, slot_pixels);
 }
 __global__ void k_advance_frames(uint32_t *counter, uint32_t n) { *counter = *counter + n; }
+
+// ---- a bucket of frames by ONE launch per tile class (VPT_OPTION_BUCKET_KERNEL, vpt_renderer_play_into) --------------------------
+// `nframes` render() passes of the tiles of one class, each pass's frame written to its slot of the caller's bucket (slot f =
+// ring + f * slot_pixels): what nframes launches of k_mcm_integrate<true> / k_mcm_miss<true> with those render targets write, with
+// the photon state in registers from the first pass to the last.  A rank's share of a sharded frame is a few hundred tiles: its pass
+// is ~8 us of arithmetic behind ~4-5 us of launch gap, table staging and state traffic (profiles/r03_shard8.json), and a bucket of
+// frames that one collective moves anyway (vpt_amd/tiles.py FrameGather) pays those once.  The frames' seeds travel BY VALUE: the two
+// classes run on two streams that nothing orders against an upload of the frame table.
+#define VPT_BUCKET_FRAMES 16
+struct FrameSeeds { float seed[VPT_BUCKET_FRAMES]; };
+template <int V, bool EARLY>
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_mcm_bucket_hit(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint32_t slot_pixels) {
+    Pix p = map_pixel(a.pm);
+    PhotonState st;
+    if (p.tile) st = photon_load(a, p.k);
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    if (!p.valid) return;
+    const float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
+    Photon ph = photon_unpack(st);
+    uint2 *dst = ring + ((size_t)p.l * a.pm.W + p.i);
+    for (uint32_t f = 0; f < nframes; f++) {
+        a.seed = fs.seed[f];
+        if (V & VPT_V_FAST) {
+            if (EARLY) mcm_events_fast_early<V & ~VPT_V_FAST>(a, t, ph, px, py);
+            else mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
+        } else {
+            if (EARLY) mcm_events_early<V>(a, t, ph, px, py);
+            else mcm_events<V>(a, t, ph, px, py);
+        }
+        // (between two launches the counters travel as floats and come back through uint(w + 0.5): the identity below 2^24)
+        store_frame_texel(dst, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+        dst += slot_pixels;
+    }
+    photon_store(a, p.k, ph);
+}
+template <int V, bool LATE>     // (the contract's arithmetic keeps six more values alive across the frame loop: 6 waves per SIMD there)
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu((V & VPT_V_FAST) ? 8 : 6, 8)))
+k_mcm_bucket_miss(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint32_t slot_pixels) {
+    Pix p = map_pixel(a.pm);
+    float4 s1 = make_float4(0.0f, 0.0f, 1.0f, 0.0f), s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    f3 s0 = { 0.0f, 0.0f, 0.0f };
+    if (p.tile) {
+        s1 = a.st1[p.k]; s3 = a.st3[p.k];
+        if (a.miss_load_pos) s0 = ((const f3 *)a.st0)[p.k];
+    }
+    extern __shared__ float4 lds_raw[];
+    const float4 *tf = stage_tf(lds_raw, a);
+    if (!p.valid) return;
+    const float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
+    Photon ph;
+    ph.direction = f3{ s1.x, s1.y, s1.z };
+    ph.bounces = 0u;
+    ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
+    ph.radiance = f3{ s3.x, s3.y, s3.z };
+    ph.samples = (uint32_t)(s3.w + 0.5f);
+    uint2 *dst = ring + ((size_t)p.l * a.pm.W + p.i);
+    if (V & VPT_V_FAST) {
+        const FastPixel c = fast_pixel(a, px, py);
+        ph.position = a.miss_load_pos ? s0 : photon_start_fast(c.from0, ph.direction);
+        for (uint32_t f = 0; f < nframes; f++) {
+            a.seed = fs.seed[f];
+            mcm_events_miss_fast<V & ~VPT_V_FAST, false, LATE>(a, tf, c, ph, px, py);
+            store_frame_texel(dst, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+            dst += slot_pixels;
+        }
+    } else {
+        const f3 from0 = unproject_near(px, py, a);
+        ph.position = a.miss_load_pos ? s0 : photon_start(from0, ph.direction);
+        for (uint32_t f = 0; f < nframes; f++) {
+            a.seed = fs.seed[f];
+            mcm_events_miss<V, false, LATE>(a, tf, ph, px, py, from0);
+            store_frame_texel(dst, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+            dst += slot_pixels;
+        }
+    }
+    a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
+    a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
+}
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_render(PassArgs a) {   // MCMRenderer.glsl:204-206
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;

@@ -291,6 +291,12 @@ class AbstractRenderer(PropertyBag):
         u, vars_ = self._collect_frames(count)
         N.check(N.lib().vpt_renderer_play_into(self._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), count, C.c_void_p(first_target), stride_bytes))
 
+    def bucket_launches(self):
+        """buckets of frames run by the bucket kernels so far (OPTION_BUCKET_KERNEL)"""
+        n = C.c_uint64(0)
+        N.check(N.lib().vpt_renderer_bucket_launches(self._h, C.byref(n)))
+        return n.value
+
     def read_frame_slot(self, slot):
         """frame `slot` of the last play(frames=True) call: [local rows][W][4] float16"""
         out = np.empty((self.local_rows(), self._size()[0], 4), dtype=np.float16)
