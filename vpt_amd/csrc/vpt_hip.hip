@@ -1094,7 +1094,7 @@ static int mcm_bucket_ready(vpt_renderer *r, const PassArgs &a, bool *ready) {
     *ready = same && r->cls.enabled && mcm_classes_runnable(r, a) && two_streams && !r->cls.verify;
     return VPT_OK;
 }
-static int launch_mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar *v, int count, uint2 *ring, uint32_t slot_pixels) {
+static int launch_mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar *v, int count, uint2 *ring, uint32_t slot_pixels, bool last_to_render_buffer) {
     if (count < 1 || count > VPT_BUCKET_FRAMES) return fail(VPT_ERR_INVALID, "a bucket launch holds 1..%d frames", VPT_BUCKET_FRAMES);
     const bool wide = (variant_of(r) & VPT_V_WIDE) != 0, fast = r->fast_math != 0;
     // HIT tiles few enough to be resident at once at the kernel's four waves per SIMD: the form with the early path end (launch_mcm_classes)
@@ -1123,6 +1123,7 @@ static int launch_mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar 
     for (int f = 0; f < VPT_BUCKET_FRAMES; f++) fs.seed[f] = f < count ? v[f].seed : 0.0f;
     PassArgs part = a;
     part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations; part.tm_table = nullptr;
+    if (!last_to_render_buffer) part.render = nullptr;
     if (r->cls.n_hit > 0) {
         part.pm.tile_list = r->cls.list; part.pm.list_n = r->cls.n_hit;
         hipLaunchKernelGGL(kh, dim3((unsigned)r->cls.n_hit), dim3(VPT_BLOCK), lds_hit, r->ctx->stream, part, fs, (uint32_t)count, ring, slot_pixels);
@@ -1560,9 +1561,12 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
             ring = r->frame_ring; r->ring_frames = count;
         }
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
+        bool by_class = false;                           // VPT_PLAY_FRAMES where the tile classes are in force: the bucket kernels, one launch per class
+        if (ring && count <= VPT_BUCKET_FRAMES) VPT_TRY(mcm_bucket_ready(r, a, &by_class));
         {
             Timed t(r, true, (uint32_t)count);
-            VPT_TRY(launch_mcm_multi(r, a, (uint32_t)count, ring));
+            if (by_class) VPT_TRY(launch_mcm_bucket(r, a, (const FrameVar *)frame_vars, count, ring, (uint32_t)((size_t)r->W * r->local_h), true));
+            else VPT_TRY(launch_mcm_multi(r, a, (uint32_t)count, ring));
         }
         hipLaunchKernelGGL(k_advance_frames, dim3(1), dim3(1), 0, c->stream, r->frame_counter, (uint32_t)count);   // keeps the graph path's counter in step
         HIP_TRY(hipGetLastError());
@@ -1604,7 +1608,7 @@ extern "C" int vpt_renderer_play_into(vpt_renderer *r, const vpt_uniforms *base,
         if (!ready) break;
         uint2 *ring = (uint2 *)((char *)first_target + (size_t)i0 * stride_bytes);
         Timed t(r, true, (uint32_t)n);
-        VPT_TRY(launch_mcm_bucket(r, a, v + i0, n, ring, (uint32_t)(stride_bytes / 8)));
+        VPT_TRY(launch_mcm_bucket(r, a, v + i0, n, ring, (uint32_t)(stride_bytes / 8), false));
         i0 += n;
         r->render_target = (uint2 *)((char *)first_target + (size_t)(i0 - 1) * stride_bytes);
     }

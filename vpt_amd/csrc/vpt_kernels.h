@@ -1356,6 +1356,8 @@ k_mcm_bucket_hit(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint3
         dst += slot_pixels;
     }
     photon_store(a, p.k, ph);
+    // (VPT_PLAY_FRAMES: the render buffer shows the last frame, as after `nframes` render() calls; null for a caller's bucket)
+    if (a.render) store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
 }
 template <int V, bool LATE>     // (the contract's arithmetic keeps six more values alive across the frame loop: 6 waves per SIMD there)
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu((V & VPT_V_FAST) ? 8 : 6, 8)))
@@ -1399,6 +1401,7 @@ k_mcm_bucket_miss(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint
     }
     a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
     a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
+    if (a.render) store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
 }
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_render(PassArgs a) {   // MCMRenderer.glsl:204-206
     Pix p = map_pixel(a.pm);
