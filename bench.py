@@ -279,6 +279,7 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
             r = vpt_amd.RendererFactory('mcm')(ctx, gvol512, default_camera(W / H), None,
                                                {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
             r.set_option(N.OPTION_FAST_MATH, fm)
+            r.set_option(N.OPTION_SPLIT_STREAMS, 2)          # tile classes in force: one launch per class (k_mcm_bucket_hit | k_mcm_bucket_miss)
             r.reset()
             for _ in range(4):
                 r.play(16, frames=True)
@@ -295,7 +296,7 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
             r.destroy()
             out[name] = {"ms_per_frame": dt / (12 * 16) * 1e3, "samples_per_s": ns / dt, "frames_per_launch": 16,
                          "roofline": {"frac": B_ALG_MCM * ns / dt / (HBM_PEAK_GBS * 1e9)},
-                         "note": "not the judged step (one render() per launch): one launch = 16 frames, each written to its ring slot, "
+                         "note": "not the judged step (one render() per launch): one launch per tile class = 16 frames, each written to its ring slot, "
                                  "photon state read once and written once per launch"}
     except Exception as e:                              # reporting only: the headline line must still be printed
         out["error"] = repr(e)
