@@ -38,3 +38,26 @@ def test_native_gather_two_ranks():
             raise AssertionError("two-rank gather did not finish in 300 s (a hung collective?)")
         outs.append(out.decode())
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_torch_pipeline_on_one_rank_frame_by_frame_and_with_bucket_kernels():
+    """bench.py's N > 1 code path on a one-rank RCCL group (--force-dist 1 --gather torch), small sizes: buckets of 8 frames through
+    vpt_renderer_play_into + one all_gather each, the gathered frame bit-compared with the same frames rendered unsharded — frame by frame
+    (the line) and with VPT_OPTION_BUCKET_KERNEL (config.bucket_kernel_form: one launch per tile class and bucket).  A fresh process:
+    a GPU-initialised torch stays out of this one."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "1", "--gather", "torch", "--volume", "64", "--width", "640",
+                        "--height", "368", "--steps", "40", "--warmup", "8", "--repeats", "2", "--other-configs", "0", "--cpu-baseline", "0",
+                        "--stream-probe", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["frame_check"] is True
+    assert line["config"]["frames_per_gather"] == 8 and line["config"]["bucket_kernel"] is False
+    b = line["config"]["bucket_kernel_form"]
+    assert b["frame_check"] is True and b["frames_per_launch"] == 8
+    assert b["bucket_launches"] >= (1000 + 2 * 40) // 8          # the warm-up and both timed blocks went through the bucket kernels
