@@ -327,6 +327,15 @@ VPT_API int vpt_tonemapper_set_source_image(vpt_tonemapper *t, const void *rgba1
 VPT_API int vpt_tonemapper_render(vpt_tonemapper *t, const struct vpt_tonemap_params *p);
 /* getTexture(): [rows][width] RGBA8 -> host (blocks); rows = the source's rows (the resolution's height when unsharded) */
 VPT_API int vpt_tonemapper_read(vpt_tonemapper *t, void *dst, size_t nbytes);
+/* (extension) vpt_renderer_play_into with the frames AS THE TONE MAPPER SHOWS THEM: frame i of `count` eager render() passes, tone-mapped to
+ * RGBA8 by `t`, into caller-owned device memory at first_target + i * stride_bytes (stride >= width * local rows * 4) — half the bytes
+ * of the RGBA16F frames for the collective that moves a bucket of them.  `t` must be armed on `r`: bound with vpt_tonemapper_set_source,
+ * VPT_TONEMAPPER_OPTION_FUSE on, vpt_tonemapper_render called once with the parameters to show (its table form).  MCM with the tile
+ * classes in force runs the bucket kernels (their frame store looks the texel up in the tone mapper's table; the renderer's own render
+ * buffer is not written); otherwise frame by frame through the fused pass and a device copy of the tone mapper's output.  Texels
+ * identical to vpt_tonemapper_render on the same frames.  Joins as vpt_renderer_play_into does (VPT_OPTION_SPLIT_CALLER_TARGETS). */
+VPT_API int vpt_renderer_play_into_display(vpt_renderer *r, vpt_tonemapper *t, const struct vpt_uniforms *base, const float *frame_vars, int count,
+                                           void *first_target, size_t stride_bytes);
 VPT_API int vpt_tonemapper_rows(vpt_tonemapper *t, int *rows);
 VPT_API int vpt_tonemapper_output_device(vpt_tonemapper *t, void **ptr, size_t *nbytes);
 /* Range and the eight curve mappers can run through a 65 536-entry byte table (every output byte depends on one

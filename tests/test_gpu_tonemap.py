@@ -437,3 +437,74 @@ def test_fused_tone_mapping_full_hd_mcm_tile_classes(gpu_ctx, oracle):
         if k in (0, 1, 5):
             same(tm.getTexture(), oracle.tonemap('artistic', r.getTexture(), **{p['name']: p['value'] for p in tm.properties}), "frame %d" % k)
     tm.destroy(); r.destroy(); gvol.destroy()
+
+
+@pytest.mark.parametrize("rkind,fast", [("mcm", 0), ("mcm", 1), ("eam", 0)])
+@pytest.mark.parametrize("tkind", ["artistic", "range", "aces"])
+def test_play_into_display_equals_the_tone_mapped_frames(gpu_ctx, oracle, rkind, fast, tkind):
+    """vpt_renderer_play_into_display: a bucket of frames as the armed tone mapper shows them (RGBA8, half the bytes a collective has to move).
+    MCM with the tile classes in force runs the bucket kernels with the tone mapper's table in their frame store; a moved camera (classes
+    void) and the other renderers go frame by frame through the fused pass + a copy of the tone mapper's output.  Every frame must equal
+    render() + toneMapper.render() of the same frame.  The renderer's frame ring stands in for the caller's bucket memory."""
+    import ctypes as C
+    from vpt_amd import _native as N
+    from conftest import orbit_camera
+    w, h = 208, 144
+    vol = sphere_volume(24, noise=40.0)
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, 'linear')
+
+    def make():
+        cam = orbit_camera(w / h, 0.7, -0.3, 3.0)
+        r = vpt_amd.RendererFactory(rkind)(gpu_ctx, gvol, cam, None, {'resolution': (w, h), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+        r.setTransferFunction(colour_tf(64, 1))
+        if rkind == 'mcm':
+            r.extinction = 6; r.steps = 4
+            r.set_option(N.OPTION_FAST_MATH, fast)
+        r.set_option(N.OPTION_SPLIT_STREAMS, 2)
+        r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
+        r.reset()
+        tm = vpt_amd.ToneMapperFactory(tkind)(gpu_ctx, r, {'resolution': (w, h)})
+        tm.set_option(N.TONEMAPPER_OPTION_TABLE, N.TONEMAPPER_TABLE_ALWAYS)
+        return r, tm, cam
+
+    # the reference sequence: render() + toneMapper.render(), frame by frame
+    r, tm, cam = make()
+    want = []
+    r.render(); tm.render()
+    for k in range(7 + 3):
+        if k == 7:
+            cam.transform.localTranslation = [0.3, 0.2, 1.6]; cam.transform.localRotation = [0, 0, 0, 1]
+        r.render(); tm.render()
+        want.append(tm.getTexture().copy())
+    tm.destroy(); r.destroy()
+
+    r, tm, cam = make()
+    r.render(); tm.render()                                              # arms the tone mapper on the renderer
+    # bucket memory: the frame ring of an idle MCM renderer on the same context stands in for the caller's buffers (16 slots of w*h*8 bytes)
+    aux = vpt_amd.MCMRenderer(gpu_ctx, gvol, orbit_camera(w / h), None, {'resolution': (w, h), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+    aux.reset(); aux.play(16, frames=True)
+    p_, n_ = C.c_void_p(), C.c_size_t()
+    N.check(N.lib().vpt_renderer_frame_ring_device(aux._h, C.byref(p_), C.byref(n_)))
+    ptr, stride = p_.value, w * h * 4
+    assert n_.value == 2 * stride
+
+    def display_frames(count):
+        r.join()                                                         # VPT_OPTION_SPLIT_CALLER_TARGETS: the caller joins before it reads
+        slots = [aux.read_frame_slot(k).view(np.uint8).reshape(2, h, w, 4) for k in range((count + 1) // 2)]
+        return np.concatenate(slots)[:count].copy()
+
+    launches0 = r.bucket_launches() if rkind == 'mcm' else 0
+    r.play_into_display(tm, 7, ptr, stride)
+    got = display_frames(7)
+    if rkind == 'mcm':
+        assert r.bucket_launches() == launches0 + 1
+    cam.transform.localTranslation = [0.3, 0.2, 1.6]; cam.transform.localRotation = [0, 0, 0, 1]     # no reset: frame by frame from here on
+    r.play_into_display(tm, 3, ptr, stride)
+    got2 = display_frames(3)
+    if rkind == 'mcm':
+        assert r.bucket_launches() == launches0 + 1
+    for k in range(7):
+        same(got[k], want[k], "%s -> %s: display frame %d of the bucket" % (rkind, tkind, k))
+    for k in range(3):
+        same(got2[k], want[7 + k], "%s -> %s: display frame %d behind the moved camera" % (rkind, tkind, k))
+    aux.destroy(); tm.destroy(); r.destroy(); gvol.destroy()

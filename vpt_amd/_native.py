@@ -45,7 +45,7 @@ SYMBOLS = [
     "vpt_renderer_destroy", "vpt_renderer_set_volume", "vpt_renderer_set_transfer_function",
     "vpt_renderer_set_environment", "vpt_renderer_resize",
     "vpt_renderer_reset", "vpt_renderer_generate", "vpt_renderer_integrate", "vpt_renderer_render_frame",
-    "vpt_renderer_render", "vpt_renderer_play", "vpt_renderer_play_into", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
+    "vpt_renderer_render", "vpt_renderer_play", "vpt_renderer_play_into", "vpt_renderer_play_into_display", "vpt_renderer_read", "vpt_renderer_render_buffer_device",
     "vpt_renderer_set_render_target", "vpt_renderer_join", "vpt_renderer_bucket_launches", "vpt_renderer_read_frame_slot", "vpt_renderer_frame_ring_device",
     "vpt_renderer_set_option", "vpt_renderer_set_lao_params", "vpt_renderer_set_occlusion_samples", "vpt_renderer_integrate_slices", "vpt_renderer_sample_count", "vpt_renderer_clear_sample_count",
     "vpt_renderer_set_profiling", "vpt_renderer_profile", "vpt_renderer_profile_side", "vpt_renderer_tile_classes", "vpt_classify_tiles",
@@ -150,7 +150,7 @@ def lib():
         "vpt_renderer_resize": [P, I, I],
         "vpt_renderer_reset": [P, UP], "vpt_renderer_generate": [P, UP], "vpt_renderer_integrate": [P, UP],
         "vpt_renderer_render_frame": [P, UP], "vpt_renderer_render": [P, UP],
-        "vpt_renderer_read": [P, I, P, SZ], "vpt_renderer_play": [P, UP, P, I, I], "vpt_renderer_play_into": [P, UP, P, I, P, SZ],
+        "vpt_renderer_read": [P, I, P, SZ], "vpt_renderer_play": [P, UP, P, I, I], "vpt_renderer_play_into": [P, UP, P, I, P, SZ], "vpt_renderer_play_into_display": [P, P, UP, P, I, P, SZ],
         "vpt_gather_play": [P, UP, P, I, I], "vpt_gather_set_root": [P, I],
         "vpt_renderer_render_buffer_device": [P, PP, C.POINTER(SZ)],
         "vpt_renderer_set_render_target": [P, P, SZ], "vpt_renderer_join": [P], "vpt_renderer_bucket_launches": [P, C.POINTER(C.c_uint64)], "vpt_renderer_read_frame_slot": [P, I, P, SZ], "vpt_renderer_frame_ring_device": [P, PP, C.POINTER(SZ)],

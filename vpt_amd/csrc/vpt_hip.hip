@@ -1085,7 +1085,7 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
 // VPT_OPTION_BUCKET_KERNEL: frames [0, count) of a bucket (frame f -> ring + f * slot_pixels texels) by one launch per tile class —
 // k_mcm_bucket_hit on the context's stream, k_mcm_bucket_miss on the first side stream.  *ready = false: the preconditions of the tile
 // classes do not hold (launch_mcm_pass) and the caller plays the frames one by one.
-typedef void (*BucketKernel)(PassArgs, FrameSeeds, uint32_t, uint2 *, uint32_t);
+typedef void (*BucketKernel)(PassArgs, FrameSeeds, uint32_t, void *, uint32_t);
 static int mcm_before_pass(vpt_renderer *r, const PassArgs &a, bool *same_matrix);
 static int mcm_bucket_ready(vpt_renderer *r, const PassArgs &a, bool *ready) {
     bool same = false;
@@ -1094,21 +1094,29 @@ static int mcm_bucket_ready(vpt_renderer *r, const PassArgs &a, bool *ready) {
     *ready = same && r->cls.enabled && mcm_classes_runnable(r, a) && two_streams && !r->cls.verify;
     return VPT_OK;
 }
-static int launch_mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar *v, int count, uint2 *ring, uint32_t slot_pixels, bool last_to_render_buffer) {
+template <bool DISPLAY>
+static void bucket_kernels(bool wide, bool fast, bool early, BucketKernel *kh, BucketKernel *km) {
+    if (early) {
+        if (fast) *kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE | VPT_V_FAST, true, DISPLAY> : (BucketKernel)k_mcm_bucket_hit<VPT_V_FAST, true, DISPLAY>;
+        else *kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE, true, DISPLAY> : (BucketKernel)k_mcm_bucket_hit<0, true, DISPLAY>;
+    } else {
+        if (fast) *kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE | VPT_V_FAST, false, DISPLAY> : (BucketKernel)k_mcm_bucket_hit<VPT_V_FAST, false, DISPLAY>;
+        else *kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE, false, DISPLAY> : (BucketKernel)k_mcm_bucket_hit<0, false, DISPLAY>;
+    }
+    const bool late = !(fast && early);
+    *km = fast ? (late ? (BucketKernel)k_mcm_bucket_miss<VPT_V_FAST, true, DISPLAY> : (BucketKernel)k_mcm_bucket_miss<VPT_V_FAST, false, DISPLAY>)
+               : (BucketKernel)k_mcm_bucket_miss<0, true, DISPLAY>;
+}
+// display_table: null = RGBA16F slots; else the armed tone mapper's table — RGBA8 slots (slot_pixels counts texels either way)
+static int launch_mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar *v, int count, void *ring, uint32_t slot_pixels, bool last_to_render_buffer,
+                             const uint8_t *display_table = nullptr) {
     if (count < 1 || count > VPT_BUCKET_FRAMES) return fail(VPT_ERR_INVALID, "a bucket launch holds 1..%d frames", VPT_BUCKET_FRAMES);
     const bool wide = (variant_of(r) & VPT_V_WIDE) != 0, fast = r->fast_math != 0;
     // HIT tiles few enough to be resident at once at the kernel's four waves per SIMD: the form with the early path end (launch_mcm_classes)
     const bool early = r->hit_form == 2 || (r->hit_form == 0 && r->cls.n_hit <= 1024);
     BucketKernel kh, km;
-    if (early) {
-        if (fast) kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE | VPT_V_FAST, true> : (BucketKernel)k_mcm_bucket_hit<VPT_V_FAST, true>;
-        else kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE, true> : (BucketKernel)k_mcm_bucket_hit<0, true>;
-    } else {
-        if (fast) kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE | VPT_V_FAST, false> : (BucketKernel)k_mcm_bucket_hit<VPT_V_FAST, false>;
-        else kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE, false> : (BucketKernel)k_mcm_bucket_hit<0, false>;
-    }
-    const bool late = !(fast && early);
-    km = fast ? (late ? (BucketKernel)k_mcm_bucket_miss<VPT_V_FAST, true> : (BucketKernel)k_mcm_bucket_miss<VPT_V_FAST, false>) : (BucketKernel)k_mcm_bucket_miss<0, true>;
+    if (display_table) bucket_kernels<true>(wide, fast, early, &kh, &km);
+    else bucket_kernels<false>(wide, fast, early, &kh, &km);
     const size_t lds_hit = lds_bytes(r), lds_miss = (size_t)r->tf_w * 2 * sizeof(float4);
     if (lds_hit > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds_hit);
     if (lds_hit > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hit));
@@ -1122,7 +1130,7 @@ static int launch_mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar 
     FrameSeeds fs;
     for (int f = 0; f < VPT_BUCKET_FRAMES; f++) fs.seed[f] = f < count ? v[f].seed : 0.0f;
     PassArgs part = a;
-    part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations; part.tm_table = nullptr;
+    part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations; part.tm_table = display_table;
     if (!last_to_render_buffer) part.render = nullptr;
     if (r->cls.n_hit > 0) {
         part.pm.tile_list = r->cls.list; part.pm.list_n = r->cls.n_hit;
@@ -2235,6 +2243,51 @@ extern "C" int vpt_tonemapper_render(vpt_tonemapper *t, const struct vpt_tonemap
     if (white) { hipStreamSynchronize(c->stream); hipFree(white); }
     if (e != hipSuccess) return fail(VPT_ERR_HIP, "tone-map launch: %s", hipGetErrorString(e));
     t->rows = rows;
+    return VPT_OK;
+}
+// `count` render() passes, frame i AS THE ARMED TONE MAPPER SHOWS IT (RGBA8) into caller memory at first_target + i * stride_bytes: the
+// bucket a collective moves holds half the bytes of vpt_renderer_play_into's RGBA16F frames.  MCM with the tile classes in force: the
+// bucket kernels (one launch per class, the texel through the tone mapper's table in their frame store); otherwise frame by frame
+// through the fused pass (which writes the tone mapper's output, VPT_TONEMAPPER_OPTION_FUSE) and a device copy of that output.
+extern "C" int vpt_renderer_play_into_display(vpt_renderer *r, vpt_tonemapper *t, const vpt_uniforms *base, const float *frame_vars, int count,
+                                              void *first_target, size_t stride_bytes) {
+    if (!r || !t || !base || !frame_vars || !first_target) return fail(VPT_ERR_INVALID, "null argument");
+    if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "frame sequences are not defined for the DOS renderer: drive it slice by slice");
+    if (t->source != r || r->tm_owner != t || !r->tm_table || !t->table_valid || !t->out)
+        return fail(VPT_ERR_INVALID, "the tone mapper is not armed on this renderer: bind it (vpt_tonemapper_set_source), keep VPT_TONEMAPPER_OPTION_FUSE on and "
+                                     "call vpt_tonemapper_render once with the parameters to show (table form)");
+    if (r->render_target) return fail(VPT_ERR_INVALID, "a caller-owned render target is set: restore the renderer's own buffer first");
+    const size_t need = (size_t)r->W * r->local_h * 4;
+    if (stride_bytes < need || stride_bytes % 4) return fail(VPT_ERR_INVALID, "target stride %zu: at least %zu bytes, a multiple of 4", stride_bytes, need);
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    PassArgs a;
+    VPT_TRY(play_args(r, base, count, &a));
+    const FrameVar *v = (const FrameVar *)frame_vars;
+    int i0 = 0;
+    while (r->kind == VPT_RENDERER_MCM && stride_bytes / 4 <= 0xffffffffull && i0 < count) {
+        const int n = std::min(count - i0, VPT_BUCKET_FRAMES);
+        bool ready = false;
+        VPT_TRY(mcm_bucket_ready(r, a, &ready));
+        if (!ready) break;
+        Timed tm(r, true, (uint32_t)n);
+        VPT_TRY(launch_mcm_bucket(r, a, v + i0, n, (char *)first_target + (size_t)i0 * stride_bytes, (uint32_t)(stride_bytes / 4), false, r->tm_table));
+        i0 += n;
+    }
+    for (int i = i0; i < count; i++) {
+        PassArgs f = frame_args(a, v[i]);
+        {
+            Timed tm(r, true);
+            VPT_TRY(launch_fused(r, f));                   // armed: the pass writes the tone mapper's output next to the render buffer
+        }
+        // (a pass that did not keep the output current — the texels of tiles it skipped are from before a bucket launch — : the separate pass)
+        if (!r->tm_valid) VPT_TRY(vpt_tonemapper_render(t, (const vpt_tonemap_params *)&t->table_params));
+        VPT_TRY(join_side(r));
+        HIP_TRY(hipMemcpyAsync((char *)first_target + (size_t)i * stride_bytes, t->out, need, hipMemcpyDeviceToDevice, r->ctx->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    if (!r->split_callers) VPT_TRY(join_side(r));            // (with VPT_OPTION_SPLIT_CALLER_TARGETS the caller joins, once per bucket)
+    r->warmed = true;
+    if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)base->steps * (uint64_t)count;
     return VPT_OK;
 }
 extern "C" int vpt_tonemapper_rows(vpt_tonemapper *t, int *rows) {

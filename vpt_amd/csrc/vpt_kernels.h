@@ -212,30 +212,33 @@ VPT_DEV uint2 pack_half4(float x, float y, float z, float w) {
 VPT_DEV void store_frame_texel(uint2 *dst, uint2 v) {
     __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x, (unsigned long long *)dst);
 }
+// the armed tone mapper's RGBA8 texel of an RGBA16F texel: the same table lookups as k_tonemap_apply_table* (vpt_tonemap.h) — bit-identical to
+// the separate pass by construction; *out (if asked for) = the tone mapper's output image
+VPT_DEV uint32_t tone_map_texel(const uint8_t *table, uint2 v, uint32_t **out) {
+    typedef const TmFuse __attribute__((address_space(4))) *FuseArgs;       // constant address space: scalar loads
+    const FuseArgs f = (FuseArgs)(uintptr_t)(table + VPT_TM_FUSE_OFFSET);
+    const int mode = f->mode;
+    if (out) *out = f->out;
+    uint32_t rgb = (uint32_t)table[v.x & 0xffffu] | ((uint32_t)table[v.x >> 16] << 8) | ((uint32_t)table[v.y & 0xffffu] << 16);
+    if (mode == 3) {                                            // k_tonemap_apply_table_artistic: the grey term must be finite
+        const float low = f->low, range = f->range;
+        float4 c = half4_to_float4(v);
+        f3 w = { (c.x - low) / range, (c.y - low) / range, (c.z - low) / range };
+        const float gray = 0.57735026918962576f;
+        float z = (dot3(w, f3{ gray, gray, gray }) * gray) * f->one_minus_saturation;
+        return ((z == 0.0f) ? rgb : 0u) | 0xff000000u;
+    }
+    return rgb | ((uint32_t)table[mode == 2 ? (v.y >> 16) : 65536u] << 24);
+}
 // the frame store of the fused passes: the RGBA16F texel into the render buffer, and — when a tone mapper is armed on this renderer —
-// its tone-mapped RGBA8 texel into the tone mapper's output as well (the same table lookups as k_tonemap_apply_table*, vpt_tonemap.h:
-// bit-identical to the separate pass by construction), which saves that pass and its launch per displayed frame
+// its tone-mapped RGBA8 texel into the tone mapper's output as well, which saves that pass and its launch per displayed frame
 VPT_DEV void store_frame(const PassArgs &a, const Pix &p, uint2 v) {
     const size_t idx = (size_t)p.l * a.pm.W + p.i;
     store_frame_texel(&a.render[idx], v);
     if (a.tm_table) {                                           // wave-uniform
-        const uint8_t *table = a.tm_table;
-        typedef const TmFuse __attribute__((address_space(4))) *FuseArgs;       // constant address space: scalar loads
-        const FuseArgs f = (FuseArgs)(uintptr_t)(table + VPT_TM_FUSE_OFFSET);
-        const int mode = f->mode;
-        uint32_t rgb = (uint32_t)table[v.x & 0xffffu] | ((uint32_t)table[v.x >> 16] << 8) | ((uint32_t)table[v.y & 0xffffu] << 16);
-        uint32_t out;
-        if (mode == 3) {                                        // k_tonemap_apply_table_artistic: the grey term must be finite
-            const float low = f->low, range = f->range;
-            float4 c = half4_to_float4(v);
-            f3 w = { (c.x - low) / range, (c.y - low) / range, (c.z - low) / range };
-            const float gray = 0.57735026918962576f;
-            float z = (dot3(w, f3{ gray, gray, gray }) * gray) * f->one_minus_saturation;
-            out = ((z == 0.0f) ? rgb : 0u) | 0xff000000u;
-        } else {
-            out = rgb | ((uint32_t)table[mode == 2 ? (v.y >> 16) : 65536u] << 24);
-        }
-        f->out[idx] = out;
+        uint32_t *out;
+        const uint32_t texel = tone_map_texel(a.tm_table, v, &out);
+        out[idx] = texel;
     }
 }
 
@@ -1330,9 +1333,16 @@ __global__ void k_advance_frames(uint32_t *counter, uint32_t n) { *counter = *co
 // classes run on two streams that nothing orders against an upload of the frame table.
 #define VPT_BUCKET_FRAMES 16
 struct FrameSeeds { float seed[VPT_BUCKET_FRAMES]; };
-template <int V, bool EARLY>
+// DISPLAY: the slots hold the frames as the armed tone mapper shows them (RGBA8 through its table, PassArgs.tm_table) instead of RGBA16F:
+// half the bytes for the collective that moves the bucket (vpt_renderer_play_into_display)
+template <bool DISPLAY>
+VPT_DEV void bucket_store(const PassArgs &a, void *ring, size_t texel, uint2 v) {
+    if (DISPLAY) ((uint32_t *)ring)[texel] = tone_map_texel(a.tm_table, v, nullptr);
+    else store_frame_texel((uint2 *)ring + texel, v);
+}
+template <int V, bool EARLY, bool DISPLAY>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
-k_mcm_bucket_hit(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint32_t slot_pixels) {
+k_mcm_bucket_hit(PassArgs a, FrameSeeds fs, uint32_t nframes, void *ring, uint32_t slot_pixels) {
     Pix p = map_pixel(a.pm);
     PhotonState st;
     if (p.tile) st = photon_load(a, p.k);
@@ -1341,7 +1351,7 @@ k_mcm_bucket_hit(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint3
     if (!p.valid) return;
     const float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     Photon ph = photon_unpack(st);
-    uint2 *dst = ring + ((size_t)p.l * a.pm.W + p.i);
+    size_t texel = (size_t)p.l * a.pm.W + p.i;
     for (uint32_t f = 0; f < nframes; f++) {
         a.seed = fs.seed[f];
         if (V & VPT_V_FAST) {
@@ -1352,16 +1362,16 @@ k_mcm_bucket_hit(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint3
             else mcm_events<V>(a, t, ph, px, py);
         }
         // (between two launches the counters travel as floats and come back through uint(w + 0.5): the identity below 2^24)
-        store_frame_texel(dst, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
-        dst += slot_pixels;
+        bucket_store<DISPLAY>(a, ring, texel, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+        texel += slot_pixels;
     }
     photon_store(a, p.k, ph);
     // (VPT_PLAY_FRAMES: the render buffer shows the last frame, as after `nframes` render() calls; null for a caller's bucket)
     if (a.render) store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
 }
-template <int V, bool LATE>     // (the contract's arithmetic keeps six more values alive across the frame loop: 6 waves per SIMD there)
+template <int V, bool LATE, bool DISPLAY>     // (the contract's arithmetic keeps six more values alive across the frame loop: 6 waves per SIMD there)
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu((V & VPT_V_FAST) ? 8 : 6, 8)))
-k_mcm_bucket_miss(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint32_t slot_pixels) {
+k_mcm_bucket_miss(PassArgs a, FrameSeeds fs, uint32_t nframes, void *ring, uint32_t slot_pixels) {
     Pix p = map_pixel(a.pm);
     float4 s1 = make_float4(0.0f, 0.0f, 1.0f, 0.0f), s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     f3 s0 = { 0.0f, 0.0f, 0.0f };
@@ -1379,15 +1389,15 @@ k_mcm_bucket_miss(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint
     ph.transmittance = f3{ 1.0f, 1.0f, 1.0f };
     ph.radiance = f3{ s3.x, s3.y, s3.z };
     ph.samples = (uint32_t)(s3.w + 0.5f);
-    uint2 *dst = ring + ((size_t)p.l * a.pm.W + p.i);
+    size_t texel = (size_t)p.l * a.pm.W + p.i;
     if (V & VPT_V_FAST) {
         const FastPixel c = fast_pixel(a, px, py);
         ph.position = a.miss_load_pos ? s0 : photon_start_fast(c.from0, ph.direction);
         for (uint32_t f = 0; f < nframes; f++) {
             a.seed = fs.seed[f];
             mcm_events_miss_fast<V & ~VPT_V_FAST, false, LATE>(a, tf, c, ph, px, py);
-            store_frame_texel(dst, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
-            dst += slot_pixels;
+            bucket_store<DISPLAY>(a, ring, texel, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+            texel += slot_pixels;
         }
     } else {
         const f3 from0 = unproject_near(px, py, a);
@@ -1395,8 +1405,8 @@ k_mcm_bucket_miss(PassArgs a, FrameSeeds fs, uint32_t nframes, uint2 *ring, uint
         for (uint32_t f = 0; f < nframes; f++) {
             a.seed = fs.seed[f];
             mcm_events_miss<V, false, LATE>(a, tf, ph, px, py, from0);
-            store_frame_texel(dst, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
-            dst += slot_pixels;
+            bucket_store<DISPLAY>(a, ring, texel, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+            texel += slot_pixels;
         }
     }
     a.st1[p.k] = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);

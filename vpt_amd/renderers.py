@@ -291,6 +291,13 @@ class AbstractRenderer(PropertyBag):
         u, vars_ = self._collect_frames(count)
         N.check(N.lib().vpt_renderer_play_into(self._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), count, C.c_void_p(first_target), stride_bytes))
 
+    def play_into_display(self, tone_mapper, count, first_target, stride_bytes):
+        """play_into with the frames as the armed `tone_mapper` shows them: RGBA8, frame i at first_target + i * stride_bytes (vpt_renderer_play_into_display)"""
+        self._bind_volume()
+        u, vars_ = self._collect_frames(count)
+        N.check(N.lib().vpt_renderer_play_into_display(self._h, tone_mapper._h, C.byref(u), vars_.ctypes.data_as(C.c_void_p), count,
+                                                       C.c_void_p(first_target), stride_bytes))
+
     def bucket_launches(self):
         """buckets of frames run by the bucket kernels so far (OPTION_BUCKET_KERNEL)"""
         n = C.c_uint64(0)

@@ -48,7 +48,7 @@ class FrameGather:
     last_frame() / last_sent() give the most recent frame assembled / as this rank rendered it.  The per-buffer calls
     wait(b) / gather(b) / frame(b) with send[b] / recv[b] remain for F = 1."""
 
-    def __init__(self, dist, torch, width, height, device, rows_per_block=ROWS_PER_BLOCK, nbuf=2, always_collective=False, frames_per_gather=1):
+    def __init__(self, dist, torch, width, height, device, rows_per_block=ROWS_PER_BLOCK, nbuf=2, always_collective=False, frames_per_gather=1, texel='rgba16f'):
         self.dist, self.torch = dist, torch
         self.always_collective = always_collective and dist.is_initialized()   # exercise RCCL even with one rank
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -58,8 +58,11 @@ class FrameGather:
         self.rows_per_block = rows_per_block
         self.F = max(1, int(frames_per_gather))
         self.nbuf = nbuf
-        self._send = [torch.zeros((self.F, self.rows, width, 4), dtype=torch.float16, device=device) for _ in range(nbuf)]
-        self._recv = [torch.zeros((self.world, self.F, self.rows, width, 4), dtype=torch.float16, device=device) for _ in range(nbuf)]
+        # texel: 'rgba16f' = the render buffers; 'rgba8' = the frames as a tone mapper shows them (vpt_renderer_play_into_display): half the bytes
+        dtype = {'rgba16f': torch.float16, 'rgba8': torch.uint8}[texel]
+        self.texel_bytes = 8 if texel == 'rgba16f' else 4
+        self._send = [torch.zeros((self.F, self.rows, width, 4), dtype=dtype, device=device) for _ in range(nbuf)]
+        self._recv = [torch.zeros((self.world, self.F, self.rows, width, 4), dtype=dtype, device=device) for _ in range(nbuf)]
         # F = 1 views with the shapes of the per-buffer interface: [rows][W][4] and [world * rows][W][4]
         self.send = [t[0] for t in self._send]
         self.recv = [t.view(self.world * self.F * self.rows, width, 4) for t in self._recv]
