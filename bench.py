@@ -89,6 +89,10 @@ def parse():
                     help="torch.distributed pipeline, MCM with tile classes: 1 = the line's pipeline runs every bucket of --frames-per-gather frames by ONE launch "
                          "per tile class (VPT_OPTION_BUCKET_KERNEL: photon state in registers across the bucket, launch gap and staging once per bucket); "
                          "0 = one launch per frame and class, as at N = 1 (the default: like for like with the single-GPU line)")
+    ap.add_argument("--display-form", type=int, default=1,
+                    help="N > 1: 1 = measure the torch.distributed pipeline once more gathering the frames AS THE TONE MAPPER SHOWS THEM (RGBA8 through the default "
+                         "Artistic tone mapper, vpt_renderer_play_into_display: bucket kernels with the table in their frame store, half the bytes per xGMI link) and "
+                         "report it beside the line (config.display_gather_form); never the line's `value`")
     ap.add_argument("--bucket-form", type=int, default=1,
                     help="N > 1: 1 = after the line's measurement, measure the torch.distributed pipeline once more with VPT_OPTION_BUCKET_KERNEL and report "
                          "it beside the line (config.bucket_kernel_form); never the line's `value` unless --bucket-kernel 1")
@@ -445,6 +449,8 @@ def main():
         bucket_capable = bool(use_dist and classes_on and split_callers and gather.F > 1 and args.fused)
         if args.bucket_kernel and bucket_capable:
             r.set_option(N.OPTION_BUCKET_KERNEL, 1)
+        # which gather the steps below drive: the RGBA16F one, or (display form) an RGBA8 one fed by vpt_renderer_play_into_display
+        pipe = {"gather": gather, "tm": None}
         assert r.local_rows() == gather.rows
         nbytes = gather.send[0].numel() * 2
         r.reset()
@@ -595,6 +601,8 @@ def main():
             line["config"]["bucket_kernel"] = bool(res.get("bucket_kernel"))
             if state.get("bucket_form"):
                 line["config"]["bucket_kernel_form"] = state["bucket_form"]
+            if state.get("display_form"):
+                line["config"]["display_gather_form"] = state["display_form"]
             return line
         state["make_line"] = make_line
 
@@ -613,11 +621,19 @@ def main():
             if not use_dist:
                 r.render()                           # one GPU: the renderer's own render buffer, nothing to exchange
                 return
-            r.set_render_target(gather.acquire().data_ptr(), nbytes)    # the next slot of the current bucket
+            g = pipe["gather"]
+            if pipe["tm"] is not None:
+                closes = g.bucket_closes()
+                r.play_into_display(pipe["tm"], 1, g.acquire().data_ptr(), nbytes // 2)
+                if split_callers and closes:
+                    r.join()
+                g.commit()
+                return
+            r.set_render_target(g.acquire().data_ptr(), nbytes)    # the next slot of the current bucket
             r.render()
-            if split_callers and gather.bucket_closes():
+            if split_callers and g.bucket_closes():
                 r.join()                             # the collective reads the bucket on this stream: every range must be in
-            gather.commit()                          # a full bucket of --frames-per-gather frames: one all_gather
+            g.commit()                               # a full bucket of --frames-per-gather frames: one all_gather
 
         def drain():
             if use_native[0]:
@@ -625,7 +641,7 @@ def main():
             else:
                 if split_callers:
                     r.join()
-                gather.flush(); gather.wait_all()
+                pipe["gather"].flush(); pipe["gather"].wait_all()
 
         frames_done = [0]
 
@@ -636,16 +652,20 @@ def main():
                 # torch.distributed pipeline: whole buckets by ONE native call each (vpt_renderer_play_into: frame i into slot i of the
                 # bucket), one caller-side join, one collective; a remainder goes frame by frame
                 done = 0
+                g = pipe["gather"]
                 while done < nsteps:
-                    bucket = gather.acquire_bucket() if nsteps - done >= gather.F else None
+                    bucket = g.acquire_bucket() if nsteps - done >= g.F else None
                     if bucket is None:
                         step(done); done += 1
                         continue
-                    r.play_into(gather.F, bucket.data_ptr(), nbytes)
+                    if pipe["tm"] is not None:
+                        r.play_into_display(pipe["tm"], g.F, bucket.data_ptr(), nbytes // 2)
+                    else:
+                        r.play_into(g.F, bucket.data_ptr(), nbytes)
                     if split_callers:
                         r.join()
-                    gather.commit_bucket()
-                    done += gather.F
+                    g.commit_bucket()
+                    done += g.F
                 return
             if f <= 1:
                 for k in range(nsteps):
@@ -802,10 +822,10 @@ def main():
                         whole.destroy()
                         ok = ok and same
                 else:
-                    frame = gather.last_frame()                         # every rank holds the assembled frame
+                    frame = pipe["gather"].last_frame()                 # every rank holds the assembled frame
                     rows = torch.as_tensor(rows_np, device=device)
                     valid = rows >= 0
-                    ok = bool(torch.equal(frame.index_select(0, rows[valid]), gather.last_sent()[valid]))
+                    ok = bool(torch.equal(frame.index_select(0, rows[valid]), pipe["gather"].last_sent()[valid]))
                     if world > 1 or args.force_dist:
                         # and the same frames rendered UNSHARDED on this GPU must give the gathered frame bit for bit
                         torch.cuda.synchronize()
@@ -820,7 +840,13 @@ def main():
                         whole.reset()
                         for _ in range(frames_done[0]):
                             whole.render()
-                        same = bool((whole.getTexture().view(np.uint16) == frame.cpu().numpy().view(np.uint16)).all())
+                        if pipe["tm"] is not None:                      # display form: the gathered frame is the tone-mapped one
+                            tm2 = vpt_amd.ToneMapperFactory('artistic')(ctx, whole, {'resolution': (W, H)})
+                            tm2.render()
+                            same = bool((tm2.getTexture() == frame.cpu().numpy()).all())
+                            tm2.destroy()
+                        else:
+                            same = bool((whole.getTexture().view(np.uint16) == frame.cpu().numpy().view(np.uint16)).all())
                         whole.destroy()
                         ok = ok and same
             torch.cuda.synchronize()
@@ -844,6 +870,32 @@ def main():
                         "registers across the bucket; every frame rendered, written to its slot and gathered; frames bit-identical).  Not the line's "
                         "`value`: the single-GPU line launches once per frame, and so does the pipeline it is compared with" % gather.F}
 
+        def measure_display_form():
+            """the torch.distributed pipeline gathering the frames as the default tone mapper shows them (RGBA8): beside the line, never its value"""
+            was = use_native[0]
+            use_native[0] = False
+            drain(); torch.cuda.synchronize()
+            r.set_render_target(0, 0)
+            tm = vpt_amd.ToneMapperFactory('artistic')(ctx, r, {'resolution': (W, H)})
+            tm.set_option(N.TONEMAPPER_OPTION_TABLE, N.TONEMAPPER_TABLE_ALWAYS)
+            r.render(); frames_done[0] += 1
+            tm.render()                                          # builds the table and arms the renderer's frame stores with it
+            g8 = FrameGather(dist, torch, W, H, device, always_collective=bool(args.force_dist), frames_per_gather=gather.F, texel='rgba8')
+            pipe["gather"], pipe["tm"] = g8, tm
+            r.set_option(N.OPTION_BUCKET_KERNEL, 1); bucket_on[0] = True
+            b = measure()
+            r.set_option(N.OPTION_BUCKET_KERNEL, int(bool(args.bucket_kernel and bucket_capable))); bucket_on[0] = bool(args.bucket_kernel and bucket_capable)
+            pipe["gather"], pipe["tm"] = gather, None
+            tm.destroy()
+            use_native[0] = was
+            state["display_form"] = {
+                "ms_per_step": b["dt_max"] / args.steps * 1e3, "value": b["samples"] / b["dt_max"], "frames_per_launch": gather.F,
+                "frame_check": b["ok"], "bucket_launches": b["bucket_launches"], "bytes_per_frame_and_xgmi_link": int(W * gather.rows * 4),
+                "what": "the torch.distributed pipeline gathering every frame AS THE DEFAULT (Artistic) TONE MAPPER SHOWS IT: vpt_renderer_play_into_display — the bucket "
+                        "kernels look each texel up in the tone mapper's table and write RGBA8 slots, one all_gather per %d frames moves half the bytes of the "
+                        "RGBA16F pipeline (%d instead of %d per frame and link); the gathered frame is checked against render() + toneMapper.render() of the same "
+                        "frames unsharded.  Not the line's `value`" % (gather.F, W * gather.rows * 4, W * gather.rows * 8)}
+
         # N > 1 with the native pipeline: FIRST a complete measurement over torch.distributed's own all_gather (the
         # well-trodden path), so that a result exists whatever the library's RCCL pipeline does on this node; THEN the
         # native pipeline under a deadline.  The line printed is the faster of the two; if the native phase does not
@@ -855,6 +907,8 @@ def main():
             state["fallback"] = results[0]
             if args.bucket_form and bucket_capable and not args.bucket_kernel:
                 measure_bucket_form()
+            if args.display_form and bucket_capable:
+                measure_display_form()
             deadline = threading.Timer(args.native_deadline, _native_gave_up)
             deadline.daemon = True
             deadline.start()
@@ -867,6 +921,10 @@ def main():
             if args.bucket_form and bucket_capable and not args.bucket_kernel and not use_native[0]:
                 state["fallback"] = results[0]
                 measure_bucket_form()
+                state["fallback"] = None
+            if args.display_form and bucket_capable and not use_native[0]:
+                state["fallback"] = results[0]
+                measure_display_form()
                 state["fallback"] = None
         res = min(results, key=lambda x: x["dt_max"])
         if len(results) > 1:

@@ -12,6 +12,8 @@ try:
     print(j["ms_per_step"], j["frame_check"], j["config"]["parallelism"], j["config"].get("other_pipeline_ms_per_step"), j["config"]["split_streams"], j["config"].get("native_preflight"))
     b = j["config"].get("bucket_kernel_form")
     if b: print("   bucket kernel form:", b["ms_per_step"], b["frame_check"], b["bucket_launches"], "frames per launch", b["frames_per_launch"])
+    d = j["config"].get("display_gather_form")
+    if d: print("   display gather form:", d["ms_per_step"], d["frame_check"], d["bucket_launches"], d["bytes_per_frame_and_xgmi_link"])
 except Exception as e:
     print("no line:", e)
 PY
