@@ -11,9 +11,14 @@ run() {   # name, bench.py arguments
 }
 # (tile classes run where two streams are allowed; counter collection serialises the dispatches, so the PMC passes of the two-stream
 # form see each kernel alone on the chip — the kernel-trace pass of the same directory shows them overlapping)
+# (two calls on the GPU pool: `r03_profiles.sh 1` and `r03_profiles.sh 2`, each within one box's time limit)
+part=${1:-all}
+if [ $part = all ] || [ $part = 1 ]; then
 run mcm512_fast_classes --fast-math 1 --split-streams 2
 run mcm512_bit_exact_classes --fast-math 0 --split-streams 2
 run mcm512_fast_general_kernel_one_stream --fast-math 1 --split-streams 1 --tile-classes 0
+fi
+[ $part = 1 ] && { ls $P; exit 0; }
 run eam256_classes_one_stream --renderer eam --volume 256 --split-streams 1
 run mip256_classes_one_stream --renderer mip --volume 256 --split-streams 1
 # a kernel trace of the marchers' three-stream form
