@@ -23,6 +23,7 @@ ap.add_argument("--shard", default="", help="rank,world,rows: time one rank's sh
 ap.add_argument("--renderer", default="mcm")
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--hit-form", type=int, default=0)
+ap.add_argument("--dummy-contexts", type=int, default=0, help="contexts (one HIP stream each) created and used BEFORE the measured one: shifts which hardware queue each later stream lands on")
 args = ap.parse_args()
 if args.lib:
     os.environ["VPT_HIP_LIBRARY"] = os.path.abspath(args.lib)
@@ -40,6 +41,9 @@ if os.path.exists(cache):
 else:
     vol = sphere_volume(args.volume, noise=48.0)
     np.save(cache, vol)
+dummies = [vpt_amd.Context(0) for _ in range(args.dummy_contexts)]
+for d in dummies:
+    d.stream_read_rate(1 << 20, 1)                  # a launch on the stream: the queue is bound at first use
 ctx = vpt_amd.Context(0)
 gvol = vpt_amd.Volume.from_array(ctx, vol, 'linear')
 W, H = args.width, args.height
@@ -76,6 +80,6 @@ blocks.sort()
 med = blocks[len(blocks) // 2]
 samples = W * H * args.steps if not args.shard else None
 print("%-28s fast %d split %d classes %d%s: median %7.2f us  min %7.2f  max %7.2f%s" % (
-    (args.tag or os.path.basename(args.lib) or "in-tree") + (" hit-form %d" % args.hit_form if args.hit_form else ""), args.fast, args.split, args.classes, (" shard " + args.shard) if args.shard else "",
+    (args.tag or os.path.basename(args.lib) or "in-tree") + (" dummies %d" % args.dummy_contexts if args.dummy_contexts else "") + (" hit-form %d" % args.hit_form if args.hit_form else ""), args.fast, args.split, args.classes, (" shard " + args.shard) if args.shard else "",
     med, blocks[0], blocks[-1], ("  frac %.3f" % (24.0 * samples / (med * 1e-6) / 8e12)) if samples and args.renderer == "mcm" else ""), flush=True)
 r.destroy(); gvol.destroy(); ctx.destroy()

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/vpt.h"
+#include <chrono>
 #include "vpt_kernels.h"
 #include "vpt_kernels_iso_depth.h"
 #include "vpt_srgb_lut.h"
@@ -778,6 +779,56 @@ static dim3 tile_grid(const vpt_renderer *r) { return dim3((unsigned)(r->tiles_x
 static bool wave_blocks(const vpt_renderer *r) {
     return r->kind != VPT_RENDERER_MCM && r->kind != VPT_RENDERER_DOS && lds_bytes(r) * 28 <= 150 * 1024;
 }
+// ---- streams that really run side by side ----------------------------------------------------------------------------------
+// HIP gives a stream one of a few hardware queues (four by default) and does not say which: two streams on one queue execute their
+// kernels one after the other.  Measured: the three tile-row ranges of an EAM frame 51.9 us on three queues, 83 us when the process had
+// created one or two other streams first; the gather pipeline's hand-off 1.5 or 6 us.  So a stream that has to
+// overlap others is PICKED: candidates are created one by one and each is tried against the streams it must overlap — a 100 us spin kernel
+// on either side; side by side they take the time of one, on one queue the time of two — until one passes (at most 8; the rejected ones
+// are destroyed afterwards, the first candidate stands if none passes, e.g. under a profiler that serialises dispatches).
+// VPT_STREAM_PROBE=0 in the environment: take the first candidate, as rounds 1-3 did.
+__global__ void k_spin(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned int it = 0;
+    while (wall_clock64() - t0 < ticks && ++it < 4000000u) {}       // every wave leaves: by the clock, or by the count
+}
+static double spin_ms(hipStream_t a, hipStream_t b, unsigned long long ticks) {
+    hipStreamSynchronize(a);
+    if (b) hipStreamSynchronize(b);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
+    if (b) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
+    hipStreamSynchronize(a);
+    if (b) hipStreamSynchronize(b);
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+static bool streams_overlap(hipStream_t a, hipStream_t b) {
+    const unsigned long long ticks = 10000;                          // 100 us of the 100 MHz wall clock
+    spin_ms(a, b, 100);                                              // (code object, queues: first use)
+    double one = 1e30, two = 1e30;
+    for (int k = 0; k < 2; k++) { one = std::min(one, spin_ms(a, nullptr, ticks)); two = std::min(two, spin_ms(a, b, ticks)); }
+    return two < 1.5 * one;
+}
+// a new non-blocking stream that overlaps every stream of `others` (null entries skipped)
+static hipError_t create_overlapping_stream(hipStream_t *out, const hipStream_t *others, int n_others) {
+    static const bool probe = []() { const char *e = getenv("VPT_STREAM_PROBE"); return !(e && e[0] == '0'); }();
+    hipStream_t tried[8]; int nt = 0; hipStream_t chosen = nullptr;
+    while (nt < 8 && !chosen) {
+        hipStream_t c;
+        hipError_t e = hipStreamCreateWithFlags(&c, hipStreamNonBlocking);
+        if (e != hipSuccess) { if (nt == 0) return e; (void)hipGetLastError(); break; }
+        tried[nt++] = c;
+        bool ok = true;
+        for (int i = 0; i < n_others && ok && probe; i++) if (others[i]) ok = streams_overlap(others[i], c);
+        if (ok) chosen = c;
+    }
+    if (!chosen) chosen = tried[0];
+    for (int i = 0; i < nt; i++) if (tried[i] != chosen) hipStreamDestroy(tried[i]);
+    (void)hipGetLastError();
+    *out = chosen;
+    return hipSuccess;
+}
+
 // the side stream's work happens-before everything enqueued on the context's stream from here on
 static int join_side(vpt_renderer *r) {
     if (!r || !r->side_busy) return VPT_OK;
@@ -1858,7 +1909,10 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
             HIP_TRY(hipSetDevice(r->ctx->device));
             if (value >= 2 && !r->ev_fork) HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
             for (int i = 0; i + 1 < value; i++) if (!r->side[i]) {
-                HIP_TRY(hipStreamCreateWithFlags(&r->side[i], hipStreamNonBlocking));
+                hipStream_t others[VPT_MAX_SPLIT] = { r->ctx->stream };      // the context's stream and the side streams there are
+                for (int k = 0; k < VPT_MAX_SPLIT - 1; k++) others[1 + k] = r->side[k];
+                HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+                HIP_TRY(create_overlapping_stream(&r->side[i], others, VPT_MAX_SPLIT));
                 HIP_TRY(hipEventCreateWithFlags(&r->ev_join[i], hipEventDisableTiming));
             }
             r->split = value; return VPT_OK;
@@ -2487,7 +2541,14 @@ extern "C" int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, i
     g->r = r; g->rank = rank; g->world = world; g->root = -1;
     g->send_bytes = (size_t)r->W * r->local_h * 8;
     int rc = VPT_OK;
-    hipError_t e = hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking);
+    hipError_t e;
+    {   // the communication stream must overlap the streams the passes run on
+        { int jr = join_side(r); if (jr != VPT_OK) { delete g; return jr; } }
+        hipStream_t others[VPT_MAX_SPLIT] = { r->ctx->stream };
+        for (int k = 0; k < VPT_MAX_SPLIT - 1; k++) others[1 + k] = r->side[k];
+        hipStreamSynchronize(r->ctx->stream);
+        e = create_overlapping_stream(&g->comm_stream, others, VPT_MAX_SPLIT);
+    }
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
         for (int i = 0; i < VPT_MAX_SPLIT && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->rendered[b][i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->gathered[b], hipEventDisableTiming);
