@@ -1,5 +1,5 @@
 'use strict';
-// node js/bench.js [--volume 512] [--width 1920] [--height 1080] [--renderer mcm] [--tonemapper artistic] [--frames 200]
+// node js/bench.js [--volume 512] [--width 1920] [--height 1080] [--renderer mcm] [--tonemapper artistic] [--frames 200] [--fast-math 1] [--split-streams 2]
 // The Node host driving the path the way the reference's application does (RenderingContext.js:123-133,152-210):
 // setVolume(reader) -> chooseRenderer -> chooseToneMapper -> N x render().  Prints one JSON line with ms/frame for the
 // renderer alone and for renderer + tone mapper, and volume samples/s.  (The judged benchmark is bench.py; this shows the
@@ -40,6 +40,12 @@ async function main() {
     rc.chooseRenderer(kind);
     rc.chooseToneMapper(tm);
     const N = native();
+    // the options bench.py's line runs with (extensions of the C ABI: VPT_OPTION_FAST_MATH for MCM, VPT_OPTION_SPLIT_STREAMS — with the tile
+    // classes, on by default, an MCM pass is the HIT-tile kernel beside the MISS-tile kernel)
+    const fast = Number(arg('fast-math', 1)), split = Number(arg('split-streams', kind === 'mcm' ? 2 : 3));
+    if (kind === 'mcm' && fast) { N.rendererSetOption(rc.renderer._h, N.VPT_OPTION_FAST_MATH, 1); }
+    if (split > 1) { N.rendererSetOption(rc.renderer._h, N.VPT_OPTION_SPLIT_STREAMS, split); }
+    rc.renderer.reset();
     const time = (f, count) => {
         for (let k = 0; k < 20; k++) { f(); }
         N.contextSynchronize(rc.gl._h);
@@ -58,7 +64,7 @@ async function main() {
     let lit = 0;
     for (let i = 0; i < W * H; i++) { if (frame.data[4 * i] > 0) { lit++; } }
     console.log(JSON.stringify({
-        host: 'node ' + process.version, workload: kind + ' ' + n + '^3 @ ' + W + 'x' + H + ' + ' + tm,
+        host: 'node ' + process.version, workload: kind + ' ' + n + '^3 @ ' + W + 'x' + H + ' + ' + tm, fast_math: kind === 'mcm' && !!fast, split_streams: split,
         renderer_ms_per_frame: a.ms, renderer_enqueue_ms_per_frame: a.enqueue_ms, samples_per_frame: samples,
         volume_samples_per_s: samples / (a.ms * 1e-3),
         renderer_plus_tonemapper_ms_per_frame: b.ms, lit_pixels: lit,
