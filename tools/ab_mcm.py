@@ -23,6 +23,7 @@ ap.add_argument("--shard", default="", help="rank,world,rows: time one rank's sh
 ap.add_argument("--renderer", default="mcm")
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--hit-form", type=int, default=0)
+ap.add_argument("--torch-stream", type=int, default=0, help="1: the context runs on a torch.cuda.Stream, as in bench.py")
 ap.add_argument("--dummy-contexts", type=int, default=0, help="contexts (one HIP stream each) created and used BEFORE the measured one: shifts which hardware queue each later stream lands on")
 args = ap.parse_args()
 if args.lib:
@@ -44,7 +45,13 @@ else:
 dummies = [vpt_amd.Context(0) for _ in range(args.dummy_contexts)]
 for d in dummies:
     d.stream_read_rate(1 << 20, 1)                  # a launch on the stream: the queue is bound at first use
-ctx = vpt_amd.Context(0)
+if args.torch_stream:
+    import torch
+    torch.cuda.set_device(0)
+    _ts = torch.cuda.Stream(device=torch.device('cuda', 0))
+    ctx = vpt_amd.Context(0, stream=_ts.cuda_stream)
+else:
+    ctx = vpt_amd.Context(0)
 gvol = vpt_amd.Volume.from_array(ctx, vol, 'linear')
 W, H = args.width, args.height
 opts = {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()}
