@@ -762,7 +762,16 @@ def main():
                 run_steps(50); extra += 50
                 drain(); torch.cuda.synchronize()
             if use_dist:
+                # (every rank must run the same number of steps — the collectives are matched —, so the length of the time-based part is agreed on:
+                # 1000 steps are timed, the slowest rank's figure decides how many more make up --warmup-seconds)
+                t_w = time.perf_counter()
                 run_steps(1000); drain(); torch.cuda.synchronize()
+                tw = torch.tensor([time.perf_counter() - t_w], dtype=torch.float64, device=device)
+                dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+                more = int(min(60000.0, max(0.0, args.warmup_seconds - float(tw[0])) / max(float(tw[0]) / 1000.0, 1e-7)))
+                more -= more % max(1, pipe["gather"].F)
+                if more > 0:
+                    run_steps(more); drain(); torch.cuda.synchronize()
             # R timed blocks of EXACTLY K steps, each bracketed by barrier + synchronize; the MEDIAN block is the one reported
             blocks = []
             r.clear_sample_count()
