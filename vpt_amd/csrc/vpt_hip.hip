@@ -1109,7 +1109,9 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
             for (int i = 0; i + 1 < k; i++) HIP_TRY(hipStreamWaitEvent(r->side[i], r->ev_fork, 0));
             r->main_dirty = false;
         }
-        for (int i = 0; i < np; i++) {
+        // (the MISS-tile kernel is the longer of the two and goes first: its stream is the one a short sequence of frames waits for at the
+        // end — blocks of 5 frames 87.5 -> 85.3 us per frame, of 20 frames 81.9 -> 81.1, long sequences the same)
+        for (int i = np - 1; i >= 0; i--) {
             PassArgs part = a;
             part.pm.tile_list = parts[i].list; part.pm.list_n = parts[i].n; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
             // profiling: the context's stream is bracketed by the caller (Timed); the first side launch gets a pair of its own
