@@ -100,7 +100,7 @@ def parse():
     ap.add_argument("--split-caller-targets", type=int, default=-1,
                     help="torch.distributed pipeline: 1 = passes into the gather's buckets run on several streams too and are joined once per bucket; "
                          "-1 = yes when the MCM tile classes are in force (HIT | MISS kernels), no otherwise")
-    ap.add_argument("--frames-per-gather", type=int, default=8,
+    ap.add_argument("--frames-per-gather", type=int, default=16,
                     help="torch.distributed pipeline: frames per all_gather (every frame is delivered, at most F - 1 frames later; one async "
                          "collective costs the host ~25 us whatever its size and a bucket's launches ~10 us per frame, against the ~17 us a "
                          "1/8 shard's kernels take: measured on a one-rank group with 1920x136 frames 27.2 / 23.3 / 22.8 us per frame at F = 4 / 8 / 16)")

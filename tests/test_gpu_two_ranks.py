@@ -41,7 +41,7 @@ def test_native_gather_two_ranks():
 
 
 def test_torch_pipeline_on_one_rank_frame_by_frame_and_with_bucket_kernels():
-    """bench.py's N > 1 code path on a one-rank RCCL group (--force-dist 1 --gather torch), small sizes: buckets of 8 frames through
+    """bench.py's N > 1 code path on a one-rank RCCL group (--force-dist 1 --gather torch), small sizes: buckets of 16 frames through
     vpt_renderer_play_into + one all_gather each, the gathered frame bit-compared with the same frames rendered unsharded — frame by frame
     (the line), with VPT_OPTION_BUCKET_KERNEL (config.bucket_kernel_form: one launch per tile class and bucket) and gathering the frames as the
     tone mapper shows them (config.display_gather_form: RGBA8 buckets, checked against render() + toneMapper.render() unsharded).  A fresh process:
@@ -58,10 +58,10 @@ def test_torch_pipeline_on_one_rank_frame_by_frame_and_with_bucket_kernels():
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["frame_check"] is True
-    assert line["config"]["frames_per_gather"] == 8 and line["config"]["bucket_kernel"] is False
+    assert line["config"]["frames_per_gather"] == 16 and line["config"]["bucket_kernel"] is False
     b = line["config"]["bucket_kernel_form"]
-    assert b["frame_check"] is True and b["frames_per_launch"] == 8
-    assert b["bucket_launches"] >= (1000 + 2 * 40) // 8          # the warm-up and both timed blocks went through the bucket kernels
+    assert b["frame_check"] is True and b["frames_per_launch"] == 16
+    assert b["bucket_launches"] >= (1000 + 2 * 32) // 16         # the warm-up and both timed blocks went through the bucket kernels
     d = line["config"]["display_gather_form"]                    # ... and gathering the tone-mapped RGBA8 frames (vpt_renderer_play_into_display)
-    assert d["frame_check"] is True and d["bucket_launches"] >= (1000 + 2 * 40) // 8
+    assert d["frame_check"] is True and d["bucket_launches"] >= (1000 + 2 * 32) // 16
     assert d["bytes_per_frame_and_xgmi_link"] == 640 * 368 * 4
