@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Instruction histogram of a kernel in vpt_amd/csrc/vpt_hip.s (make -C vpt_amd/csrc asm).
+"""Instruction histogram of a kernel in vpt_amd/csrc/vpt_mcm.s (make -C vpt_amd/csrc asm).
 
   python tools/isa_histogram.py [mangled-name-substring] [--json out.json]
 
@@ -43,7 +43,7 @@ def main():
     out_json = None
     if "--json" in sys.argv:
         out_json = sys.argv[sys.argv.index("--json") + 1]
-    path = "vpt_amd/csrc/vpt_hip.s"
+    path = "vpt_amd/csrc/vpt_mcm.s"
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^[A-Za-z_][\w$]*:", l) and want in l.split(":")[0])
     name = lines[start].split(":")[0]

@@ -314,6 +314,16 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_lao(PassArgs a) {
     }
     count_samples(a.samples, ns);
 }
+// reset / render: the shaders of the EAM renderer (LAORenderer.glsl:285-287: (0, 0, 0, 1) into RGBA8; :259-261)
+__global__ void __launch_bounds__(VPT_BLOCK) k_lao_reset(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (p.tile) ((uint32_t *)a.acc)[p.k] = 0xff000000u;
+}
+__global__ void __launch_bounds__(VPT_BLOCK) k_lao_render(PassArgs a) {
+    Pix p = map_pixel(a.pm);
+    if (!p.valid) return;
+    store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], eam_to_half4(((uint32_t *)a.acc)[p.k]));
+}
 __global__ void __launch_bounds__(VPT_BLOCK) k_lao_integrate(PassArgs a) {
     Pix p = map_pixel(a.pm);
     if (p.valid) ((uint32_t *)a.acc)[p.k] = ((const uint32_t *)a.frame)[p.k];
