@@ -181,7 +181,9 @@ VPT_API int vpt_renderer_read(vpt_renderer *r, int buffer, void *host_dst, size_
 /* device pointer of the row-major RGBA16F render buffer (for the RCCL frame gather) */
 VPT_API int vpt_renderer_render_buffer_device(vpt_renderer *r, void **device_ptr, size_t *nbytes);
 /* redirect _renderFrame output into caller-owned device memory (>= width*local_rows*8 bytes), e.g. the send buffer of
- * the frame gather; NULL restores the renderer's own render buffer (gl.bindFramebuffer analogue, SingleBuffer.js:28-32) */
+ * the frame gather; NULL restores the renderer's own render buffer (gl.bindFramebuffer analogue, SingleBuffer.js:28-32).  The first pass into a
+ * target after this call writes every texel of it; later passes into the SAME target may skip texels whose value cannot have changed since
+ * (the accumulating renderers' tiles that miss the volume): a caller that writes into the memory itself calls this function again */
 VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, size_t nbytes);
 /* implementation switches (results are identical either way).  VPT_OPTION_MCS_PERSISTENT (default 0): run the MCS
  * generate pass as persistent waves with __ballot/__popcll active-ray compaction instead of one thread per pixel
@@ -239,6 +241,13 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * are in force (VPT_OPTION_TILE_CLASSES with VPT_OPTION_SPLIT_STREAMS >= 2 and VPT_OPTION_SPLIT_CALLER_TARGETS); elsewhere frame by
  * frame as without the option.  Every frame is rendered and written to its slot either way; results identical. */
 #define VPT_OPTION_BUCKET_KERNEL 9
+/* VPT_OPTION_COLUMN_RECORDS (default 2; MCM renderer, LINEAR filter, one-channel byte volumes; extension): 1 = the in-cube samples of the MCM
+ * events are fetched from the volume's COLUMN RECORDS — a third layout of the same texels, built on the first MCM pass that wants it: one
+ * dword per voxel holding the 2 x 2 x-y footprint of its cell, the records of a voxel column contiguous, so that the eight taps of a
+ * trilinear sample are ONE dword-aligned 8-byte gather from one 64-byte sector instead of two byte-aligned windows of a 128-byte brick
+ * line.  4 bytes per voxel of HBM.  Same taps, same lerps: results identical.  0 = the apron bricks, as the other renderers; 2 = records
+ * where the bricks are beyond the Infinity Cache (> 512 MiB: measured 2-4 % faster there, 4-16 % slower on volumes that fit it). */
+#define VPT_OPTION_COLUMN_RECORDS 10
 VPT_API int vpt_renderer_set_option(vpt_renderer *r, int option, int value);
 /* (extension) how many buckets of frames vpt_renderer_play_into has run through the bucket kernels so far (VPT_OPTION_BUCKET_KERNEL) */
 VPT_API int vpt_renderer_bucket_launches(vpt_renderer *r, uint64_t *launches);

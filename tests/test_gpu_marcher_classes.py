@@ -193,3 +193,85 @@ def test_eam_full_hd_on_and_off(gpu_ctx, oracle):
 
     same(run(0), run(1), "EAM 1080p")
     sc.gvol.destroy()
+
+
+# ---- render destinations other than the renderer's own buffer (round 4) ---------------------------------------------------------------
+# A pass that launches the HIT tiles only leaves the other texels of its DESTINATION as they are: right only where a whole-image pass has
+# written that destination since the reset.  A caller's render target, the slots of a bucket and the gather's ring change from frame to
+# frame — each must take one whole pass first (TileClasses.complete in vpt_internal.h).
+
+def reference_frames(sc, kind, n, **props):
+    ref = sc.renderer(kind)
+    ref.set_option(N.OPTION_TILE_CLASSES, 0)
+    for k, v in props.items():
+        setattr(ref, k, v)
+    ref.reset()
+    frames = []
+    for _ in range(n):
+        ref.render()
+        frames.append(ref.getTexture().copy())
+    ref.destroy()
+    return frames
+
+
+@pytest.mark.parametrize("kind", ["eam", "mip", "mcs", "iso"])
+def test_render_targets_cycling_through_three_buffers(gpu_ctx, oracle, kind):
+    """vpt_renderer_set_render_target into three caller-owned buffers in turn (here: the render buffers of three idle renderers), then
+    the same buffers again WITHOUT announcing them anew is what play_into does — both against an unsharded renderer with classes off"""
+    sc = far_scene(gpu_ctx, oracle)
+    want = reference_frames(sc, kind, 9)
+    holders = [sc.renderer(kind) for _ in range(3)]
+    targets = [h.render_buffer_device() for h in holders]
+    r = sc.renderer(kind)
+    r.reset()
+    for k in range(9):
+        ptr, nbytes = targets[k % 3]
+        r.set_render_target(ptr, nbytes)
+        r.render()
+        r.join()
+        gpu_ctx.synchronize()
+        assert_same_bits(holders[k % 3].getTexture(), want[k], "%s frame %d through a cycling render target" % (kind, k))
+    r.set_render_target(0, 0)
+    r.destroy()
+    for h in holders:
+        h.destroy()
+    sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("kind", ["eam", "mip", "depth"])
+def test_play_into_three_slots(gpu_ctx, oracle, kind):
+    """vpt_renderer_play_into: frame i of a call into slot i of a bucket, the same bucket call after call (the torch.distributed
+    pipeline's shape).  The bucket is the frame ring of an idle MCM renderer, read back slot by slot"""
+    sc = far_scene(gpu_ctx, oracle)
+    want = reference_frames(sc, kind, 9)
+    holder = sc.renderer('mcm')
+    holder.reset(); holder.play(3, frames=True)                   # allocates the ring; three readable slots
+    import ctypes as C
+    p, n = C.c_void_p(), C.c_size_t()
+    N.check(N.lib().vpt_renderer_frame_ring_device(holder._h, C.byref(p), C.byref(n)))
+    r = sc.renderer(kind)
+    r.reset()
+    for call in range(3):
+        r.play_into(3, p.value, n.value)
+        r.join()
+        gpu_ctx.synchronize()
+        for i in range(3):
+            assert_same_bits(holder.read_frame_slot(i), want[3 * call + i], "%s call %d slot %d" % (kind, call, i))
+    r.destroy(); holder.destroy(); sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("kind", ["eam", "mip"])
+@pytest.mark.parametrize("root", [-1, 0])
+def test_native_gather_ring_with_a_marcher(gpu_ctx, oracle, kind, root):
+    """vpt_gather_render renders into send[frame % 16] (or, as the root, into its slot of recv[..]): 20 frames, so the ring wraps"""
+    from vpt_amd.tiles import RcclFrameGather
+    sc = far_scene(gpu_ctx, oracle)
+    want = reference_frames(sc, kind, 20)
+    shard = sc.renderer(kind, shard=(0, 1, 8))
+    shard.reset()
+    g = RcclFrameGather(shard, RcclFrameGather.unique_id(), 0, 1, root=root)
+    for k in range(20):
+        g.render()
+        if k in (0, 1, 2, 15, 16, 17, 19):
+            assert_same_bits(g.frame(), want[k], "%s gathered frame %d (root %d)" % (kind, k, root))
+    g.destroy(); shard.destroy(); sc.gvol.destroy()

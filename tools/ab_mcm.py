@@ -23,6 +23,12 @@ ap.add_argument("--shard", default="", help="rank,world,rows: time one rank's sh
 ap.add_argument("--renderer", default="mcm")
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--hit-form", type=int, default=0)
+ap.add_argument("--records", type=int, default=-1, help="VPT_OPTION_COLUMN_RECORDS (MCM): 0 / 1; -1 = the library's default")
+ap.add_argument("--camera-z", type=float, default=2.0, help="z of the default camera's translation (0.9: the volume fills the frame, every tile is a HIT tile)")
+ap.add_argument("--extinction", type=float, default=0.0)
+ap.add_argument("--tf", default="", help="'ramp': the 256x1 grey ramp with alpha = v instead of the default 2x1 transfer function")
+ap.add_argument("--kernel-times", type=int, default=0, help="1: HIP events around every 4th launch: per-kernel averages (context stream | side stream)")
+ap.add_argument("--digest", type=int, default=0, help="1: print a digest of the radiance buffer after the run (same seeds: equal across bit-identical builds / options)")
 ap.add_argument("--torch-stream", type=int, default=0, help="1: the context runs on a torch.cuda.Stream, as in bench.py")
 ap.add_argument("--dummy-contexts", type=int, default=0, help="contexts (one HIP stream each) created and used BEFORE the measured one: shifts which hardware queue each later stream lands on")
 args = ap.parse_args()
@@ -40,7 +46,14 @@ cache = "/tmp/vpt_vol_%d.npy" % args.volume
 if os.path.exists(cache):
     vol = np.load(cache)
 else:
-    vol = sphere_volume(args.volume, noise=48.0)
+    from concurrent.futures import ThreadPoolExecutor
+    n = args.volume
+    vol = np.empty((n, n, n), dtype=np.uint8)
+
+    def _slab(z0):
+        vol[z0:z0 + 16] = sphere_volume(n, noise=48.0, z_range=(z0, min(n, z0 + 16)))
+    with ThreadPoolExecutor(max_workers=min(14, len(os.sched_getaffinity(0)))) as ex:
+        list(ex.map(_slab, range(0, n, 16)))
     np.save(cache, vol)
 dummies = [vpt_amd.Context(0) for _ in range(args.dummy_contexts)]
 for d in dummies:
@@ -57,7 +70,15 @@ W, H = args.width, args.height
 opts = {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()}
 if args.shard:
     opts['shard'] = tuple(int(x) for x in args.shard.split(","))
-r = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, default_camera(W / H), None, opts)
+camera = default_camera(W / H)
+if args.camera_z != 2.0:
+    camera.transform.localTranslation = [0.0, 0.0, args.camera_z]
+r = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, opts)
+if args.extinction:
+    r.extinction = args.extinction
+if args.tf == "ramp":
+    from vpt_amd.synthetic import ramp_tf
+    r.setTransferFunction(ramp_tf(256))
 if args.renderer == "mcm":
     r.set_option(N.OPTION_FAST_MATH, args.fast)
     r.steps = args.steps
@@ -67,8 +88,9 @@ except vpt_amd.VptError:
     pass                                              # a build from before the option existed
 if args.hit_form:
     r.set_option(N.OPTION_HIT_KERNEL_FORM, args.hit_form)
-if args.split > 1:
-    r.set_option(N.OPTION_SPLIT_STREAMS, args.split)
+if args.records >= 0 and args.renderer == "mcm":
+    r.set_option(N.OPTION_COLUMN_RECORDS, args.records)
+r.set_option(N.OPTION_SPLIT_STREAMS, max(1, args.split))
 r.reset()
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.3:
@@ -85,8 +107,23 @@ for _ in range(args.blocks):
     blocks.append((time.perf_counter() - t0) / args.frames * 1e6)
 blocks.sort()
 med = blocks[len(blocks) // 2]
+extra = ""
+if args.kernel_times:
+    r.set_profiling(4)
+    for _ in range(200):
+        r.render()
+    ctx.synchronize()
+    ms, n = r.profile(); ms2, n2 = r.profile_side()
+    r.set_profiling(False)
+    extra += "  kernels: context %.2f us" % (ms / max(n, 1) * 1e3) + ((" | side %.2f us" % (ms2 / n2 * 1e3)) if n2 else "")
+    if args.renderer == "mcm":
+        extra += "  tiles %s" % (r.tile_classes()[:2],)
+if args.digest:
+    import hashlib
+    extra += "  digest " + hashlib.sha256(r.read(N.BUFFER_MCM_RADIANCE if args.renderer == "mcm" else N.BUFFER_RENDER).tobytes()).hexdigest()[:12]
 samples = W * H * args.steps if not args.shard else None
 print("%-28s fast %d split %d classes %d%s: median %7.2f us  min %7.2f  max %7.2f%s" % (
     (args.tag or os.path.basename(args.lib) or "in-tree") + (" dummies %d" % args.dummy_contexts if args.dummy_contexts else "") + (" hit-form %d" % args.hit_form if args.hit_form else ""), args.fast, args.split, args.classes, (" shard " + args.shard) if args.shard else "",
-    med, blocks[0], blocks[-1], ("  frac %.3f" % (24.0 * samples / (med * 1e-6) / 8e12)) if samples and args.renderer == "mcm" else ""), flush=True)
+    med, blocks[0], blocks[-1], ("  frac %.3f" % (24.0 * samples / (med * 1e-6) / 8e12)) if samples and args.renderer == "mcm" else "") +
+    (" records %d" % args.records if args.records >= 0 else "") + extra, flush=True)
 r.destroy(); gvol.destroy(); ctx.destroy()

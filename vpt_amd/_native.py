@@ -18,6 +18,7 @@ OPTION_TILE_CLASSES = 6
 OPTION_VERIFY_TILE_CLASSES = 7
 OPTION_HIT_KERNEL_FORM = 8
 OPTION_BUCKET_KERNEL = 9
+OPTION_COLUMN_RECORDS = 10
 PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED, PLAY_FRAMES = 0, 1, 2, 3
 FRAME_SLOTS = 16
 RENDERER_MIP, RENDERER_EAM, RENDERER_MCS, RENDERER_MCM, RENDERER_ISO, RENDERER_DEPTH, RENDERER_LAO, RENDERER_DOS = 0, 1, 2, 3, 4, 5, 6, 7

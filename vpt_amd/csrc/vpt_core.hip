@@ -139,8 +139,45 @@ extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format
         HIP_TRY(hipMemcpy(v->tab32, t32.data(), t32.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(v->tabc, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
     }
+    if (v->channels == 1 && !v->f32) {
+        // column records: 2-D Z-order over (x, y) with as many bits per axis as the axis needs, nz records of 4 bytes per column
+        int cb[2] = { 0, 0 };
+        while ((1 << cb[0]) < w) cb[0]++;
+        while ((1 << cb[1]) < h) cb[1]++;
+        int cpos[2][16]; int ctotal = 0;
+        for (int level = 0; level < 16; level++)
+            for (int ax = 0; ax < 2; ax++) if (level < cb[ax]) cpos[ax][level] = ctotal++;
+        auto col_code = [&](int ax, uint32_t i) { uint64_t c = 0; for (int k = 0; k < cb[ax]; k++) c |= (uint64_t)((i >> k) & 1u) << cpos[ax][k]; return c; };
+        const uint64_t ncols = (col_code(0, (uint32_t)w - 1) | col_code(1, (uint32_t)h - 1)) + 1, col_bytes = 4ull * (uint64_t)d;
+        v->rec_bytes = (size_t)(ncols * col_bytes);
+        v->rec_wide = ncols * col_bytes > 0x100000000ull;          // (the largest offset used is rec_bytes - 4)
+        std::vector<uint32_t> r32((size_t)w + h), rc((size_t)w + h);
+        for (int i = 0; i < w; i++) { rc[i] = (uint32_t)col_code(0, (uint32_t)i); r32[i] = (uint32_t)(col_code(0, (uint32_t)i) * col_bytes); }
+        for (int i = 0; i < h; i++) { rc[(size_t)w + i] = (uint32_t)col_code(1, (uint32_t)i); r32[(size_t)w + i] = (uint32_t)(col_code(1, (uint32_t)i) * col_bytes); }
+        HIP_TRY(hipMalloc(&v->rtab32, r32.size() * 4));
+        HIP_TRY(hipMalloc(&v->rtabc, rc.size() * 4));
+        HIP_TRY(hipMemcpy(v->rtab32, r32.data(), r32.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(v->rtabc, rc.data(), rc.size() * 4, hipMemcpyHostToDevice));
+    }
     v->dirty = true;
     *out = v;
+    return VPT_OK;
+}
+// The column records (vpt_device.h record_addr) of a one-channel byte volume, (re)built from the linear storage when blocks have been
+// uploaded since the last build.  Allocated on first use: only the MCM renderer samples them (4 bytes per voxel).
+int volume_records(vpt_volume *v) {
+    if (!v || v->channels != 1 || v->f32) return fail(VPT_ERR_INVALID, "column records exist for one-channel byte volumes");
+    VPT_TRY(vpt_volume_finalize(v));
+    if (v->rec_valid) return VPT_OK;
+    vpt_context *c = v->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!v->records) HIP_TRY(hipMalloc(&v->records, v->rec_bytes + 64));      // + the dword behind the last column's last record
+    for (vpt_renderer *r : c->renderers) if (r->vol == v) VPT_TRY(join_side(r));   // passes in flight read the old records
+    hipLaunchKernelGGL(k_build_records, dim3((unsigned)((v->nx + 63) / 64), (unsigned)v->ny, (unsigned)((v->nz + 15) / 16)), dim3(256), 0, c->stream,
+                       v->linear, v->records, v->nx, v->ny, v->nz, v->rec_wide ? v->rtabc : v->rtab32, v->rec_wide ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    v->rec_valid = true;
+    for (vpt_renderer *r : c->renderers) if (r->vol == v) r->main_dirty = true;    // side streams must see the build
     return VPT_OK;
 }
 static int volume_upload(vpt_volume *v, int x, int y, int z, int w, int h, int d, const void *data, size_t nbytes, bool on_device) {
@@ -172,7 +209,7 @@ static int volume_upload(vpt_volume *v, int x, int y, int z, int w, int h, int d
         HIP_TRY(hipGetLastError());
     }
     if (!on_device) HIP_TRY(hipStreamSynchronize(c->stream));   // host buffer may be released by the caller
-    v->dirty = true; v->any_upload = true;
+    v->dirty = true; v->any_upload = true; v->rec_valid = false;
     return VPT_OK;
 }
 extern "C" int vpt_volume_upload_block(vpt_volume *v, int x, int y, int z, int w, int h, int d, const void *data, size_t nbytes) {
@@ -235,6 +272,9 @@ extern "C" int vpt_volume_destroy(vpt_volume *v) {
     if (v->linear) hipFree(v->linear);
     if (v->bricks) hipFree(v->bricks);
     if (v->atlas) hipFree(v->atlas);
+    if (v->records) hipFree(v->records);
+    if (v->rtab32) hipFree(v->rtab32);
+    if (v->rtabc) hipFree(v->rtabc);
     if (v->staging) hipFree(v->staging);
     if (v->tab32) hipFree(v->tab32);
     if (v->tabc) hipFree(v->tabc);
@@ -268,7 +308,7 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     renderer_free_buffers(r);
     r->cls.valid = false; r->cls.stale = false;            // new geometry, zeroed state: classes come back with the next reset
-    r->cls.passes = 0; r->cls.fused_passes = 0; r->cls.reset_seen = false;   // (zeroed buffers are not a reset: nothing is skipped before one)
+    r->cls.passes = 0; r->cls.fused_passes = 0; r->cls.reset_seen = false; r->cls.n_complete = 0;   // (zeroed buffers are not a reset: nothing is skipped before one)
     r->dos_cur = 0; r->dos_rect_valid = false;
     int nblocks = (r->H + r->R - 1) / r->R;                 // row blocks in the image
     int mine = (nblocks - r->g + r->G - 1) / r->G;          // blocks b with b % G == g
@@ -368,7 +408,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->ndc_x = r->ndc_y = nullptr;
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
-    r->fast_math = 0; r->boundary_atlas = 1;
+    r->fast_math = 0; r->boundary_atlas = 1; r->column_records = 2;
     r->frame_ring = nullptr; r->ring_frames = 0; r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0; r->hit_form = 0; r->bucket_kernel = false; r->bucket_launches = 0;
@@ -593,6 +633,10 @@ int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, PassArgs
         a->vol.elem_shift = v->f32 ? 2u : 0u;
         a->vol.atlas = r->boundary_atlas ? v->atlas : nullptr;
         a->vol.atlas_face = v->atlas_face; a->vol.atlas_shift = v->atlas_shift;
+        if (renderer_uses_records(r)) {
+            VPT_TRY(volume_records(v));
+            a->vol.records = v->records; a->vol.rtab32 = v->rtab32; a->vol.rtabc = v->rtabc; a->vol.rec_col_bytes = 4u * (uint32_t)v->nz;
+        }
     }
     a->env.texels = r->env; a->env.w = r->env_w; a->env.h = r->env_h; a->env.constant = r->env_const;
     a->tf = r->tf; a->tf_w = r->tf_w; a->tf_h = r->tf_h; a->tf_fw = (float)r->tf_w; a->tf_hi = (float)(r->tf_w - 1);
@@ -803,6 +847,9 @@ extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t
     size_t need = (size_t)r->W * r->local_h * 8;
     if (ptr && nbytes < need) return fail(VPT_ERR_INVALID, "render target too small: %zu < %zu", nbytes, need);
     r->render_target = (uint2 *)ptr; r->target_is_callers = ptr != nullptr;
+    // what the library knows about this memory's texels (marcher_track: tiles it may skip) ends here: the caller may have used it in between
+    for (int i = 0; i < r->cls.n_complete; i++)
+        if (ptr && r->cls.complete[i] == ptr) { r->cls.complete[i] = r->cls.complete[--r->cls.n_complete]; break; }
     return VPT_OK;
 }
 extern "C" int vpt_renderer_set_lao_params(vpt_renderer *r, const struct vpt_lao_params *p) {
@@ -856,6 +903,11 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_HIT_KERNEL_FORM: an MCM option");
             if (value < 0 || value > 2) return fail(VPT_ERR_INVALID, "VPT_OPTION_HIT_KERNEL_FORM: 0 (automatic), 1 or 2");
             r->hit_form = value; return VPT_OK;
+        case VPT_OPTION_COLUMN_RECORDS:
+            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_COLUMN_RECORDS: an MCM option");
+            VPT_TRY(join_side(r));
+            if (value < 0 || value > 2) return fail(VPT_ERR_INVALID, "VPT_OPTION_COLUMN_RECORDS: 0 (bricks), 1 (records) or 2 (by volume size)");
+            r->column_records = value; return VPT_OK;
         case VPT_OPTION_BUCKET_KERNEL:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_BUCKET_KERNEL: an MCM option");
             r->bucket_kernel = value != 0; return VPT_OK;

@@ -301,6 +301,11 @@ struct DevVolume {
     uint32_t elem_shift;     // log2 of the bytes per texel channel: 0 (UNSIGNED_BYTE) or 2 (FLOAT)
     const uint32_t *atlas;   // boundary atlas (one-channel volumes; null: not built or switched off) — see sample_volume_boundary
     uint32_t atlas_face, atlas_shift;   // dwords per face image, log2 of its row pitch
+    // column records (one-channel byte volumes, LINEAR filter; null: not built or switched off) — see record_addr
+    const uint8_t *records;
+    const uint32_t *rtab32;  // RX | RY (nx + ny entries): byte offset of the column's first record
+    const uint32_t *rtabc;   // the columns' Z-order codes alone (records beyond 4 GiB)
+    uint32_t rec_col_bytes;  // bytes of one column: nz * 4
 };
 // LDS image of the per-workgroup tables: [tf pairs][TX][TY][TZ]
 struct LdsTables {
@@ -344,6 +349,7 @@ VPT_DEV const uint8_t *cell_addr(const DevVolume &v, const LdsTables &t, uint32_
 #define VPT_V_FAST    16  // MCM / MCS: hardware rcp / rsq / sqrt / log / sin / cos and shorter algebraic forms (no bit-exact CPU twin; VPT_OPTION_FAST_MATH)
 #define VPT_V_F32     32  // FLOAT texels (R32F; R16F widened on upload): 5^3 floats in a 512-byte slot, no normalisation
 #define VPT_V_RG      8   // two-channel (RG8) volume: texture(uVolume, p).rg has both channels, the transfer function is looked up in 2-D
+#define VPT_V_REC     64  // in-cube samples from the column records instead of the bricks (one-channel byte volumes, LINEAR filter; MCM)
 // the eight taps around a cell of one channel's brick and their trilinear blend: taps +0,+1 (y,z) ; +5,+6 (y+1,z) ;
 // +25,+26 (y,z+1) ; +30,+31 (y+1,z+1) = two 8-byte windows of one line.
 // tools/gather_rates.hip (MI355X, L1-resident gathers): a dword-aligned 8/12/16-byte wave load costs ~27-33 cycles
@@ -391,6 +397,40 @@ VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
         l0 = (uint32_t)w0; h0 = (uint32_t)(w0 >> 32); l1 = (uint32_t)w1; h1 = (uint32_t)(w1 >> 32);
     }
     return trilinear_blend(l0, h0, l1, h1, fx, fy, fz);
+}
+// ---- column records (round 4) -------------------------------------------------------------------------------------------
+// The photons of the MCM renderer sample at independent random positions: after its first event no two lanes of a wave share a
+// brick, every in-cube sample is a cold line, and what it costs is the texture path's work per gather (two byte-aligned 8-byte
+// windows: ~2 x 60 cycles per wave instruction against ~30 for a dword-aligned load, tools/gather_rates.hip) and the 64-byte
+// sectors it pulls (1.5 on average for the two windows of a 128-byte brick line).  So the volume is kept a THIRD time for this
+// access pattern, the way the boundary atlas keeps the faces: record(x, y, z) = the four texels of the cell's x-y footprint in ONE
+// dword — [t(x,y,z), t(x+1,y,z), t(x,y+1,z), t(x+1,y+1,z)], indices clamped like the apron — and the records of a voxel column
+// (x, y, 0 .. nz-1) contiguous, so that the eight taps of a trilinear sample are records z and z + 1 of one column: ONE dword-aligned
+// 8-byte gather from one 64-byte sector (two where the pair straddles a sector: 1 in 16).  Same taps, same x -> y -> z lerps as
+// trilinear_blend: bit-identical.  4 bytes per voxel (512^3: 512 MiB, 1024^3: 4 GiB, 2048^3: 32 GiB of the 288 GB).  Columns are
+// ordered by a 2-D Z-order code of (x, y) with as many bits per axis as the axis needs; the address is separable,
+//     off(x, y, z) = RX[x] + RY[y] + 4 z,   RX[x] = CX[x] * 4 nz,   RY[y] = CY[y] * 4 nz
+// two LDS lookups and a shift-add (beyond 4 GiB the tables hold the column code and the product is one v_mad_u64_u32).
+// At z = nz - 1 the filter weight fz is exactly 0 (linear_cell), so what the load's second dword holds — the next column's first
+// record, or the 8 bytes of padding behind the last column — never reaches the result.
+template <bool WIDE>
+VPT_DEV const uint8_t *record_addr(const DevVolume &v, const LdsTables &t, uint32_t x, uint32_t y, uint32_t z) {
+    if (WIDE) return v.records + ((uint64_t)(t.tx[x] + t.ty[y]) * v.rec_col_bytes + (z << 2));
+    return v.records + (uint32_t)(t.tx[x] + t.ty[y] + (z << 2));
+}
+// the blend of records z (lo) and z + 1 (hi): the same values and the same order of operations as trilinear_blend
+VPT_DEV float record_blend(uint32_t lo, uint32_t hi, float fx, float fy, float fz) {
+    float c000 = cvt_ubyte<0>(lo), c100 = cvt_ubyte<1>(lo), c010 = cvt_ubyte<2>(lo), c110 = cvt_ubyte<3>(lo);
+    float c001 = cvt_ubyte<0>(hi), c101 = cvt_ubyte<1>(hi), c011 = cvt_ubyte<2>(hi), c111 = cvt_ubyte<3>(hi);
+    float c00 = lerpf(c000, c100, fx), c10 = lerpf(c010, c110, fx);
+    float c01 = lerpf(c001, c101, fx), c11 = lerpf(c011, c111, fx);
+    float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
+    return lerpf(c0, c1, fz) * VPT_INV255;
+}
+VPT_DEV uint64_t record_load(const uint8_t *a) {
+    uint64_t w;
+    __builtin_memcpy(&w, __builtin_assume_aligned(a, 4), 8);
+    return w;
 }
 // ---- boundary atlas ---------------------------------------------------------------------------------------------------
 // For a position with a coordinate outside [0, 1] (MCM samples before its bounds test, MCMRenderer.glsl:132-142) the clamped
@@ -492,6 +532,10 @@ VPT_DEV f2 sample_volume_rg(const DevVolume &v, const LdsTables &t, f3 p) {
     linear_cell(p.x, v.fnx, v.hx, x, fx);
     linear_cell(p.y, v.fny, v.hy, y, fy);
     linear_cell(p.z, v.fnz, v.hz, z, fz);
+    if (V & VPT_V_REC) {                                          // (one channel: the launch code never combines REC with RG)
+        const uint64_t w = record_load(record_addr<WIDE>(v, t, x, y, z));
+        return f2{ record_blend((uint32_t)w, (uint32_t)(w >> 32), fx, fy, fz), 0.0f };
+    }
     const uint8_t *a = cell_addr<WIDE>(v, t, x, y, z);
     return f2{ trilinear_taps<V>(a, fx, fy, fz), RG ? trilinear_taps<V>(a + 128, fx, fy, fz) : 0.0f };
 }

@@ -63,12 +63,16 @@ struct vpt_volume {
     uint32_t *atlas;       // boundary atlas: the six outer voxel planes as 2 x 2-footprint dwords (vpt_device.h sample_volume_boundary); one-channel volumes
     size_t atlas_dwords;
     uint32_t atlas_face, atlas_shift;   // dwords per face image (row pitch x rows), log2 of the row pitch
+    // column records (vpt_device.h record_addr; one-channel byte volumes): built on the first MCM pass that wants them (volume_records)
+    uint8_t *records; size_t rec_bytes; bool rec_valid, rec_wide;
+    uint32_t *rtab32, *rtabc;           // RX | RY: byte offsets of the columns / their Z-order codes
 };
 
 // Tile classes (vpt_kernels.h, "Tile classes"): per reset the host sorts the 16x16 tiles into those none of whose camera rays
 // can meet the cube (MISS) and the rest (HIT).  While every pass uses the reset's matrix (and blur == 0) a MISS tile's photons
 // never enter the cube, so its passes run k_mcm_miss on 32 B of state; `stale` says that the position / transmittance arrays
 // of the MISS tiles are behind and k_mcm_materialize must run before anything but k_mcm_miss looks at them.
+#define VPT_COMPLETE_DESTS 40
 struct TileClasses {
     bool enabled, verify;          // VPT_OPTION_TILE_CLASSES (default on), VPT_OPTION_VERIFY_TILE_CLASSES
     bool valid;                    // the lists describe `mvp` for the present geometry, and every pass since that reset used it
@@ -83,6 +87,9 @@ struct TileClasses {
     bool first_mix_one;            // the first pass since the reset was a fused pass with mix == 1 (MCS, Depth: accumulator = frame exactly)
     bool list_now;                 // the launch being enqueued covers the HIT tiles only
     bool reset_seen;               // vpt_renderer_reset has run on the present buffers (zero-filled buffers are not a reset)
+    // render destinations (the renderer's own buffer, a caller's target, the slots of a bucket or of the gather ring) that a WHOLE-image fused
+    // pass has written since the reset: only there do the skipped tiles hold their final texels (marcher_track)
+    const void *complete[VPT_COMPLETE_DESTS]; int n_complete;
 };
 struct vpt_renderer {
     vpt_context *ctx;
@@ -133,6 +140,7 @@ struct vpt_renderer {
     uint64_t bucket_launches;      // buckets of frames run by k_mcm_bucket_* so far (vpt_renderer_bucket_launches)
     bool bucket_kernel;            // VPT_OPTION_BUCKET_KERNEL: vpt_renderer_play_into runs a bucket's frames by one launch per tile class
     int hit_form;                  // VPT_OPTION_HIT_KERNEL_FORM: 0 = by the number of HIT tiles, 1 = k_mcm_integrate, 2 = k_mcm_integrate_early
+    int column_records;            // VPT_OPTION_COLUMN_RECORDS: 0 = bricks, 1 = column records, 2 (default) = records where the bricks exceed VPT_RECORDS_AUTO_BYTES
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
     void *scratch; size_t scratch_bytes;
@@ -180,6 +188,7 @@ static inline size_t frame_elem(int kind) {
 // ---------------------------------------------------------------------------------------------
 int join_side(vpt_renderer *r);                     // the side streams' work happens-before everything enqueued on the context's stream from here on
 int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, PassArgs *a);
+int volume_records(vpt_volume *v);                  // builds the column records of a finalized one-channel byte volume if they are not current
 hipError_t create_overlapping_stream(hipStream_t *out, const hipStream_t *others, int n_others);
 bool invert_matrix(const float *m, double out[4][4]);               // column-major float matrix -> its inverse (double); false: singular
 int classes_build(vpt_renderer *r, const float *mvp_inverse);       // tile lists of `mvp_inverse` on the device (classify_tiles)
@@ -301,8 +310,18 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     return VPT_OK;
 }
 // the instantiation for (addressing, filter, channels): V = VPT_V_WIDE | VPT_V_NEAREST | VPT_V_RG bits
+// MCM on a one-channel byte volume with the LINEAR filter: the in-cube samples come from the column records (VPT_OPTION_COLUMN_RECORDS).
+// Measured (round 4, 1080p headline camera, us per frame bricks -> records): 512^3 80.0 -> 83.3, every tile HIT 143.9 -> 157.1, extinction 50
+// 80.3 -> 92.9 — 256 MiB of bricks mostly live in the 256 MB Infinity Cache and a dense medium's short steps re-use brick lines, 512 MiB of
+// records do neither —; 1024^3 (2 GiB of bricks, beyond every cache) 98.5 -> 96.6, HIT + MISS kernels alone 127.2 -> 122.0.  Hence AUTO.
+#define VPT_RECORDS_AUTO_BYTES (512ull << 20)
+static inline bool renderer_uses_records(const vpt_renderer *r) {
+    const vpt_volume *v = r->vol;
+    if (!(r->kind == VPT_RENDERER_MCM && v && v->channels == 1 && !v->f32 && v->filter == VPT_FILTER_LINEAR && v->rtab32 != nullptr)) return false;
+    return r->column_records == 1 || (r->column_records == 2 && v->brick_bytes > VPT_RECORDS_AUTO_BYTES);
+}
 static inline int variant_of(const vpt_renderer *r) {
-    return (r->vol->wide ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0) | (r->vol->channels == 2 ? VPT_V_RG : 0) |
+    return ((r->vol->wide || (renderer_uses_records(r) && r->vol->rec_wide)) ? VPT_V_WIDE : 0) | (r->vol->filter == VPT_FILTER_NEAREST ? VPT_V_NEAREST : 0) | (r->vol->channels == 2 ? VPT_V_RG : 0) |
            (r->vol->f32 ? VPT_V_F32 : 0);
 }
 #define LAUNCH_S(KT, r, a) do { \

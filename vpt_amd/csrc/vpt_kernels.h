@@ -154,7 +154,8 @@ VPT_DEV void multi_pass_select(PassArgs &a, uint32_t base, uint32_t f) {
 }
 
 // dynamic LDS: [tf pairs: tf_w * 2 float4][TX nx][TY ny][TZ nz], 4-byte entries (byte offsets, or brick codes when WIDE)
-template <bool WIDE>
+// REC: the two column tables RX | RY of the column records (vpt_device.h record_addr) in place of the three brick tables
+template <bool WIDE, bool REC = false>
 VPT_DEV LdsTables stage_lds(float4 *lds, const PassArgs &a) {
     const int nthreads = (int)blockDim.x;
     for (int t = (int)threadIdx.x; t < a.tf_w; t += nthreads) {
@@ -162,9 +163,9 @@ VPT_DEV LdsTables stage_lds(float4 *lds, const PassArgs &a) {
         lds[2 * t] = v;
         lds[2 * t + 1] = make_float4(n.x - v.x, n.y - v.y, n.z - v.z, n.w - v.w);
     }
-    int ntab = a.vol.nx + a.vol.ny + a.vol.nz;
+    int ntab = REC ? a.vol.nx + a.vol.ny : a.vol.nx + a.vol.ny + a.vol.nz;
     uint32_t *tab = (uint32_t *)(lds + 2 * a.tf_w);
-    const uint32_t *src = WIDE ? a.vol.tabc : a.vol.tab32;
+    const uint32_t *src = REC ? (WIDE ? a.vol.rtabc : a.vol.rtab32) : (WIDE ? a.vol.tabc : a.vol.tab32);
     // 16 bytes per lane: the staging is on the critical path of every workgroup (a 512^3 table image is 6 KiB: two round
     // trips for 256 threads instead of six)
     const int n4 = ntab >> 2;

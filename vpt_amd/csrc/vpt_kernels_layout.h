@@ -148,6 +148,33 @@ __global__ void __launch_bounds__(128) k_brickify_f32(const float *lin, float *b
     }
 }
 
+// column records (vpt_device.h record_addr): a workgroup takes 64 voxels of a row x 16 slices of one y, stages the rows y and
+// y + 1 (clamped) in LDS and writes, per column, the 16 records of its z range as one contiguous 64-byte run (four lanes x four
+// dwords).  offsets = RX | RY (nx + ny entries): the column's first record in bytes, or its Z-order code when `wide`
+// (then byte offset = code * 4 nz).  Any size: indices clamped, partial tiles guarded.
+__global__ void __launch_bounds__(256) k_build_records(const uint8_t *lin, uint8_t *records, int nx, int ny, int nz, const uint32_t *offsets, int wide) {
+    __shared__ uint8_t tile[2][16][68];
+    const int t = (int)threadIdx.x;
+    const int x0 = (int)blockIdx.x * 64, y = (int)blockIdx.y, z0 = (int)blockIdx.z * 16;
+    const int y1 = min(y + 1, ny - 1);
+    for (int idx = t; idx < 2 * 16 * 65; idx += 256) {
+        const int xi = idx % 65, rz = idx / 65, zi = rz & 15, rw = rz >> 4;
+        const int x = min(x0 + xi, nx - 1), z = min(z0 + zi, nz - 1);
+        tile[rw][zi][xi] = lin[((size_t)z * ny + (rw ? y1 : y)) * nx + x];
+    }
+    __syncthreads();
+    const int xl = t >> 2, zq = (t & 3) * 4, x = x0 + xl;
+    if (x >= nx) return;
+    const uint32_t o = offsets[x] + offsets[nx + y];
+    uint8_t *col = records + (wide ? (uint64_t)o * (uint64_t)(4 * nz) : (uint64_t)o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int zi = zq + k, z = z0 + zi;
+        if (z < nz)
+            ((uint32_t *)col)[z] = (uint32_t)tile[0][zi][xl] | ((uint32_t)tile[0][zi][xl + 1] << 8) | ((uint32_t)tile[1][zi][xl] << 16) | ((uint32_t)tile[1][zi][xl + 1] << 24);
+    }
+}
+
 // boundary atlas (vpt_device.h sample_volume_boundary): thread c of [0, cx + cy + cz) builds cell c of the low-side AND the
 // high-side face of its axis from the linear volume.  Face x: cells (a, b) = (y, z); y: (x, z); z: (x, y); face f = 2 * axis +
 // side at dword f * face, cell (a, b) at (b << shift) + a.

@@ -119,17 +119,23 @@ VPT_DEV SampleLoads mcm_sample_issue(const PassArgs &a, const LdsTables &t, f3 p
         linear_cell(p.x, a.vol.fnx, a.vol.hx, x, s.f0);
         linear_cell(p.y, a.vol.fny, a.vol.hy, y, s.f1);
         linear_cell(p.z, a.vol.fnz, a.vol.hz, z, s.f2);
-        const uint8_t *b = cell_addr<WIDE>(a.vol, t, x, y, z);
-        __builtin_memcpy(&s.w0, b, 8);
-        __builtin_memcpy(&s.w1, b + 25, 8);
+        if (V & VPT_V_REC) {
+            s.w0 = record_load(record_addr<WIDE>(a.vol, t, x, y, z));      // records z | z + 1 of the column: all eight taps
+        } else {
+            const uint8_t *b = cell_addr<WIDE>(a.vol, t, x, y, z);
+            __builtin_memcpy(&s.w0, b, 8);
+            __builtin_memcpy(&s.w1, b + 25, 8);
+        }
     }
     s.atlas = at ? 1u : 0u;
     asm volatile("" : "+v"(s.atlas));
     return s;
 }
+template <int V>
 VPT_DEV float4 mcm_sample_finish(const PassArgs &a, const LdsTables &t, const SampleLoads &s) {
     float r;
     if (s.atlas) r = boundary_blend(s.aw, s.f0, s.f1);
+    else if (V & VPT_V_REC) r = record_blend((uint32_t)s.w0, (uint32_t)(s.w0 >> 32), s.f0, s.f1, s.f2);
     else r = trilinear_blend((uint32_t)s.w0, (uint32_t)(s.w0 >> 32), (uint32_t)s.w1, (uint32_t)(s.w1 >> 32), s.f0, s.f1, s.f2);
     float4 vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
     asm volatile("" : "+v"(vs.w));
@@ -137,7 +143,7 @@ VPT_DEV float4 mcm_sample_finish(const PassArgs &a, const LdsTables &t, const Sa
 }
 template <int V>
 VPT_DEV float4 mcm_sample(const PassArgs &a, const LdsTables &t, f3 p, bool oob) {
-    if (!(V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32))) return mcm_sample_finish(a, t, mcm_sample_issue<V>(a, t, p, oob));
+    if (!(V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32))) return mcm_sample_finish<V>(a, t, mcm_sample_issue<V>(a, t, p, oob));
     float4 vs = sample_volume_color<V>(a, t, p);
     asm volatile("" : "+v"(vs.w));
     return vs;
@@ -196,7 +202,7 @@ VPT_DEV void mcm_events_early(const PassArgs &a, const LdsTables &t, Photon &ph,
             photon_deposit(ph, f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z });
             reset_photon(state, ph, px, py, a, from0);
         }
-        float4 vs = mcm_sample_finish(a, t, ld);
+        float4 vs = mcm_sample_finish<V>(a, t, ld);
         float p_null = 1.0f - vs.w;
         float p_scat = (bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
         float p_abs = 1.0f - p_null - p_scat;
@@ -342,7 +348,7 @@ VPT_DEV void mcm_events_fast_early(const PassArgs &a, const LdsTables &t, Photon
             float4 env = sample_environment(a.env, ph.direction);
             fast_path_end(a, c, state, ph, f3{ ph.transmittance.x * env.x, ph.transmittance.y * env.y, ph.transmittance.z * env.z }, px, py);
         }
-        float4 vs = mcm_sample_finish(a, t, lds);
+        float4 vs = mcm_sample_finish<V>(a, t, lds);
         float p_null = 1.0f - vs.w;
         float p_scat = (bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
         float p_abs = 1.0f - p_null - p_scat;
@@ -398,7 +404,7 @@ VPT_DEV void photon_store(const PassArgs &a, int k, const Photon &ph) {       //
 template <bool FUSE_RENDER, int V, bool PREFETCH>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(PREFETCH ? 5 : 7, 8))) k_mcm_persist(PassArgs a, int nseg) {
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0, (V & VPT_V_REC) != 0>(lds_raw, a);
     const int lane = (int)threadIdx.x & 63;
     const int nwaves = (int)gridDim.x * (VPT_BLOCK / 64);
     int g = (int)blockIdx.x * (VPT_BLOCK / 64) + ((int)threadIdx.x >> 6);
@@ -446,7 +452,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     PhotonState st;
     if (p.tile) st = photon_load(a, p.k);
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0, (V & VPT_V_REC) != 0>(lds_raw, a);
     if (!p.valid) return;
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     Photon ph = photon_unpack(st);
@@ -464,7 +470,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     PhotonState st;
     if (p.tile) st = photon_load(a, p.k);
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0, (V & VPT_V_REC) != 0>(lds_raw, a);
     if (!p.valid) return;
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     Photon ph = photon_unpack(st);
@@ -607,7 +613,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_materialize(PassArgs a) {
 template <int V, bool FRAMES>
 VPT_DEV void mcm_multi_body(PassArgs &a, uint32_t npasses, uint2 *ring, uint32_t slot_pixels) {
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0, (V & VPT_V_REC) != 0>(lds_raw, a);
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
@@ -658,7 +664,7 @@ k_mcm_bucket_hit(PassArgs a, FrameSeeds fs, uint32_t nframes, void *ring, uint32
     PhotonState st;
     if (p.tile) st = photon_load(a, p.k);
     extern __shared__ float4 lds_raw[];
-    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0, (V & VPT_V_REC) != 0>(lds_raw, a);
     if (!p.valid) return;
     const float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     Photon ph = photon_unpack(st);

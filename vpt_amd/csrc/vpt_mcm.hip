@@ -10,6 +10,23 @@
 
 // ---- MCM passes over the tile classes ---------------------------------------------------------------------------------
 typedef void (*PassKernel)(PassArgs);
+// the sampler variant of the tile-class kernels (LINEAR one-channel byte volumes): VPT_V_WIDE | VPT_V_FAST | VPT_V_REC
+static int class_variant(const vpt_renderer *r, const PassArgs &a) {
+    return (variant_of(r) & VPT_V_WIDE) | (r->fast_math ? VPT_V_FAST : 0) | (a.vol.records ? VPT_V_REC : 0);
+}
+#define VARIANT_CASES(...) switch (v) { \
+        case 0: { constexpr int V = 0; return __VA_ARGS__; } \
+        case VPT_V_WIDE: { constexpr int V = VPT_V_WIDE; return __VA_ARGS__; } \
+        case VPT_V_FAST: { constexpr int V = VPT_V_FAST; return __VA_ARGS__; } \
+        case VPT_V_FAST | VPT_V_WIDE: { constexpr int V = VPT_V_FAST | VPT_V_WIDE; return __VA_ARGS__; } \
+        case VPT_V_REC: { constexpr int V = VPT_V_REC; return __VA_ARGS__; } \
+        case VPT_V_REC | VPT_V_WIDE: { constexpr int V = VPT_V_REC | VPT_V_WIDE; return __VA_ARGS__; } \
+        case VPT_V_REC | VPT_V_FAST: { constexpr int V = VPT_V_REC | VPT_V_FAST; return __VA_ARGS__; } \
+        default: { constexpr int V = VPT_V_REC | VPT_V_FAST | VPT_V_WIDE; return __VA_ARGS__; } }
+template <bool FUSE> static PassKernel hit_kernel(int v, bool early) {
+    if (early) VARIANT_CASES((PassKernel)k_mcm_integrate_early<FUSE, V>)
+    VARIANT_CASES((PassKernel)k_mcm_integrate<FUSE, V>)
+}
 static bool mcm_classes_usable(const vpt_renderer *r, const PassArgs &a) {
     return r->cls.enabled && r->cls.valid && a.blur == 0.0f && memcmp(r->cls.mvp, a.mvp_inv.m, sizeof(r->cls.mvp)) == 0;
 }
@@ -46,18 +63,12 @@ static int mcm_classify(vpt_renderer *r, const vpt_uniforms *u) {
 // so that the latency-bound HIT tiles and the arithmetic-bound MISS tiles share the chip for the whole frame
 template <bool FUSE>
 static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
-    const bool wide = (variant_of(r) & VPT_V_WIDE) != 0, fast = r->fast_math != 0, check = r->cls.verify;
+    const bool fast = r->fast_math != 0, check = r->cls.verify;
     PassKernel kh, km;
     // the HIT tiles: few enough to be resident at once at 5 waves per SIMD (a shard's share) -> the form with the early path end,
     // whose pass is one wave per SIMD walking a chain of dependent latencies; else the 7-waves form (VPT_OPTION_HIT_KERNEL_FORM overrides)
     const bool early = r->hit_form == 2 || (r->hit_form == 0 && r->cls.n_hit <= 1280);
-    if (early) {
-        if (fast) kh = wide ? (PassKernel)k_mcm_integrate_early<FUSE, VPT_V_WIDE | VPT_V_FAST> : (PassKernel)k_mcm_integrate_early<FUSE, VPT_V_FAST>;
-        else kh = wide ? (PassKernel)k_mcm_integrate_early<FUSE, VPT_V_WIDE> : (PassKernel)k_mcm_integrate_early<FUSE, 0>;
-    } else {
-        if (fast) kh = wide ? (PassKernel)k_mcm_integrate<FUSE, VPT_V_WIDE | VPT_V_FAST> : (PassKernel)k_mcm_integrate<FUSE, VPT_V_FAST>;
-        else kh = wide ? (PassKernel)k_mcm_integrate<FUSE, VPT_V_WIDE> : (PassKernel)k_mcm_integrate<FUSE, 0>;
-    }
+    kh = hit_kernel<FUSE>(class_variant(r, a), early);
     // the MISS tiles: the sample consumed after the path end (its gather flies under that arithmetic) — whole frame 80.8 -> 79.3-79.7 us
     // fast-math, 96.1 -> 92.8 bit-exact, rank 3 of 8's share 18.4 -> 17.1 bit-exact but 15.8 -> 16.9 fast-math: there the sample is
     // consumed where the shader takes it
@@ -140,15 +151,14 @@ int mcm_bucket_ready(vpt_renderer *r, const PassArgs &a, bool *ready) {
     *ready = same && r->cls.enabled && mcm_classes_runnable(r, a) && two_streams && !r->cls.verify;
     return VPT_OK;
 }
+template <bool DISPLAY> static BucketKernel bucket_hit_kernel(int v, bool early) {
+    if (early) VARIANT_CASES((BucketKernel)k_mcm_bucket_hit<V, true, DISPLAY>)
+    VARIANT_CASES((BucketKernel)k_mcm_bucket_hit<V, false, DISPLAY>)
+}
 template <bool DISPLAY>
-static void bucket_kernels(bool wide, bool fast, bool early, BucketKernel *kh, BucketKernel *km) {
-    if (early) {
-        if (fast) *kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE | VPT_V_FAST, true, DISPLAY> : (BucketKernel)k_mcm_bucket_hit<VPT_V_FAST, true, DISPLAY>;
-        else *kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE, true, DISPLAY> : (BucketKernel)k_mcm_bucket_hit<0, true, DISPLAY>;
-    } else {
-        if (fast) *kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE | VPT_V_FAST, false, DISPLAY> : (BucketKernel)k_mcm_bucket_hit<VPT_V_FAST, false, DISPLAY>;
-        else *kh = wide ? (BucketKernel)k_mcm_bucket_hit<VPT_V_WIDE, false, DISPLAY> : (BucketKernel)k_mcm_bucket_hit<0, false, DISPLAY>;
-    }
+static void bucket_kernels(int v, bool early, BucketKernel *kh, BucketKernel *km) {
+    const bool fast = (v & VPT_V_FAST) != 0;
+    *kh = bucket_hit_kernel<DISPLAY>(v, early);
     const bool late = !(fast && early);
     *km = fast ? (late ? (BucketKernel)k_mcm_bucket_miss<VPT_V_FAST, true, DISPLAY> : (BucketKernel)k_mcm_bucket_miss<VPT_V_FAST, false, DISPLAY>)
                : (BucketKernel)k_mcm_bucket_miss<0, true, DISPLAY>;
@@ -157,12 +167,12 @@ static void bucket_kernels(bool wide, bool fast, bool early, BucketKernel *kh, B
 int mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar *v, int count, void *ring, uint32_t slot_pixels, bool last_to_render_buffer,
                const uint8_t *display_table) {
     if (count < 1 || count > VPT_BUCKET_FRAMES) return fail(VPT_ERR_INVALID, "a bucket launch holds 1..%d frames", VPT_BUCKET_FRAMES);
-    const bool wide = (variant_of(r) & VPT_V_WIDE) != 0, fast = r->fast_math != 0;
+    const bool fast = r->fast_math != 0;
     // HIT tiles few enough to be resident at once at the kernel's four waves per SIMD: the form with the early path end (launch_mcm_classes)
     const bool early = r->hit_form == 2 || (r->hit_form == 0 && r->cls.n_hit <= 1024);
     BucketKernel kh, km;
-    if (display_table) bucket_kernels<true>(wide, fast, early, &kh, &km);
-    else bucket_kernels<false>(wide, fast, early, &kh, &km);
+    if (display_table) bucket_kernels<true>(class_variant(r, a), early, &kh, &km);
+    else bucket_kernels<false>(class_variant(r, a), early, &kh, &km);
     const size_t lds_hit = lds_bytes(r), lds_miss = (size_t)r->tf_w * 2 * sizeof(float4);
     if (lds_hit > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds_hit);
     if (lds_hit > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hit));
@@ -243,6 +253,10 @@ static int launch_mcm_pass(vpt_renderer *r, const PassArgs &a) {
 #ifdef VPT_WITH_PERSISTENT_KERNELS
     if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) { LAUNCH_MCM_PERSIST(FUSE, r, a); return VPT_OK; }
 #endif
+    if (a.vol.records) {                                   // (LINEAR one-channel byte volume: variant_of is 0 or VPT_V_WIDE)
+        const unsigned g_ = (unsigned)r->ntiles;
+        return launch_sampling(hit_kernel<FUSE>(class_variant(r, a), false), r, a, g_);
+    }
     if (r->fast_math) { if (FUSE) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM0F, r, a); }
     else { if (FUSE) LAUNCH_S(K_MCM1, r, a); else LAUNCH_S(K_MCM0, r, a); }
     return VPT_OK;
@@ -283,6 +297,10 @@ int mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses, uint2 *ring)
     VPT_TRY(mcm_before_pass(r, a, nullptr));
     VPT_TRY(mcm_materialize(r));                      // a whole-image kernel: every tile's full photon state
     if (r->side_busy) VPT_TRY(join_side(r));
+    if (a.vol.records) {                              // column records: LINEAR one-channel byte volumes
+        const int v = class_variant(r, a);
+        VARIANT_CASES(ring ? launch_frames(k_mcm_frames<V>, r, a, npasses, ring) : launch_multi(k_mcm_multi<V>, r, a, npasses))
+    }
 #define MULTI_CASES(F) switch (variant_of(r)) { \
         case 0: return ring ? launch_frames(k_mcm_frames<0 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<0 | F>, r, a, npasses); \
         case 1: return ring ? launch_frames(k_mcm_frames<1 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<1 | F>, r, a, npasses); \

@@ -25,6 +25,7 @@ static int marcher_track(vpt_renderer *r, const PassArgs &a, bool fused, float f
     const int k = r->kind;
     if (k != VPT_RENDERER_MIP && k != VPT_RENDERER_EAM && k != VPT_RENDERER_ISO && k != VPT_RENDERER_MCS && k != VPT_RENDERER_DEPTH) return VPT_OK;
     if (c.passes == 0) {
+        c.n_complete = 0;
         memcpy(c.mvp, a.mvp_inv.m, sizeof(c.mvp));
         c.valid = false; c.poisoned = false;
         c.first_mix_one = fused && first_mix == 1.0f;
@@ -35,11 +36,24 @@ static int marcher_track(vpt_renderer *r, const PassArgs &a, bool fused, float f
     if (fused && c.enabled && !c.poisoned && !r->no_split /* not while a graph is being captured: its grid would be frozen */) {
         const bool fixed_point = k == VPT_RENDERER_DEPTH ? c.first_mix_one : (k == VPT_RENDERER_MCS ? (c.first_mix_one && r->env_opaque) : true);
         if (c.fused_passes >= 1 && fixed_point && c.reset_seen) {
-            if (!c.valid) VPT_TRY(classes_build(r, c.mvp));
-            c.list_now = c.valid && c.n_hit > 0 && c.n_miss > 0;
+            // ... and only into a destination whose skipped tiles already hold those values: one that a whole-image fused pass has written
+            // since the reset (a caller's render target, the slots of a bucket, the gather's ring: each takes one whole pass first)
+            bool complete = false;
+            for (int i = 0; i < c.n_complete && !complete; i++) complete = c.complete[i] == (const void *)a.render;
+            if (complete) {
+                if (!c.valid) VPT_TRY(classes_build(r, c.mvp));
+                c.list_now = c.valid && c.n_hit > 0 && c.n_miss > 0;
+            }
         }
     }
-    if (fused) c.fused_passes++;
+    if (fused) {
+        c.fused_passes++;
+        if (!c.list_now && !c.poisoned) {                         // a whole-image pass under the reset's matrix: its destination is complete now
+            bool known = false;
+            for (int i = 0; i < c.n_complete && !known; i++) known = c.complete[i] == (const void *)a.render;
+            if (!known && c.n_complete < VPT_COMPLETE_DESTS) c.complete[c.n_complete++] = (const void *)a.render;
+        }
+    }
     return VPT_OK;
 }
 

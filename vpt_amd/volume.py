@@ -139,6 +139,13 @@ class Volume(EventTarget):
         vol.setFilter(filter)
         return vol
 
+    def upload_block(self, x, y, z, block):
+        """(extension) texSubImage3D of one more block into the ready volume: `block` is [depth][height][width] in the volume's texel type;
+        the device layouts are rebuilt by the next pass that samples the volume"""
+        block = np.ascontiguousarray(block)
+        d, h, w = block.shape[:3]
+        N.check(N.lib().vpt_volume_upload_block(self.texture, int(x), int(y), int(z), w, h, d, block.ctypes.data_as(C.c_void_p), block.nbytes))
+
     def set_wide_tables(self, wide):
         """force the > 4 GiB addressing variant of the kernels (automatic above 4 GiB of bricked data)"""
         N.check(N.lib().vpt_volume_set_wide_tables(self.texture, 1 if wide else 0))
