@@ -170,8 +170,10 @@ VPT_API int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const f
 /* frame `slot` of the last VPT_PLAY_FRAMES call ([local rows][width][4] RGBA16F), and the ring's device address (extensions: the
  * reference renders one frame per animation tick, AbstractRenderer.js:60-70, and has no frame sequences) */
 /* (extension) `count` eager render() passes by one call, frame i written to caller-owned device memory at first_target + i * stride_bytes
- * (e.g. the slots of a bucket one collective will move); frame_vars as for vpt_renderer_play.  Equivalent to `count` times
- * { vpt_renderer_set_render_target; vpt_renderer_render }; the same stream rules apply (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join) */
+ * (e.g. the slots of a bucket one collective will move); frame_vars as for vpt_renderer_play.  The same frames as `count` times
+ * { vpt_renderer_set_render_target; vpt_renderer_render }, but the bucket's passes run on every stream of a split pass (MCM: the tile
+ * classes' two kernels) and are joined ONCE, before the call returns: whatever the caller enqueues on the context's stream next sees all
+ * `count` frames.  A later call with the same slots may skip texels that cannot have changed (see vpt_renderer_set_render_target). */
 VPT_API int vpt_renderer_play_into(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, void *first_target, size_t stride_bytes);
 VPT_API int vpt_renderer_read_frame_slot(vpt_renderer *r, int slot, void *host_dst, size_t nbytes);
 VPT_API int vpt_renderer_frame_ring_device(vpt_renderer *r, void **device_ptr, size_t *slot_bytes);
@@ -207,8 +209,10 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * value bit for bit (a clamped cell has weight 0 along the clamped axis), one aligned 4-byte gather instead of two unaligned
  * 8-byte ones.  0 = always the bricks. */
 #define VPT_OPTION_BOUNDARY_ATLAS 3
-/* VPT_OPTION_SPLIT_STREAMS (default 1; every renderer but DOS): K in 2 .. VPT_MAX_SPLIT = a pass is launched as K tile-row ranges, all but
- * the first on private side streams.  A pixel's pass depends on its own previous pass only, so consecutive passes of the
+/* VPT_OPTION_SPLIT_STREAMS (every renderer but DOS; default since round 4: MCM 2 — the HIT | MISS kernels of the tile classes —, MIP / EAM / ISO /
+ * Depth 3, MCS / LAO 1: the measured best forms, so that a caller who sets nothing gets them; VPT_DEFAULT_SPLIT=1 in the environment restores 1
+ * everywhere): K in 2 .. VPT_MAX_SPLIT = a pass is launched as K tile-row ranges (or K parts of a tile list), all but
+ * the first on private side streams (created by the first pass that uses them).  A pixel's pass depends on its own previous pass only, so consecutive passes of the
  * ranges never wait for each other and the launch gap, ramp and tail of one range overlap the body of the others (HIP
  * streams in place of one longer launch).  Every other entry point (reads, reset, tone mapper, gather, synchronize ...) first
  * joins the side streams into the context's stream, so callers see the usual in-order semantics; while the render buffer is
@@ -217,28 +221,24 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * stream.  Results identical. */
 #define VPT_MAX_SPLIT 4
 #define VPT_OPTION_SPLIT_STREAMS 4
-/* VPT_OPTION_SPLIT_CALLER_TARGETS (default 0; MCM renderer): 1 = passes into a caller-owned render target are split as well.  The
- * caller then owes a vpt_renderer_join() before work of its own on the context's stream reads the target — e.g. once per bucket
- * of frames handed to a collective, not once per frame (vpt_amd/tiles.py FrameGather, bench.py --gather torch). */
-#define VPT_OPTION_SPLIT_CALLER_TARGETS 5
+/* (5: retired in round 4 — vpt_renderer_play_into* split their passes and join once per call by themselves) */
 /* VPT_OPTION_TILE_CLASSES (default 1; MCM renderer, LINEAR filter, one-channel volumes with the boundary atlas; extension, no
  * reference counterpart): vpt_renderer_reset() sorts the 16x16 tiles into those none of whose camera rays (jitter included) can meet
  * the unit cube ("MISS") and the rest; while the passes keep the reset's uMvpInverseMatrix and blur == 0, a MISS tile's photon is
  * re-emitted and leaves again at every event (MCMRenderer.glsl:135-141 after resetPhoton :70-78), so its passes run a straight-line
  * kernel on 32 of the 56 state bytes per pixel.  Every buffer a caller can read is identical either way.
+ * Value 2 (MCM; a measurement aid): the two class kernels also where a pass must stay on ONE stream, one after the other — each alone on the chip
+ * (slower than the general kernel there, which is why 1 does not do it).
  * VPT_OPTION_VERIFY_TILE_CLASSES (default 0): the MISS-tile kernel also counts events that were inside the cube after all
  * (vpt_renderer_tile_classes' `violations`: must stay 0). */
 #define VPT_OPTION_TILE_CLASSES 6
 #define VPT_OPTION_VERIFY_TILE_CLASSES 7
-/* VPT_OPTION_HIT_KERNEL_FORM (default 0; MCM renderer with tile classes): which form of the HIT-tile kernel runs — 1 = k_mcm_integrate
- * (72 registers, 7 waves per SIMD), 2 = k_mcm_integrate_early (the out-of-cube lanes' path end between issuing the sample's loads and
- * consuming them; 5 waves per SIMD), 0 = the second where the HIT tiles are few enough to be resident at once at its occupancy
- * (<= 1280: a shard's share of a frame), the first otherwise.  Results identical. */
-#define VPT_OPTION_HIT_KERNEL_FORM 8
+/* (8: retired in round 4 — the library picks the HIT-tile kernel's form by the number of HIT tiles; VPT_HIT_KERNEL_FORM=1|2 in the environment
+ * at renderer creation forces one for A/B measurements and tests) */
 /* VPT_OPTION_BUCKET_KERNEL (default 0; MCM renderer; extension): vpt_renderer_play_into() runs up to 16 frames of its bucket by ONE launch
  * per tile class — the photon state stays in registers from the first frame to the last, launch gap, table staging and state traffic are
  * paid once per bucket instead of once per frame (what a rank's small share of a sharded frame mostly pays for) — where the tile classes
- * are in force (VPT_OPTION_TILE_CLASSES with VPT_OPTION_SPLIT_STREAMS >= 2 and VPT_OPTION_SPLIT_CALLER_TARGETS); elsewhere frame by
+ * are in force (VPT_OPTION_TILE_CLASSES with VPT_OPTION_SPLIT_STREAMS >= 2: the defaults); elsewhere frame by
  * frame as without the option.  Every frame is rendered and written to its slot either way; results identical. */
 #define VPT_OPTION_BUCKET_KERNEL 9
 /* VPT_OPTION_COLUMN_RECORDS (default 2; MCM renderer, LINEAR filter, one-channel byte volumes; extension): 1 = the in-cube samples of the MCM
@@ -342,7 +342,7 @@ VPT_API int vpt_tonemapper_read(vpt_tonemapper *t, void *dst, size_t nbytes);
  * VPT_TONEMAPPER_OPTION_FUSE on, vpt_tonemapper_render called once with the parameters to show (its table form).  MCM with the tile
  * classes in force runs the bucket kernels (their frame store looks the texel up in the tone mapper's table; the renderer's own render
  * buffer is not written); otherwise frame by frame through the fused pass and a device copy of the tone mapper's output.  Texels
- * identical to vpt_tonemapper_render on the same frames.  Joins as vpt_renderer_play_into does (VPT_OPTION_SPLIT_CALLER_TARGETS). */
+ * identical to vpt_tonemapper_render on the same frames.  Joins once, before it returns, as vpt_renderer_play_into does. */
 VPT_API int vpt_renderer_play_into_display(vpt_renderer *r, vpt_tonemapper *t, const struct vpt_uniforms *base, const float *frame_vars, int count,
                                            void *first_target, size_t stride_bytes);
 VPT_API int vpt_tonemapper_rows(vpt_tonemapper *t, int *rows);

@@ -452,7 +452,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("gatherUniqueId", GatherUniqueId); EXPORT("gatherCreate", GatherCreate); EXPORT("gatherDestroy", GatherDestroy);
     EXPORT("gatherSetRoot", GatherSetRoot); EXPORT("gatherRender", GatherRender); EXPORT("gatherPlay", GatherPlay); EXPORT("gatherSynchronize", GatherSynchronize);
     EXPORT("gatherReadFrame", GatherReadFrame);
-    CONST(VPT_OPTION_MCS_PERSISTENT); CONST(VPT_OPTION_MCM_PERSISTENT); CONST(VPT_OPTION_FAST_MATH); CONST(VPT_OPTION_BOUNDARY_ATLAS); CONST(VPT_OPTION_SPLIT_STREAMS); CONST(VPT_OPTION_SPLIT_CALLER_TARGETS); CONST(VPT_OPTION_TILE_CLASSES); CONST(VPT_OPTION_VERIFY_TILE_CLASSES); CONST(VPT_OPTION_HIT_KERNEL_FORM); CONST(VPT_OPTION_BUCKET_KERNEL);
+    CONST(VPT_OPTION_MCS_PERSISTENT); CONST(VPT_OPTION_MCM_PERSISTENT); CONST(VPT_OPTION_FAST_MATH); CONST(VPT_OPTION_BOUNDARY_ATLAS); CONST(VPT_OPTION_SPLIT_STREAMS); CONST(VPT_OPTION_TILE_CLASSES); CONST(VPT_OPTION_VERIFY_TILE_CLASSES); CONST(VPT_OPTION_BUCKET_KERNEL); CONST(VPT_OPTION_COLUMN_RECORDS);
     CONST(VPT_PLAY_EAGER); CONST(VPT_PLAY_GRAPH); CONST(VPT_PLAY_FUSED); CONST(VPT_PLAY_FRAMES); CONST(VPT_FRAME_SLOTS);
     CONST(VPT_RENDERER_MIP); CONST(VPT_RENDERER_EAM); CONST(VPT_RENDERER_MCS); CONST(VPT_RENDERER_MCM);
     CONST(VPT_RENDERER_ISO); CONST(VPT_RENDERER_DEPTH); CONST(VPT_RENDERER_LAO); CONST(VPT_RENDERER_DOS); CONST(VPT_BUFFER_DOS_OCCLUSION);

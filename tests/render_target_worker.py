@@ -2,7 +2,7 @@
 """Worker of tests/test_gpu_parity.py::test_mcm_split_streams_with_a_caller_owned_render_target (a fresh process: torch's GPU
 state stays out of the pytest process).  A frame rendered into caller memory (vpt_renderer_set_render_target) is read by work
 the CALLER enqueues on the context's stream right behind render(): with VPT_OPTION_SPLIT_STREAMS on, such passes must not leave
-rows on a side stream.  The context runs on torch's current stream; the consumer is a torch copy on that stream, with no library
+rows on a side stream (vpt_renderer_play_into may, and joins before it returns).  The context runs on torch's current stream; the consumer is a torch copy on that stream, with no library
 call in between.  Exit code 0 and a final line "OK" = every copied frame equals the one-stream run's."""
 import os
 import sys
@@ -26,21 +26,22 @@ def main():
     gvol = vpt_amd.Volume.from_array(ctx, sphere_volume(64, noise=40.0), 'linear')
     cam, tr = default_camera(W / H), Transform(Node())
     outs = []
-    # (split, caller joins): one stream; three ranges kept on the context's stream by the library; three ranges on three streams
-    # with VPT_OPTION_SPLIT_CALLER_TARGETS and a vpt_renderer_join() before the consumer
-    for split, caller_joins in ((1, False), (3, False), (3, True)):
+    # one stream; three ranges asked for but kept on the context's stream by the library (a caller-owned target); vpt_renderer_play_into, whose
+    # passes do run on every stream (here: the HIT | MISS kernels of the tile classes + a third stream) and are joined by the call itself
+    for split, through_play_into in ((1, False), (3, False), (3, True)):
         r = vpt_amd.MCMRenderer(ctx, gvol, cam, None, {'resolution': (W, H), 'transform': tr, 'rng': GoldenRatioRng()})
         r.set_option(N.OPTION_SPLIT_STREAMS, split)
-        r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, int(caller_joins))
         target = torch.zeros((H, W, 4), dtype=torch.float16, device=dev)
-        r.set_render_target(target.data_ptr(), target.numel() * 2)
+        if not through_play_into:
+            r.set_render_target(target.data_ptr(), target.numel() * 2)
         r.reset()
         copies = []
         for _ in range(6):
-            r.render()
-            if caller_joins:
-                r.join()
-            copies.append(target.clone())                 # enqueued on the context's stream, straight behind the pass
+            if through_play_into:
+                r.play_into(1, target.data_ptr(), target.numel() * 2)
+            else:
+                r.render()
+            copies.append(target.clone())                 # enqueued on the context's stream, straight behind the pass: no library call in between
         torch.cuda.synchronize()
         outs.append([c.cpu().numpy() for c in copies])
         r.set_render_target(0, 0)

@@ -24,6 +24,24 @@ def far_scene(gpu_ctx, oracle, w=208, h=144, env=None, cam=(0.7, -0.3, 3.2), n=2
     return Scene(gpu_ctx, oracle, n, w, h, filt, tf=colour_tf(48, 1), env=env, camera=orbit_camera(w / h, *cam))
 
 
+def mcm_with_form(sc, form, **kw):
+    """an MCM renderer whose HIT-tile kernel form is forced (VPT_HIT_KERNEL_FORM is read when the renderer is created): 1 = k_mcm_integrate,
+    2 = k_mcm_integrate_early, 0 = the library's choice by the number of HIT tiles"""
+    import os
+    old = os.environ.get("VPT_HIT_KERNEL_FORM")
+    if form:
+        os.environ["VPT_HIT_KERNEL_FORM"] = str(form)
+    else:
+        os.environ.pop("VPT_HIT_KERNEL_FORM", None)
+    try:
+        return sc.renderer('mcm', **kw)
+    finally:
+        if old is None:
+            os.environ.pop("VPT_HIT_KERNEL_FORM", None)
+        else:
+            os.environ["VPT_HIT_KERNEL_FORM"] = old
+
+
 def all_buffers(r):
     return [r.read(b).copy() for b in MCM_BUFFERS] + [r.getTexture().copy()]
 
@@ -31,13 +49,12 @@ def all_buffers(r):
 @pytest.mark.parametrize("fast", [0, 1])
 @pytest.mark.parametrize("split,form", [(1, 0), (3, 1), (2, 2)])
 def test_classes_on_and_off_give_identical_buffers(gpu_ctx, oracle, fast, split, form):
-    """form: VPT_OPTION_HIT_KERNEL_FORM — 1 = k_mcm_integrate on the HIT tiles, 2 = k_mcm_integrate_early (path end of the out-of-cube
+    """form: VPT_HIT_KERNEL_FORM in the environment — 1 = k_mcm_integrate on the HIT tiles, 2 = k_mcm_integrate_early (path end of the out-of-cube
     lanes under the sample's loads), 0 = chosen by the number of HIT tiles; one stream runs the general kernel on every tile"""
     sc = far_scene(gpu_ctx, oracle, env=env_map(16, 8))
 
     def run(classes):
-        r = sc.renderer('mcm')
-        r.set_option(N.OPTION_HIT_KERNEL_FORM, form)
+        r = mcm_with_form(sc, form)
         r.set_option(N.OPTION_TILE_CLASSES, classes)
         r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
         r.set_option(N.OPTION_FAST_MATH, fast)
@@ -261,8 +278,7 @@ def test_full_hd_frame_classes_on_and_off(gpu_ctx, oracle, fast, form):
     sc = Scene(gpu_ctx, oracle, 128, 1920, 1080, camera=default_camera(1920 / 1080), noise=48.0)
 
     def run(classes):
-        r = sc.renderer('mcm')
-        r.set_option(N.OPTION_HIT_KERNEL_FORM, form)
+        r = mcm_with_form(sc, form)
         r.set_option(N.OPTION_TILE_CLASSES, classes)
         r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
         r.set_option(N.OPTION_FAST_MATH, fast)
@@ -303,11 +319,8 @@ def test_bucket_kernel_equals_frame_by_frame(gpu_ctx, oracle, fast, shard, form)
 
     def run(bucket):
         sc = far_scene(gpu_ctx, oracle, w=200, h=184, env=env)
-        r = sc.renderer('mcm', shard=shard) if shard else sc.renderer('mcm')
+        r = mcm_with_form(sc, form, shard=shard) if shard else mcm_with_form(sc, form)
         r.set_option(N.OPTION_FAST_MATH, fast)
-        r.set_option(N.OPTION_HIT_KERNEL_FORM, form)
-        r.set_option(N.OPTION_SPLIT_STREAMS, 2)
-        r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
         r.set_option(N.OPTION_BUCKET_KERNEL, bucket)
         r.extinction = 4; r.steps = 4; r.anisotropy = 0.2
         r.reset()
@@ -353,3 +366,56 @@ def test_bucket_kernel_equals_frame_by_frame(gpu_ctx, oracle, fast, shard, form)
     assert len(a) == len(b) and na == nb
     for k, (x, y) in enumerate(zip(a, b)):
         assert_same_bits(y, x, "bucket kernel vs frame by frame, output %d" % k)
+
+
+def test_a_default_constructed_renderer_runs_the_tile_classes(gpu_ctx, oracle):
+    """round 4: the measured best form is the library's default — RendererFactory('mcm') + reset() + render() with NO option call launches the
+    HIT | MISS kernels on two streams (VPT_OPTION_SPLIT_STREAMS defaults to 2 for MCM, the side stream is created by the first pass)"""
+    sc = far_scene(gpu_ctx, oracle)
+    r = sc.renderer('mcm')
+    r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)          # (counts only; does not change what is launched)
+    r.extinction = 5
+    o = oracle.OracleRenderer('mcm', sc.osc, sc.w, sc.h)
+    r.reset()
+    o.reset(oracle.make_frame(sc.w, sc.h, sc.m, seed=np.float32(GoldenRatioRng()())))
+    hit, miss, _ = r.tile_classes()
+    assert miss > 0 and hit > 0
+    r.set_profiling(1)
+    for _ in range(3):
+        r.render()
+        o.render(to_frame(oracle, sc, r._u))
+    assert r.profile_side()[1] == 3                        # three passes put a launch on the side stream: the MISS-tile kernel
+    r.set_profiling(False)
+    for b, s in zip(MCM_BUFFERS, o.state):
+        assert_same_bits(r.read(b), s.reshape(sc.h, sc.w, 4), "state buffer %d" % b)
+    assert r.tile_classes()[2] == 0
+    r.destroy(); sc.gvol.destroy()
+
+
+def test_a_distant_camera_runs_every_tile_as_a_hit_tile(gpu_ctx, oracle):
+    """near-plane points thousands of units from the cube: the classification's absolute margin no longer covers the kernels' fp32 rounding
+    there, every tile is HIT (vpt_core.hip VPT_CLASS_FAR) — and the images agree with the classes switched off, VERIFY on"""
+    from vpt_amd.scene import default_camera
+    w, h = 208, 144
+    cam = default_camera(w / h)
+    cam.transform.localTranslation = [0.3, 0.2, 5000.0]
+    pc = cam.components[0]
+    pc.fovy = 0.0006; pc.near = 2500.0; pc.far = 10000.0
+    sc = Scene(gpu_ctx, oracle, 24, w, h, tf=colour_tf(48, 1), camera=cam)
+    outs = []
+    for classes in (0, 1):
+        r = sc.renderer('mcm')
+        r.set_option(N.OPTION_TILE_CLASSES, classes)
+        r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
+        r.extinction = 3
+        r.reset()
+        if classes:
+            assert r.tile_classes()[1] == 0
+        for _ in range(3):
+            r.render()
+        assert r.tile_classes()[2] == 0
+        outs.append(all_buffers(r))
+        r.destroy()
+    for k, (x, y) in enumerate(zip(*outs)):
+        assert_same_bits(y, x, "distant camera, output %d" % k)
+    sc.gvol.destroy()

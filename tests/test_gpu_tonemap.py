@@ -461,7 +461,6 @@ def test_play_into_display_equals_the_tone_mapped_frames(gpu_ctx, oracle, rkind,
             r.extinction = 6; r.steps = 4
             r.set_option(N.OPTION_FAST_MATH, fast)
         r.set_option(N.OPTION_SPLIT_STREAMS, 2)
-        r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
         r.reset()
         tm = vpt_amd.ToneMapperFactory(tkind)(gpu_ctx, r, {'resolution': (w, h)})
         tm.set_option(N.TONEMAPPER_OPTION_TABLE, N.TONEMAPPER_TABLE_ALWAYS)
@@ -489,7 +488,6 @@ def test_play_into_display_equals_the_tone_mapped_frames(gpu_ctx, oracle, rkind,
     assert n_.value == 2 * stride
 
     def display_frames(count):
-        r.join()                                                         # VPT_OPTION_SPLIT_CALLER_TARGETS: the caller joins before it reads
         slots = [aux.read_frame_slot(k).view(np.uint8).reshape(2, h, w, 4) for k in range((count + 1) // 2)]
         return np.concatenate(slots)[:count].copy()
 

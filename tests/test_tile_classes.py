@@ -114,3 +114,17 @@ def test_volume_off_screen_is_all_miss():
     cam.transform.localTranslation = [40, 0, 2]                          # looking down -z, far to the side of the cube
     cls = classify(w, h, mvp_inverse_matrix(cam, Transform(Node())))
     assert cls.all()
+
+
+def test_a_distant_camera_classifies_nothing_as_miss():
+    """The margin of the classification is absolute (1e-3 of the cube) while the kernels' fp32 error of from + t * direction grows with
+    |from|: with the near plane thousands of units away (a distant, narrow camera standing in for an orthographic one) no tile may be
+    called MISS; a camera at a moderate distance still is classified"""
+    w, h = 320, 200
+    for dist, expect_miss in ((30.0, True), (5000.0, False)):
+        cam = default_camera(w / h)
+        cam.transform.localTranslation = [0.3, 0.2, dist]
+        pc = cam.components[0]
+        pc.fovy = 0.02; pc.near = 0.5 * dist; pc.far = 2.0 * dist
+        cls = classify(w, h, mvp_inverse_matrix(cam, Transform(Node())))
+        assert bool(cls.any()) == expect_miss, (dist, int(cls.sum()))

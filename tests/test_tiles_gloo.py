@@ -1,5 +1,6 @@
-"""CPU, world_size 2 (gloo): the N > 1 path of bench.py — per-rank row shards, one equal-sized all_gather per frame,
-reassembly by index_select — reproduces the full frame on every rank."""
+"""CPU, world sizes 2, 4 and 8 (gloo): the N > 1 path of bench.py — per-rank row shards, one equal-sized all_gather per frame or per
+bucket of frames (RGBA16F, and the RGBA8 display buckets of vpt_renderer_play_into_display at 16 frames per collective), reassembly by
+index_select — reproduces the full frame on every rank."""
 import os
 import socket
 import subprocess
@@ -81,6 +82,32 @@ WORKER = textwrap.dedent("""
             assert g.acquire_bucket() is None
             assert (g.last_frame()[:, :, 2] == frame - 1).all()     # (flushes the partial bucket)
     g.flush(); g.wait_all()
+    # the display form (bench.py's config.display_gather_form): RGBA8 texels, 16 frames per all_gather — whole buckets, then a partial one
+    F = 16
+    g = FrameGather(dist, torch, W, H, torch.device("cpu"), frames_per_gather=F, texel='rgba8')
+    assert g.texel_bytes == 4 and g._send[0].dtype == torch.uint8
+    frame = 0
+    rows8 = (mine %% 251).to(torch.uint8)[:, None]
+    for step in range(3):
+        bucket = g.acquire_bucket()
+        assert bucket is not None and bucket.shape == (F, g.rows, W, 4) and bucket.dtype == torch.uint8
+        bucket.zero_()
+        for j in range(F):
+            bucket[j][rows_mine, :, 0] = rows8
+            bucket[j][rows_mine, :, 1] = torch.arange(W, dtype=torch.uint8)
+            bucket[j][rows_mine, :, 2] = (frame + j) %% 256
+            bucket[j][rows_mine, :, 3] = 255
+        g.commit_bucket()
+        frame += F
+        img = g.last_frame()
+        assert img.shape == (H, W, 4) and img.dtype == torch.uint8
+        assert (img[:, :, 0] == (torch.arange(H) %% 251).to(torch.uint8)[:, None]).all(), step
+        assert (img[:, :, 1] == torch.arange(W, dtype=torch.uint8)[None, :]).all() and (img[:, :, 2] == (frame - 1) %% 256).all() and (img[:, :, 3] == 255).all(), step
+    for k in range(5):                                        # a partial bucket of 5 frames, flushed by last_frame()
+        t = g.acquire(); t.zero_(); t[rows_mine, :, 0] = rows8; t[rows_mine, :, 2] = (frame %% 256); g.commit(); frame += 1
+    img = g.last_frame()
+    assert (img[:, :, 0] == (torch.arange(H) %% 251).to(torch.uint8)[:, None]).all() and (img[:, :, 2] == (frame - 1) %% 256).all()
+    g.flush(); g.wait_all()
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
@@ -91,13 +118,17 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_frame_gather_world2_gloo(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_frame_gather_gloo(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]

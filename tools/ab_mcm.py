@@ -13,7 +13,7 @@ ap.add_argument("--lib", default="")
 ap.add_argument("--tag", default="")
 ap.add_argument("--fast", type=int, default=1)
 ap.add_argument("--split", type=int, default=3)
-ap.add_argument("--classes", type=int, default=1)
+ap.add_argument("--classes", type=int, default=1, help="VPT_OPTION_TILE_CLASSES: 0 off, 1 on, 2 on even on one stream (each class kernel alone on the chip)")
 ap.add_argument("--volume", type=int, default=512)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
@@ -22,7 +22,7 @@ ap.add_argument("--blocks", type=int, default=5)
 ap.add_argument("--shard", default="", help="rank,world,rows: time one rank's share of the frame")
 ap.add_argument("--renderer", default="mcm")
 ap.add_argument("--steps", type=int, default=8)
-ap.add_argument("--hit-form", type=int, default=0)
+ap.add_argument("--hit-form", type=int, default=0, help="1 / 2: force a form of the HIT-tile kernel (VPT_HIT_KERNEL_FORM in the environment of the renderer's creation)")
 ap.add_argument("--records", type=int, default=-1, help="VPT_OPTION_COLUMN_RECORDS (MCM): 0 / 1; -1 = the library's default")
 ap.add_argument("--camera-z", type=float, default=2.0, help="z of the default camera's translation (0.9: the volume fills the frame, every tile is a HIT tile)")
 ap.add_argument("--extinction", type=float, default=0.0)
@@ -34,6 +34,8 @@ ap.add_argument("--dummy-contexts", type=int, default=0, help="contexts (one HIP
 args = ap.parse_args()
 if args.lib:
     os.environ["VPT_HIP_LIBRARY"] = os.path.abspath(args.lib)
+if args.hit_form:
+    os.environ["VPT_HIT_KERNEL_FORM"] = str(args.hit_form)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -86,8 +88,6 @@ try:
     r.set_option(N.OPTION_TILE_CLASSES, args.classes)
 except vpt_amd.VptError:
     pass                                              # a build from before the option existed
-if args.hit_form:
-    r.set_option(N.OPTION_HIT_KERNEL_FORM, args.hit_form)
 if args.records >= 0 and args.renderer == "mcm":
     r.set_option(N.OPTION_COLUMN_RECORDS, args.records)
 r.set_option(N.OPTION_SPLIT_STREAMS, max(1, args.split))
@@ -115,7 +115,10 @@ if args.kernel_times:
     ctx.synchronize()
     ms, n = r.profile(); ms2, n2 = r.profile_side()
     r.set_profiling(False)
-    extra += "  kernels: context %.2f us" % (ms / max(n, 1) * 1e3) + ((" | side %.2f us" % (ms2 / n2 * 1e3)) if n2 else "")
+    if args.split == 1 and n2:          # one stream, VPT_OPTION_TILE_CLASSES 2: HIT then MISS; the outer pair brackets both
+        extra += "  kernels alone: HIT %.2f us | MISS %.2f us" % ((ms / max(n, 1) - ms2 / n2) * 1e3, ms2 / n2 * 1e3)
+    else:
+        extra += "  kernels: context %.2f us" % (ms / max(n, 1) * 1e3) + ((" | side %.2f us" % (ms2 / n2 * 1e3)) if n2 else "")
     if args.renderer == "mcm":
         extra += "  tiles %s" % (r.tile_classes()[:2],)
 if args.digest:

@@ -33,7 +33,7 @@ for shard in ((3, 8, 8), (1, 4, 8), (0, 2, 8), None):
         r = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / H), None, opts)
         r.set_option(N.OPTION_FAST_MATH, fast)
         r.set_option(N.OPTION_SPLIT_STREAMS, 2)
-        r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
+       
         r.set_option(N.OPTION_BUCKET_KERNEL, bucket)
         r.reset()
         r.play(16, frames=True)

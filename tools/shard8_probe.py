@@ -76,7 +76,6 @@ def main():
         for world, rank in (() if os.environ.get('VPT_PROBE_HANDOFF_ONLY') else ((8, 3), (4, 1), (2, 0), (1, 0))):
             for bucket in (0, 1):
                 sh = make(ctx, gvol, W, H, fast, 2, shard=(rank, world, 8) if world > 1 else None)
-                sh.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
                 sh.set_option(N.OPTION_BUCKET_KERNEL, bucket)
                 sh.play(16, frames=True)
                 p, n = C.c_void_p(), C.c_size_t()

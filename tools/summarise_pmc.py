@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses one tools/r03_pmc.sh directory: kernel_stats.csv (rocprofv3 --kernel-trace --stats) and summary.json with, PER KERNEL of
+"""Condenses one tools/pmc.sh directory: kernel_stats.csv (rocprofv3 --kernel-trace --stats) and summary.json with, PER KERNEL of
 the renderer (k_mcm_integrate, k_mcm_miss, k_eam, ...), the mean per-launch counter values, corrected as MI355X_MICROARCH.md
 prescribes (gfx950: FETCH_SIZE counts 128-byte requests at 64 bytes -> doubled; WRITE_SIZE exact; both in KiB)."""
 import csv
@@ -10,11 +10,22 @@ import sys
 
 d = sys.argv[1]
 summary = {"_command": open(os.path.join(d, "command.txt")).read().strip(), "kernels": {}}
+# the traced run's own bench line (kt.log holds bench.py's stdout): the tracer's overhead is on record next to the kernel durations
+traced = None
+try:
+    for line in open(os.path.join(d, "kt.log"), errors="replace"):
+        if line.startswith('{"metric"'):
+            j = json.loads(line)
+            traced = {"ms_per_step": j["ms_per_step"], "steps": j["steps"], "value": j["value"]}
+except OSError:
+    pass
+summary["_traced_run"] = traced
 stats = glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(d, "kernel_stats.csv"), "w") as f:
-        f.write("# %s\nName,Calls,TotalDurationUs,AverageUs,MinUs,MaxUs,Percentage\n" % summary["_command"])
+        f.write("# %s\n# the traced run's own figure: ms_per_step %s over %s steps (rocprofv3 --kernel-trace active, no time-based warm-up)\nName,Calls,TotalDurationUs,AverageUs,MinUs,MaxUs,Percentage\n"
+                % (summary["_command"], ("%.5f" % traced["ms_per_step"]) if traced else "?", traced["steps"] if traced else "?"))
         for r in rows[:12]:
             f.write('"%s",%s,%.3f,%.3f,%.3f,%.3f,%s\n' % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3,
                                                          float(r.get("MinNs", 0)) / 1e3, float(r.get("MaxNs", 0)) / 1e3, r["Percentage"]))

@@ -38,7 +38,7 @@ def main():
             shard, full_h = ((3, 8, 8), 1080) if H == 136 else ((0, 1, 8), H)
             r = vpt_amd.MCMRenderer(ctx, gvol, default_camera(W / full_h), None, {'resolution': (W, full_h), 'transform': Transform(Node()), 'rng': GoldenRatioRng(), 'shard': shard})
             assert int(r.local_rows()) == H
-            r.set_option(N.OPTION_FAST_MATH, 1); r.set_option(N.OPTION_SPLIT_STREAMS, 2); r.set_option(N.OPTION_SPLIT_CALLER_TARGETS, 1)
+            r.set_option(N.OPTION_FAST_MATH, 1); r.set_option(N.OPTION_SPLIT_STREAMS, 2);
             r.set_option(N.OPTION_BUCKET_KERNEL, bucket_kernel)
             r.reset()
             gather = FrameGather(dist, torch, W, H, device, always_collective=True, frames_per_gather=F, texel='rgba8' if display else 'rgba16f')

@@ -13,10 +13,8 @@ OPTION_MCM_PERSISTENT = 1
 OPTION_FAST_MATH = 2
 OPTION_BOUNDARY_ATLAS = 3
 OPTION_SPLIT_STREAMS = 4
-OPTION_SPLIT_CALLER_TARGETS = 5
 OPTION_TILE_CLASSES = 6
 OPTION_VERIFY_TILE_CLASSES = 7
-OPTION_HIT_KERNEL_FORM = 8
 OPTION_BUCKET_KERNEL = 9
 OPTION_COLUMN_RECORDS = 10
 PLAY_EAGER, PLAY_GRAPH, PLAY_FUSED, PLAY_FRAMES = 0, 1, 2, 3

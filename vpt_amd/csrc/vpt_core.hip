@@ -308,6 +308,7 @@ static int renderer_alloc_buffers(vpt_renderer *r) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     renderer_free_buffers(r);
     r->cls.valid = false; r->cls.stale = false;            // new geometry, zeroed state: classes come back with the next reset
+    r->cls.built = false;
     r->cls.passes = 0; r->cls.fused_passes = 0; r->cls.reset_seen = false; r->cls.n_complete = 0;   // (zeroed buffers are not a reset: nothing is skipped before one)
     r->dos_cur = 0; r->dos_rect_valid = false;
     int nblocks = (r->H + r->R - 1) / r->R;                 // row blocks in the image
@@ -391,6 +392,19 @@ extern "C" int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba
     r->cls.poisoned = true;                                  // (MCS: the fixed points of the ray-missing pixels move with the environment)
     return VPT_OK;
 }
+// VPT_OPTION_SPLIT_STREAMS as the library sets it itself (round 4: the measured best form is the default, not an option a caller has to know).
+// MCM: the HIT | MISS kernels of the tile classes need two streams (1080p headline frame 80 us against 108 for the general kernel on one).
+// MIP, EAM, ISO, Depth: three ranges on three streams (EAM 256^3 63.6 -> 52.0 us, MIP 56.2 -> 45.0, ISO 60.6 -> 56.9, Depth 62.3 -> 57.0).
+// MCS, LAO: one (unmeasured gains; the MCS pass is 16 us).  DOS cannot split.  VPT_DEFAULT_SPLIT=1 in the environment: one stream everywhere.
+static int default_split(int kind) {
+    static const bool one = []() { const char *e = getenv("VPT_DEFAULT_SPLIT"); return e && e[0] == '1' && !e[1]; }();
+    if (one) return 1;
+    switch (kind) {
+        case VPT_RENDERER_MCM: return 2;
+        case VPT_RENDERER_MIP: case VPT_RENDERER_EAM: case VPT_RENDERER_ISO: case VPT_RENDERER_DEPTH: return 3;
+        default: return 1;
+    }
+}
 extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int height, vpt_renderer **out) {
     if (!c || !out) return fail(VPT_ERR_INVALID, "null argument");
     if (kind < VPT_RENDERER_MIP || kind > VPT_RENDERER_DOS) return fail(VPT_ERR_INVALID, "No suitable class");  // RendererFactory.js:21
@@ -409,9 +423,9 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
     r->fast_math = 0; r->boundary_atlas = 1; r->column_records = 2;
-    r->frame_ring = nullptr; r->ring_frames = 0; r->split = 1; r->target_is_callers = false; r->no_split = false; r->split_callers = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->frame_ring = nullptr; r->ring_frames = 0; r->split = default_split(kind); r->target_is_callers = false; r->no_split = false; r->bucket_call = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
-    memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0; r->hit_form = 0; r->bucket_kernel = false; r->bucket_launches = 0;
+    memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0; { const char *e = getenv("VPT_HIT_KERNEL_FORM"); r->hit_form = (e && (e[0] == '1' || e[0] == '2') && !e[1]) ? e[0] - '0' : 0; } r->bucket_kernel = false; r->bucket_launches = 0;
     r->tm_owner = nullptr; r->tm_valid = false; r->tm_table = nullptr; r->tm_out = nullptr; r->tm_mode = 0;
     r->lao = LaoParams{ 1, 0.69f, 1, 0.05f, 1, 0.54f, 10, 0.19f, 1.0f, { 2.0f, 12.0f, 3.0f } };
     int rc = renderer_alloc_buffers(r);
@@ -444,6 +458,7 @@ extern "C" int vpt_renderer_destroy(vpt_renderer *r) {
     if (r->work_counter) hipFree(r->work_counter);
     if (r->cls.list) hipFree(r->cls.list);
     if (r->cls.violations) hipFree(r->cls.violations);
+    for (int i = 0; i < 2; i++) { if (r->cls.staging[i]) hipHostFree(r->cls.staging[i]); if (r->cls.staged[i]) hipEventDestroy(r->cls.staged[i]); }
     if (r->frame_ring) hipFree(r->frame_ring);
     if (r->frame_table) hipFree(r->frame_table);
     if (r->frame_staging) hipHostFree(r->frame_staging);
@@ -526,6 +541,7 @@ bool invert_matrix(const float *m, double out[4][4]) {
 #ifndef VPT_CLASS_EPS
 #define VPT_CLASS_EPS 0.001
 #endif
+#define VPT_CLASS_FAR 1000.0
 static void classify_tiles(int W, int H, int local_h, int G, int g, int R, const float *mvp_inverse, std::vector<uint8_t> &classes, int *ptx, int *pty) {
     const int tiles_x = (W + VPT_TILE - 1) / VPT_TILE, tiles_y = (local_h + VPT_TILE - 1) / VPT_TILE;
     *ptx = tiles_x; *pty = tiles_y;
@@ -533,6 +549,16 @@ static void classify_tiles(int W, int H, int local_h, int G, int g, int R, const
     double M[4][4];
     for (int k = 0; k < 16; k++) if (!(fabsf(mvp_inverse[k]) < 1e30f)) return;       // NaN / inf / absurd entries
     if (!invert_matrix(mvp_inverse, M)) return;
+    // VPT_CLASS_EPS is an ABSOLUTE margin against the kernels' fp32 evaluation of from + t * direction, whose rounding grows with |from|
+    // (about |from| * 2^-23 per operation): with the near-plane points beyond ~1e3 units (an orthographic-like or very distant camera) it
+    // no longer covers it — every tile HIT
+    for (int c = 0; c < 4; c++) {
+        const double x = (c & 1) ? 1.0 : -1.0, y = (c & 2) ? 1.0 : -1.0;
+        double q[4];
+        for (int row = 0; row < 4; row++) q[row] = (double)mvp_inverse[row] * x + (double)mvp_inverse[4 + row] * y - (double)mvp_inverse[8 + row] + (double)mvp_inverse[12 + row];
+        if (!(fabs(q[3]) > 1e-30)) return;
+        for (int k = 0; k < 3; k++) if (!(fabs(q[k] / q[3]) < VPT_CLASS_FAR)) return;
+    }
     double px[8], py[8], zmin = 1e300, zmax = -1e300;
     for (int c = 0; c < 8; c++) {
         const double e = VPT_CLASS_EPS;
@@ -669,31 +695,36 @@ int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, PassArgs
 // HIP gives a stream one of a few hardware queues (four by default) and does not say which: two streams on one queue execute their
 // kernels one after the other.  Measured: the three tile-row ranges of an EAM frame 51.9 us on three queues, 83 us when the process had
 // created one or two other streams first; the gather pipeline's hand-off 1.5 or 6 us.  So a stream that has to
-// overlap others is PICKED: candidates are created one by one and each is tried against the streams it must overlap — a 100 us spin kernel
-// on either side; side by side they take the time of one, on one queue the time of two — until one passes (at most 8; the rejected ones
-// are destroyed afterwards, the first candidate stands if none passes, e.g. under a profiler that serialises dispatches).
-// VPT_STREAM_PROBE=0 in the environment: take the first candidate, as rounds 1-3 did.
-__global__ void k_spin(unsigned long long ticks) {
+// overlap others is PICKED: candidates are created one by one and each is tried against the streams it must overlap until one passes (at
+// most 8; the rejected ones are destroyed afterwards, the first candidate stands if none passes, e.g. under a profiler that serialises
+// dispatches).  The test is a rendezvous, not a timing (round 4; rounds 1-3 compared two 100 us wall-clock measurements, which eight ranks
+// probing at once on one host can blur): kernel A on the one stream waits for a flag that kernel B on the other stream raises.  On two
+// queues B runs beside A and A sees the flag within microseconds; on one queue B cannot start before A has ended, and A gives up after
+// VPT_PROBE_TICKS of the wall clock — every wave leaves by the flag, the clock or an iteration cap.  The flag lives in pinned host memory
+// (coherent for both kernels whichever XCD they run on).
+// VPT_STREAM_PROBE=0 in the environment: take the first candidate, as rounds 1-2 did.
+#define VPT_PROBE_TICKS 20000ull                                      // 200 us of the 100 MHz wall clock
+__global__ void k_probe_wait(uint32_t *flag, uint32_t *seen, unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();
-    unsigned int it = 0;
-    while (wall_clock64() - t0 < ticks && ++it < 4000000u) {}       // every wave leaves: by the clock, or by the count
+    uint32_t it = 0, v = 0;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) == 0u && wall_clock64() - t0 < ticks && ++it < 2000000u) {}
+    *seen = v;
 }
-static double spin_ms(hipStream_t a, hipStream_t b, unsigned long long ticks) {
-    hipStreamSynchronize(a);
-    if (b) hipStreamSynchronize(b);
-    const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
-    if (b) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
-    hipStreamSynchronize(a);
-    if (b) hipStreamSynchronize(b);
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-}
+__global__ void k_probe_raise(uint32_t *flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 static bool streams_overlap(hipStream_t a, hipStream_t b) {
-    const unsigned long long ticks = 10000;                          // 100 us of the 100 MHz wall clock
-    spin_ms(a, b, 100);                                              // (code object, queues: first use)
-    double one = 1e30, two = 1e30;
-    for (int k = 0; k < 2; k++) { one = std::min(one, spin_ms(a, nullptr, ticks)); two = std::min(two, spin_ms(a, b, ticks)); }
-    return two < 1.5 * one;
+    static uint32_t *words = nullptr;                                // [0] flag, [1] seen: pinned, kept for the life of the process
+    if (!words && hipHostMalloc((void **)&words, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { words = nullptr; (void)hipGetLastError(); return true; }
+    bool seen = false;
+    for (int round = 0; round < 2 && !seen; round++) {               // (round 0 also pays for the code object's first use on these queues)
+        hipStreamSynchronize(a); hipStreamSynchronize(b);
+        words[0] = 0u; words[1] = 0u;
+        hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, a, words, words + 1, VPT_PROBE_TICKS);
+        hipLaunchKernelGGL(k_probe_raise, dim3(1), dim3(1), 0, b, words);
+        hipStreamSynchronize(a); hipStreamSynchronize(b);
+        seen = words[1] != 0u;
+    }
+    (void)hipGetLastError();
+    return seen;
 }
 // a new non-blocking stream that overlaps every stream of `others` (null entries skipped)
 hipError_t create_overlapping_stream(hipStream_t *out, const hipStream_t *others, int n_others) {
@@ -715,6 +746,22 @@ hipError_t create_overlapping_stream(hipStream_t *out, const hipStream_t *others
     return hipSuccess;
 }
 
+// the side streams of VPT_OPTION_SPLIT_STREAMS = r->split, created (and picked: create_overlapping_stream) when the option is set or, for
+// the library's default, by the first pass that wants them
+int ensure_split_streams(vpt_renderer *r) {
+    if (r->split < 2 || (r->side[r->split - 2] && r->ev_fork)) return VPT_OK;
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    if (!r->ev_fork) HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i + 1 < r->split; i++) if (!r->side[i]) {
+        hipStream_t others[VPT_MAX_SPLIT] = { r->ctx->stream };      // the context's stream and the side streams there are
+        for (int k = 0; k < VPT_MAX_SPLIT - 1; k++) others[1 + k] = r->side[k];
+        HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+        HIP_TRY(create_overlapping_stream(&r->side[i], others, VPT_MAX_SPLIT));
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_join[i], hipEventDisableTiming));
+    }
+    r->main_dirty = true;
+    return VPT_OK;
+}
 // the side stream's work happens-before everything enqueued on the context's stream from here on
 int join_side(vpt_renderer *r) {
     if (!r || !r->side_busy) return VPT_OK;
@@ -725,35 +772,56 @@ int join_side(vpt_renderer *r) {
     r->side_busy = false; r->main_dirty = true;
     return VPT_OK;
 }
-// classifies the tiles for `mvp_inverse` (see classify_tiles) and puts the lists on the device: HIT tiles first, then MISS tiles
+// classifies the tiles for `mvp_inverse` (see classify_tiles) and puts the lists on the device: HIT tiles first, then MISS tiles.
+// Host cost per call (1080p: 8 160 tiles): ~60 us of classification + one asynchronous 32 KB upload from pinned memory, no host wait;
+// nothing at all when the lists on the device already describe this matrix and geometry.
 int classes_build(vpt_renderer *r, const float *mvp_inverse) {
-    r->cls.valid = false;
+    TileClasses &c = r->cls;
+    c.valid = false;
+    const int geom[6] = { r->W, r->H, r->local_h, r->G, r->g, r->R };
+    if (c.built && c.list && memcmp(c.built_mvp, mvp_inverse, sizeof(c.built_mvp)) == 0 && memcmp(c.built_geom, geom, sizeof(geom)) == 0) {
+        memmove(c.mvp, mvp_inverse, sizeof(c.mvp));
+        c.valid = true;                                         // (n_hit / n_miss / the device lists are those of the last build)
+        return VPT_OK;
+    }
     std::vector<uint8_t> cls; int tx, ty;
     classify_tiles(r->W, r->H, r->local_h, r->G, r->g, r->R, mvp_inverse, cls, &tx, &ty);
     if (tx != r->tiles_x || ty != r->tiles_y || tx > 0xffff || ty > 0xffff) return VPT_OK;
-    std::vector<uint32_t> list(cls.size());
+    const int n = (int)cls.size(), s = c.stage_next;
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    if (c.staging_capacity[s] < n) {
+        if (c.staged[s]) HIP_TRY(hipEventSynchronize(c.staged[s]));
+        if (c.staging[s]) { HIP_TRY(hipHostFree(c.staging[s])); c.staging[s] = nullptr; }
+        HIP_TRY(hipHostMalloc((void **)&c.staging[s], (size_t)n * sizeof(uint32_t), hipHostMallocDefault));
+        c.staging_capacity[s] = n;
+    }
+    if (!c.staged[s]) HIP_TRY(hipEventCreateWithFlags(&c.staged[s], hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(c.staged[s]));            // the copy out of this buffer two builds ago: long done (no wait in practice)
+    uint32_t *list = c.staging[s];
     int nh = 0, nm = 0;
     for (int pass = 0; pass < 2; pass++)
         for (int y = 0; y < ty; y++) for (int x = 0; x < tx; x++)
             if ((int)cls[(size_t)y * tx + x] == pass) { list[(size_t)nh + nm] = (uint32_t)x | ((uint32_t)y << 16); (pass ? nm : nh)++; }
     VPT_TRY(join_side(r));                                      // passes in flight read the old lists
-    if (r->cls.capacity < (int)list.size()) {
+    if (c.capacity < n) {
         HIP_TRY(hipStreamSynchronize(r->ctx->stream));
-        if (r->cls.list) { HIP_TRY(hipFree(r->cls.list)); r->cls.list = nullptr; }
-        HIP_TRY(hipMalloc(&r->cls.list, list.size() * sizeof(uint32_t)));
-        r->cls.capacity = (int)list.size();
+        if (c.list) { HIP_TRY(hipFree(c.list)); c.list = nullptr; }
+        HIP_TRY(hipMalloc(&c.list, (size_t)n * sizeof(uint32_t)));
+        c.capacity = n;
     }
-    if (!r->cls.violations) {
-        HIP_TRY(hipMalloc(&r->cls.violations, sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(r->cls.violations, 0, sizeof(unsigned long long), r->ctx->stream));
+    if (!c.violations) {       // [0]: VPT_OPTION_VERIFY_TILE_CLASSES
+        HIP_TRY(hipMalloc(&c.violations, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(c.violations, 0, 16 * sizeof(unsigned long long), r->ctx->stream));
     }
-    // (the lists travel on the context's stream, behind the passes that read the old ones)
-    HIP_TRY(hipMemcpyAsync(r->cls.list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, r->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(r->ctx->stream));              // `list` is pageable host memory about to go out of scope
+    // (the lists travel on the context's stream, behind the passes that read the old ones; the side streams pick them up at the next fork)
+    HIP_TRY(hipMemcpyAsync(c.list, list, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, r->ctx->stream));
+    HIP_TRY(hipEventRecord(c.staged[s], r->ctx->stream));
+    c.stage_next = s ^ 1;
     r->main_dirty = true;
-    r->cls.n_hit = nh; r->cls.n_miss = nm;
-    memcpy(r->cls.mvp, mvp_inverse, sizeof(r->cls.mvp));
-    r->cls.valid = true;
+    c.n_hit = nh; c.n_miss = nm;
+    memmove(c.mvp, mvp_inverse, sizeof(c.mvp));
+    memcpy(c.built_mvp, mvp_inverse, sizeof(c.built_mvp)); memcpy(c.built_geom, geom, sizeof(geom)); c.built = true;
+    c.valid = true;
     return VPT_OK;
 }
 // ---------------------------------------------------------------------------------------------
@@ -822,6 +890,7 @@ extern "C" int vpt_renderer_read_frame_slot(vpt_renderer *r, int slot, void *dst
 }
 extern "C" int vpt_renderer_frame_ring_device(vpt_renderer *r, void **ptr, size_t *slot_bytes) {
     if (!r || !ptr || !slot_bytes) return fail(VPT_ERR_INVALID, "null argument");
+    VPT_TRY(join_side(r));                                   // (whoever gets the address works on the context's stream: the ring's writers come first)
     *ptr = r->frame_ring; *slot_bytes = (size_t)r->W * r->local_h * 8;
     return VPT_OK;
 }
@@ -843,7 +912,7 @@ extern "C" int vpt_renderer_join(vpt_renderer *r) {
 }
 extern "C" int vpt_renderer_set_render_target(vpt_renderer *r, void *ptr, size_t nbytes) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
-    if (!r->split_callers) VPT_TRY(join_side(r));            // (launches in flight carry their target in their arguments)
+    VPT_TRY(join_side(r));                                   // (launches in flight carry their target in their arguments)
     size_t need = (size_t)r->W * r->local_h * 8;
     if (ptr && nbytes < need) return fail(VPT_ERR_INVALID, "render target too small: %zu < %zu", nbytes, need);
     r->render_target = (uint2 *)ptr; r->target_is_callers = ptr != nullptr;
@@ -879,30 +948,15 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
             if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_SPLIT_STREAMS: the DOS renderer's slices depend on each other across pixels");
             if (value < 1 || value > VPT_MAX_SPLIT) return fail(VPT_ERR_INVALID, "VPT_OPTION_SPLIT_STREAMS: 1 .. %d", VPT_MAX_SPLIT);
             VPT_TRY(join_side(r));
-            HIP_TRY(hipSetDevice(r->ctx->device));
-            if (value >= 2 && !r->ev_fork) HIP_TRY(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
-            for (int i = 0; i + 1 < value; i++) if (!r->side[i]) {
-                hipStream_t others[VPT_MAX_SPLIT] = { r->ctx->stream };      // the context's stream and the side streams there are
-                for (int k = 0; k < VPT_MAX_SPLIT - 1; k++) others[1 + k] = r->side[k];
-                HIP_TRY(hipStreamSynchronize(r->ctx->stream));
-                HIP_TRY(create_overlapping_stream(&r->side[i], others, VPT_MAX_SPLIT));
-                HIP_TRY(hipEventCreateWithFlags(&r->ev_join[i], hipEventDisableTiming));
-            }
-            r->split = value; return VPT_OK;
-        case VPT_OPTION_SPLIT_CALLER_TARGETS:
-            VPT_TRY(join_side(r));
-            r->split_callers = value != 0; return VPT_OK;
+            r->split = value;
+            return ensure_split_streams(r);
         case VPT_OPTION_FAST_MATH:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_FAST_MATH: only the MCM renderer has a fast-arithmetic variant");
             if ((value != 0) != (r->fast_math != 0)) VPT_TRY(mcm_materialize(r));   // MISS-tile positions in the arithmetic that produced the directions
             r->fast_math = value != 0; return VPT_OK;
         case VPT_OPTION_TILE_CLASSES:
             if (r->kind == VPT_RENDERER_DOS || r->kind == VPT_RENDERER_LAO) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_TILE_CLASSES: not an option of the DOS / LAO renderers");
-            r->cls.enabled = value != 0; return VPT_OK;
-        case VPT_OPTION_HIT_KERNEL_FORM:
-            if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_HIT_KERNEL_FORM: an MCM option");
-            if (value < 0 || value > 2) return fail(VPT_ERR_INVALID, "VPT_OPTION_HIT_KERNEL_FORM: 0 (automatic), 1 or 2");
-            r->hit_form = value; return VPT_OK;
+            r->cls.enabled = value != 0; r->cls.one_stream = value == 2; return VPT_OK;
         case VPT_OPTION_COLUMN_RECORDS:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_COLUMN_RECORDS: an MCM option");
             VPT_TRY(join_side(r));

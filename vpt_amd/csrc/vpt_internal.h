@@ -75,10 +75,16 @@ struct vpt_volume {
 #define VPT_COMPLETE_DESTS 40
 struct TileClasses {
     bool enabled, verify;          // VPT_OPTION_TILE_CLASSES (default on), VPT_OPTION_VERIFY_TILE_CLASSES
+    bool one_stream;               // VPT_OPTION_TILE_CLASSES = 2: the MCM class kernels also where they must follow each other on one stream (each alone on the chip: measurements)
     bool valid;                    // the lists describe `mvp` for the present geometry, and every pass since that reset used it
     float mvp[16];
     uint32_t *list; int capacity;  // device: n_hit HIT tiles, then n_miss MISS tiles, each tx | ty << 16
     int n_hit, n_miss;
+    // what the lists on the device were built for: a reset with the same matrix and geometry (the interactive case: a transfer function or a
+    // parameter changed, the camera did not) re-uses them — no classification, no upload (classes_build)
+    bool built; float built_mvp[16]; int built_geom[6];
+    // uploads go through two pinned staging buffers in turn, no host wait: staged[i] = the copy out of staging[i] has been enqueued and completes
+    uint32_t *staging[2]; int staging_capacity[2]; hipEvent_t staged[2]; int stage_next;
     bool stale, stale_fast;        // MISS tiles' position / transmittance arrays are behind; the pass that left them ran the fast variant
     unsigned long long *violations;
     // the accumulating ray marchers (MIP, EAM, ISO, MCS, Depth): see marcher_track
@@ -124,7 +130,7 @@ struct vpt_renderer {
     // of one overlap the body of the others.  Every other entry point joins the side streams into the context's stream first.
     bool target_is_callers;        // render_target was set by vpt_renderer_set_render_target (not by the gather pipeline)
     bool no_split;                 // set while a frame sequence is being captured into a hipGraph (one stream only)
-    bool split_callers;            // VPT_OPTION_SPLIT_CALLER_TARGETS: such passes are split too, the caller joins (vpt_renderer_join)
+    bool bucket_call;              // inside vpt_renderer_play_into*: the passes into the caller's bucket may use every stream, the call joins them before it returns
     int last_ranges;               // how many tile-row ranges (streams) the last sampling launch used
     hipEvent_t *stop_events;       // gather pipeline: event i is attached to range i's launch (hipExtLaunchKernel stop event: the
     bool stop_used;                // dispatch packet's own completion signal, no barrier packet behind the kernel)
@@ -139,7 +145,7 @@ struct vpt_renderer {
     struct vpt_tonemapper *tm_owner; bool tm_valid; const uint8_t *tm_table; uint32_t *tm_out; int tm_mode;
     uint64_t bucket_launches;      // buckets of frames run by k_mcm_bucket_* so far (vpt_renderer_bucket_launches)
     bool bucket_kernel;            // VPT_OPTION_BUCKET_KERNEL: vpt_renderer_play_into runs a bucket's frames by one launch per tile class
-    int hit_form;                  // VPT_OPTION_HIT_KERNEL_FORM: 0 = by the number of HIT tiles, 1 = k_mcm_integrate, 2 = k_mcm_integrate_early
+    int hit_form;                  // VPT_HIT_KERNEL_FORM in the environment at creation (A/B and tests): 0 = by the number of HIT tiles, 1 = k_mcm_integrate, 2 = k_mcm_integrate_early
     int column_records;            // VPT_OPTION_COLUMN_RECORDS: 0 = bricks, 1 = column records, 2 (default) = records where the bricks exceed VPT_RECORDS_AUTO_BYTES
     unsigned long long *samples;   // device counter (MIP/EAM/MCS)
     uint64_t samples_host;         // analytic part (MCM)
@@ -186,6 +192,7 @@ static inline size_t frame_elem(int kind) {
 // ---------------------------------------------------------------------------------------------
 // shared host functions (vpt_core.hip unless noted)
 // ---------------------------------------------------------------------------------------------
+int ensure_split_streams(vpt_renderer *r);          // creates the side streams r->split asks for, if they do not exist yet
 int join_side(vpt_renderer *r);                     // the side streams' work happens-before everything enqueued on the context's stream from here on
 int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, PassArgs *a);
 int volume_records(vpt_volume *v);                  // builds the column records of a finalized one-channel byte volume if they are not current
@@ -218,6 +225,11 @@ int mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar *v, int count,
                const uint8_t *display_table);
 int launch_fused(vpt_renderer *r, const PassArgs &a);               // vpt_render.hip: the fused render() launch of the renderer's kind
 
+struct BucketCall {              // scope of a vpt_renderer_play_into* call (vpt_renderer.bucket_call)
+    vpt_renderer *r;
+    explicit BucketCall(vpt_renderer *r_) : r(r_) { r->bucket_call = true; }
+    ~BucketCall() { r->bucket_call = false; }
+};
 // frame sequences (vpt_render.hip)
 int play_args(vpt_renderer *r, const vpt_uniforms *base, int count, PassArgs *a);
 int play_upload_table(vpt_renderer *r, const float *vars, int count, PassArgs *a);
@@ -261,10 +273,11 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     const bool wave = wave_blocks(r);
     const unsigned xmul = wave ? 4u : 1u;
     const dim3 block(wave ? 64u : (unsigned)VPT_BLOCK);
-    const bool split = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers);
+    const bool split = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->bucket_call);
+    if (split) VPT_TRY(ensure_split_streams(r));
     // (a frame rendered into caller memory — vpt_renderer_set_render_target — is consumed by work the caller enqueues on the
     // context's stream right behind it: such passes stay on that stream unless the caller has taken the join upon itself
-    // (VPT_OPTION_SPLIT_CALLER_TARGETS + vpt_renderer_join).  The gather pipeline waits for every range itself.)
+    // (vpt_renderer_play_into*: one join per bucket of frames, at the end of the call).  The gather pipeline waits for every range itself.)
     if (r->cls.list_now) {
         // the HIT tiles only (marcher_track): K equal parts of the list on the K streams
         if (r->side_busy && r->last_layout != 1) VPT_TRY(join_side(r));

@@ -105,6 +105,39 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
 // that both kinds fly together (a wave-event of a HIT tile is a chain of dependent latencies: -1 memory latency per event), and
 // the EARLY event loops below put the out-of-cube lanes' path end between the two.  The second phase tests an opaque copy of the
 // predicate, or the compiler would thread the phases back into one branch.
+// ---- instrumented build (make EXTRA=-DVPT_EVENT_TIMING; tools/r04_event_timing.py): a wave clock read at wave-uniform points of the event
+// loop of k_mcm_integrate.  Each mark first waits for the counters it names (so a phase ends when its results are there) and pins the values
+// the phase produced (so the compiler cannot move the phase's arithmetic behind the mark); the 100 MHz wall clock (s_memrealtime) is summed
+// per phase and wave; every wave adds its sums to ITS OWN 128-byte slot of the timing buffer (PassArgs.violations in such a build:
+// [wave of the launch][16]; same-address atomics would serialise at ~12 ns each and stall the memory pipe they measure), the host sums.
+// Reading the clock is a scalar memory operation whose round trip lands in the phase that follows the mark: slot 7 holds one extra mark per
+// event (two reads back to back), which the tool subtracts from every phase.
+// The marks serialise what the shipped kernel overlaps (the wheel draw under the sample's flight, ...): the instrumented kernel is a few
+// per cent slower, and its phases are an upper bound of the shipped kernel's.
+#ifdef VPT_EVENT_TIMING
+#define VPT_TIMING_WAVES 16384
+struct EventClock { unsigned long long prev, start; unsigned long long acc[8]; };
+VPT_DEV void ev_start(EventClock &c) { for (int i = 0; i < 8; i++) c.acc[i] = 0ull; c.prev = wall_clock64(); c.start = c.prev; }
+#define EV_MARK(c, slot, WAIT) do { asm volatile(WAIT ::: "memory"); const unsigned long long n_ = wall_clock64(); (c).acc[slot] += n_ - (c).prev; (c).prev = n_; } while (0)
+#define EV_PIN3(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z))
+VPT_DEV void ev_flush(const EventClock &c, unsigned long long *out) {
+    if (((int)threadIdx.x & 63) == 0 && out) {
+        unsigned long long *slot = out + (((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) & (VPT_TIMING_WAVES - 1)) * 16;
+        for (int i = 0; i < 8; i++) slot[i] += c.acc[i];
+        slot[8] += 1ull;
+        slot[9] = c.start; slot[10] = c.prev;                 // this launch's wave: first and last clock read (absolute)
+    }
+}
+#define EV_PARAM , EventClock &evc
+#define EV_ARG , evc
+#define EV_LOCAL EventClock evc; ev_start(evc);
+#else
+#define EV_MARK(c, slot, WAIT) do { } while (0)
+#define EV_PIN3(v) do { } while (0)
+#define EV_PARAM
+#define EV_ARG
+#define EV_LOCAL
+#endif
 struct SampleLoads { uint32_t aw; uint64_t w0, w1; float f0, f1, f2; uint32_t atlas; };
 template <int V>
 VPT_DEV SampleLoads mcm_sample_issue(const PassArgs &a, const LdsTables &t, f3 p, bool oob) {
@@ -149,17 +182,28 @@ VPT_DEV float4 mcm_sample(const PassArgs &a, const LdsTables &t, f3 p, bool oob)
     return vs;
 }
 template <int V>
-VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
+VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py EV_PARAM) {
     const f3 from0 = unproject_near(px, py, a);
 
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    EV_MARK(evc, 5, "s_waitcnt vmcnt(0) lgkmcnt(0)");                                        // prologue: state load, LDS staging, seed
     for (uint32_t s = 0u; s < a.steps; s++) {
+        EV_MARK(evc, 7, "");                                                                   // calibration: the cost of a mark itself
         float dist = random_exponential(state, a.inv_extinction);
         ph.position = madd3(ph.position, dist, ph.direction);
         f3 q = ph.position;
         // any(greaterThan(pos, 1)) || any(lessThan(pos, 0)), NaN components compare false
         bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+#ifdef VPT_EVENT_TIMING
+        EV_PIN3(q); EV_MARK(evc, 0, "");                                                      // free path: PCG, log, move, bounds test
+        const SampleLoads ld_ = mcm_sample_issue<V>(a, t, q, oob);
+        EV_MARK(evc, 1, "s_waitcnt lgkmcnt(0)");                                              // filter cell, LDS address tables, loads issued
+        EV_MARK(evc, 2, "s_waitcnt vmcnt(0)");                                                // the loads' flight (atlas dword | brick windows)
+        float4 vs = mcm_sample_finish<V>(a, t, ld_);
+        EV_MARK(evc, 3, "s_waitcnt lgkmcnt(0)");                                              // blend + transfer function (LDS)
+#else
         float4 vs = mcm_sample<V>(a, t, q, oob);
+#endif
         float p_null = 1.0f - vs.w;
         float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
         float p_abs = 1.0f - p_null - p_scat;
@@ -178,6 +222,7 @@ VPT_DEV void mcm_events(const PassArgs &a, const LdsTables &t, Photon &ph, float
             ph.direction = sample_hg(state, a.anisotropy, ph.direction);
             ph.bounces++;
         }
+        EV_PIN3(ph.position); EV_PIN3(ph.direction); EV_MARK(evc, 4, "");                     // wheel, probabilities, path end | scattering
     }
 }
 // The same events with the out-of-cube lanes' path end (deposit + resetPhoton: they need the random stream only, and whether a
@@ -301,18 +346,29 @@ VPT_DEV void fast_path_end(const PassArgs &a, const FastPixel &c, uint32_t &stat
     }
 }
 template <int V>
-VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py) {
+VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, float px, float py EV_PARAM) {
     const FastPixel c = fast_pixel(a, px, py);
     // -ln(u * 2^-32) / extinction = (log2(u) - 32) * ld
     const float ld = -0.6931471805599453f * a.inv_extinction, ld32 = -32.0f * ld;
 
     uint32_t state = hash3(__float_as_uint(ndc_to_uv(px)), __float_as_uint(ndc_to_uv(py)), __float_as_uint(a.seed));
+    EV_MARK(evc, 5, "s_waitcnt vmcnt(0) lgkmcnt(0)");
     for (uint32_t s = 0u; s < a.steps; s++) {
+        EV_MARK(evc, 7, "");
         float dist = fmaf(hw_log2(pcg_float(state)), ld, ld32);
         ph.position = madd3(ph.position, dist, ph.direction);
         f3 q = ph.position;
         bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+#ifdef VPT_EVENT_TIMING
+        EV_PIN3(q); EV_MARK(evc, 0, "");
+        const SampleLoads ld_ = mcm_sample_issue<V>(a, t, q, oob);
+        EV_MARK(evc, 1, "s_waitcnt lgkmcnt(0)");
+        EV_MARK(evc, 2, "s_waitcnt vmcnt(0)");
+        float4 vs = mcm_sample_finish<V>(a, t, ld_);
+        EV_MARK(evc, 3, "s_waitcnt lgkmcnt(0)");
+#else
         float4 vs = mcm_sample<V>(a, t, q, oob);
+#endif
         float p_null = 1.0f - vs.w;
         float p_scat = (ph.bounces >= a.max_bounces) ? 0.0f : vs.w * vmax(vmax(vs.x, vs.y), vs.z);
         float p_abs = 1.0f - p_null - p_scat;
@@ -329,6 +385,7 @@ VPT_DEV void mcm_events_fast(const PassArgs &a, const LdsTables &t, Photon &ph, 
             ph.direction = sample_hg_fast(state, a.anisotropy, ph.direction);
             ph.bounces++;
         }
+        EV_PIN3(ph.position); EV_PIN3(ph.direction); EV_MARK(evc, 4, "");
     }
 }
 template <int V>
@@ -428,7 +485,8 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
         int l = ty * VPT_TILE + (w >> 1) * 8 + (lane >> 3);
         int j = global_row(a.pm, l);
         if (i < a.pm.W && l < a.pm.local_h && j < a.pm.H) {
-            mcm_events<V>(a, t, ph, ndc_col(a.pm, i), ndc_row(a.pm, j));
+            EV_LOCAL
+            mcm_events<V>(a, t, ph, ndc_col(a.pm, i), ndc_row(a.pm, j) EV_ARG);
             photon_store(a, (int)kc, ph);
             if (FUSE_RENDER)
                 a.render[(size_t)l * a.pm.W + i] = pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f);
@@ -445,6 +503,9 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
 template <bool FUSE_RENDER, int V>
 __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(VPT_MCM_WAVES, 8))) k_mcm_integrate(PassArgs a) {
+#ifdef VPT_EVENT_TIMING
+    EventClock evc; ev_start(evc);
+#endif
     apply_frame_table(a);
     // the photon state (4 x dwordx4 per lane, one contiguous 1 KiB segment per wave and array) does not depend on the LDS
     // image: its loads are issued first, so they fly while the workgroup stages the tables and hashes its seed
@@ -456,10 +517,14 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     if (!p.valid) return;
     float px = ndc_col(a.pm, p.i), py = ndc_row(a.pm, p.j);
     Photon ph = photon_unpack(st);
-    if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
-    else mcm_events<V>(a, t, ph, px, py);
+    if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py EV_ARG);
+    else mcm_events<V>(a, t, ph, px, py EV_ARG);
     photon_store(a, p.k, ph);
     if (FUSE_RENDER) store_frame(a, p, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
+#ifdef VPT_EVENT_TIMING
+    EV_MARK(evc, 6, "s_waitcnt vmcnt(0)");                                                    // epilogue: state and frame stores
+    ev_flush(evc, a.violations);
+#endif
 }
 // the HIT-tile kernel with the early path end (mcm_events_early), compiled for 5 waves per SIMD: selected by the library for tile lists
 // short enough to be resident at once at that occupancy (shards)
@@ -621,8 +686,9 @@ VPT_DEV void mcm_multi_body(PassArgs &a, uint32_t npasses, uint2 *ring, uint32_t
     uint32_t base = a.frame_base;
     for (uint32_t f = 0; f < npasses; f++) {
         a.seed = a.frame_table[(base + f) & a.frame_mask].seed;
-        if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
-        else mcm_events<V>(a, t, ph, px, py);
+        EV_LOCAL
+        if (V & VPT_V_FAST) mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py EV_ARG);
+        else mcm_events<V>(a, t, ph, px, py EV_ARG);
         // the unfused sequence stores the counters as floats between passes and re-reads them with uint(w + 0.5):
         // identical for every count below 2^24
         // VPT_PLAY_FRAMES: every pass's frame is written (slot f of the frame ring), as `npasses` render() calls would show them
@@ -673,10 +739,10 @@ k_mcm_bucket_hit(PassArgs a, FrameSeeds fs, uint32_t nframes, void *ring, uint32
         a.seed = fs.seed[f];
         if (V & VPT_V_FAST) {
             if (EARLY) mcm_events_fast_early<V & ~VPT_V_FAST>(a, t, ph, px, py);
-            else mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py);
+            else { EV_LOCAL mcm_events_fast<V & ~VPT_V_FAST>(a, t, ph, px, py EV_ARG); }
         } else {
             if (EARLY) mcm_events_early<V>(a, t, ph, px, py);
-            else mcm_events<V>(a, t, ph, px, py);
+            else { EV_LOCAL mcm_events<V>(a, t, ph, px, py EV_ARG); }
         }
         // (between two launches the counters travel as floats and come back through uint(w + 0.5): the identity below 2^24)
         bucket_store<DISPLAY>(a, ring, texel, pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));

@@ -10,6 +10,21 @@
 
 // ---- MCM passes over the tile classes ---------------------------------------------------------------------------------
 typedef void (*PassKernel)(PassArgs);
+#ifdef VPT_EVENT_TIMING
+#define VPT_TIMING_ARG(part, hit) do { if (hit) (part).violations = timing; } while (0)
+#else
+#define VPT_TIMING_ARG(part, hit) do { } while (0)
+#endif
+#ifdef VPT_EVENT_TIMING
+static unsigned long long *g_timing = nullptr;
+static unsigned long long *timing_buffer(vpt_renderer *r) {
+    if (!g_timing) {
+        if (hipMalloc(&g_timing, (size_t)VPT_TIMING_WAVES * 16 * sizeof(unsigned long long)) != hipSuccess) { g_timing = nullptr; return nullptr; }
+        hipMemsetAsync(g_timing, 0, (size_t)VPT_TIMING_WAVES * 16 * sizeof(unsigned long long), r->ctx->stream);
+    }
+    return g_timing;
+}
+#endif
 // the sampler variant of the tile-class kernels (LINEAR one-channel byte volumes): VPT_V_WIDE | VPT_V_FAST | VPT_V_REC
 static int class_variant(const vpt_renderer *r, const PassArgs &a) {
     return (variant_of(r) & VPT_V_WIDE) | (r->fast_math ? VPT_V_FAST : 0) | (a.vol.records ? VPT_V_REC : 0);
@@ -66,7 +81,7 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     const bool fast = r->fast_math != 0, check = r->cls.verify;
     PassKernel kh, km;
     // the HIT tiles: few enough to be resident at once at 5 waves per SIMD (a shard's share) -> the form with the early path end,
-    // whose pass is one wave per SIMD walking a chain of dependent latencies; else the 7-waves form (VPT_OPTION_HIT_KERNEL_FORM overrides)
+    // whose pass is one wave per SIMD walking a chain of dependent latencies; else the 7-waves form (VPT_HIT_KERNEL_FORM in the environment overrides)
     const bool early = r->hit_form == 2 || (r->hit_form == 0 && r->cls.n_hit <= 1280);
     kh = hit_kernel<FUSE>(class_variant(r, a), early);
     // the MISS tiles: the sample consumed after the path end (its gather flies under that arithmetic) — whole frame 80.8 -> 79.3-79.7 us
@@ -81,7 +96,7 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     if (lds_hit > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds_hit);
     if (lds_hit > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hit));
     int k = 1;
-    if (r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers)) k = r->split;
+    if (r->split >= 2 && !r->no_split && (!r->target_is_callers || r->bucket_call)) k = r->split;
     if (r->side_busy && r->last_layout != 1) VPT_TRY(join_side(r));      // the tile -> stream map changes: order the streams once
     r->last_layout = 1;
     struct Part { PassKernel kernel; const uint32_t *list; int n; size_t lds; };
@@ -89,6 +104,10 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     // (measured, 1080p headline frame, us per frame: HIT | MISS on two streams 81.0; HIT | MISS/2 | MISS/2 82.3-83.0; HIT/2 | HIT/2 | MISS
     // 82.7-84.1; four streams 93; one stream, HIT then MISS: 102.  Capping the HIT kernel's residency (dynamic LDS) to 2 / 3 / 4 / 5
     // workgroups per CU so that MISS waves always sit beside its waves: 99 / 91 / 83.4 / 82.2 against 81.6 uncapped — DESIGN.md section 5)
+#ifdef VPT_EVENT_TIMING
+    unsigned long long *const timing = timing_buffer(r);
+#endif
+    // (a frame the volume fills — no MISS tile at all — was tried with the HIT list in k parts on the k streams: 143.9 -> 143.7 us, nothing)
     const int hit_parts = r->cls.n_hit > 0 ? 1 : 0;
     const int miss_parts = std::max(1, k - hit_parts);
     for (int i = 0; i < hit_parts; i++) {
@@ -104,8 +123,22 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
         for (int i = 0; i < np; i++) {
             PassArgs part = a;
             part.pm.tile_list = parts[i].list; part.pm.list_n = parts[i].n; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
+            VPT_TIMING_ARG(part, i < hit_parts);
+            // profiling: the caller's pair (Timed) brackets both launches; the MISS-tile kernel gets the pair vpt_renderer_profile_side reads
+            hipEvent_t e1 = nullptr;
+            if (i >= hit_parts && i == np - 1 && r->timed_now) {
+                if (r->side_events_used == r->side_events.size()) {
+                    hipEvent_t a0, a1;
+                    if (hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess) r->side_events.push_back({ a0, a1 });
+                }
+                if (r->side_events_used < r->side_events.size()) {
+                    hipEventRecord(r->side_events[r->side_events_used].first, r->ctx->stream);
+                    e1 = r->side_events[r->side_events_used++].second;
+                }
+            }
             if (i + 1 == np) launch_range(parts[i].kernel, r, dim3((unsigned)parts[i].n), dim3(VPT_BLOCK), parts[i].lds, r->ctx->stream, part, 0);
             else hipLaunchKernelGGL(parts[i].kernel, dim3((unsigned)parts[i].n), dim3(VPT_BLOCK), parts[i].lds, r->ctx->stream, part);
+            if (e1) hipEventRecord(e1, r->ctx->stream);
         }
         r->last_ranges = 1;
     } else {
@@ -119,6 +152,7 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
         for (int i = np - 1; i >= 0; i--) {
             PassArgs part = a;
             part.pm.tile_list = parts[i].list; part.pm.list_n = parts[i].n; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
+            VPT_TIMING_ARG(part, i < hit_parts);
             // profiling: the context's stream is bracketed by the caller (Timed); the first side launch gets a pair of its own
             hipEvent_t e1 = nullptr;
             if (i == 1 && r->timed_now) {
@@ -147,7 +181,8 @@ typedef void (*BucketKernel)(PassArgs, FrameSeeds, uint32_t, void *, uint32_t);
 int mcm_bucket_ready(vpt_renderer *r, const PassArgs &a, bool *ready) {
     bool same = false;
     VPT_TRY(mcm_before_pass(r, a, &same));
-    const bool two_streams = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers);
+    const bool two_streams = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->bucket_call);
+    if (two_streams) VPT_TRY(ensure_split_streams(r));
     *ready = same && r->cls.enabled && mcm_classes_runnable(r, a) && two_streams && !r->cls.verify;
     return VPT_OK;
 }
@@ -246,9 +281,10 @@ static int launch_mcm_pass(vpt_renderer *r, const PassArgs &a) {
     // The two kernels of the classes pay on two streams (1080p headline frame 81 us against 99-106 for the general kernel; rank 3 of 8's
     // share 17.7 against 19.4) and lose when they have to follow each other on ONE stream (102; the share: 30.5 against 20.7): a pass
     // that must stay on the context's stream — no VPT_OPTION_SPLIT_STREAMS, a caller-owned render target without
-    // VPT_OPTION_SPLIT_CALLER_TARGETS, a sequence being captured — runs the general kernel.
-    const bool two_streams = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->split_callers);
-    if (same && r->cls.enabled && mcm_classes_runnable(r, a) && two_streams) return launch_mcm_classes<FUSE>(r, a);
+    // vpt_renderer_play_into*, a sequence being captured — runs the general kernel.
+    const bool two_streams = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->bucket_call);
+    if (two_streams) VPT_TRY(ensure_split_streams(r));
+    if (same && r->cls.enabled && mcm_classes_runnable(r, a) && (two_streams || r->cls.one_stream)) return launch_mcm_classes<FUSE>(r, a);
     VPT_TRY(mcm_materialize(r));
 #ifdef VPT_WITH_PERSISTENT_KERNELS
     if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) { LAUNCH_MCM_PERSIST(FUSE, r, a); return VPT_OK; }
@@ -322,3 +358,33 @@ int mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses, uint2 *ring)
     MULTI_CASES(0)
 #undef MULTI_CASES
 }
+
+#ifdef VPT_EVENT_TIMING
+// instrumented builds only (tools/r04_event_timing.py binds it by name): the HIT-tile kernel's phase clocks summed over its waves since the last
+// call, in 10 ns ticks — [0..4] per event: free path | cell + tables | load flight | blend + transfer function | decision + path end;
+// [5] prologue, [6] epilogue, [7] one calibration mark per event, [8] waves
+extern "C" VPT_API int vpt_probe_event_timing(vpt_renderer *r, uint64_t *out9) {
+    if (!r || !out9 || !g_timing) return fail(VPT_ERR_INVALID, "no timing buffer (run a classified pass first)");
+    VPT_TRY(join_side(r));
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    std::vector<unsigned long long> host((size_t)VPT_TIMING_WAVES * 16);
+    HIP_TRY(hipMemcpyAsync(host.data(), g_timing, host.size() * 8, hipMemcpyDeviceToHost, r->ctx->stream));
+    HIP_TRY(hipMemsetAsync(g_timing, 0, host.size() * 8, r->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    for (int k = 0; k < 9; k++) out9[k] = 0;
+    for (size_t w = 0; w < VPT_TIMING_WAVES; w++) for (int k = 0; k < 9; k++) out9[k] += host[w * 16 + k];
+    // the LAST launch's timeline: when its waves started and ended, relative to the first wave's start (10 ns ticks): out9[9 ..] =
+    // { waves, start p50, start p90, start max, end p10, end p50, end p90, end max }
+    std::vector<unsigned long long> st, en;
+    unsigned long long t0 = ~0ull;
+    for (size_t w = 0; w < VPT_TIMING_WAVES; w++) if (host[w * 16 + 8]) { st.push_back(host[w * 16 + 9]); en.push_back(host[w * 16 + 10]); t0 = std::min(t0, host[w * 16 + 9]); }
+    for (int k = 9; k < 17; k++) out9[k] = 0;
+    if (!st.empty()) {
+        std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+        const size_t n = st.size();
+        out9[9] = n; out9[10] = st[n / 2] - t0; out9[11] = st[n * 9 / 10] - t0; out9[12] = st[n - 1] - t0;
+        out9[13] = en[n / 10] - t0; out9[14] = en[n / 2] - t0; out9[15] = en[n * 9 / 10] - t0; out9[16] = en[n - 1] - t0;
+    }
+    return VPT_OK;
+}
+#endif

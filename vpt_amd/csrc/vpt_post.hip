@@ -225,6 +225,7 @@ extern "C" int vpt_renderer_play_into_display(vpt_renderer *r, vpt_tonemapper *t
     PassArgs a;
     VPT_TRY(play_args(r, base, count, &a));
     const FrameVar *v = (const FrameVar *)frame_vars;
+    BucketCall bucket_call{ r };
     int i0 = 0;
     while (r->kind == VPT_RENDERER_MCM && stride_bytes / 4 <= 0xffffffffull && i0 < count) {
         const int n = std::min(count - i0, VPT_BUCKET_FRAMES);
@@ -247,7 +248,7 @@ extern "C" int vpt_renderer_play_into_display(vpt_renderer *r, vpt_tonemapper *t
         HIP_TRY(hipMemcpyAsync((char *)first_target + (size_t)i * stride_bytes, t->out, need, hipMemcpyDeviceToDevice, r->ctx->stream));
     }
     HIP_TRY(hipGetLastError());
-    if (!r->split_callers) VPT_TRY(join_side(r));            // (with VPT_OPTION_SPLIT_CALLER_TARGETS the caller joins, once per bucket)
+    VPT_TRY(join_side(r));                                   // one join per bucket: the caller's collective comes next on the context's stream
     r->warmed = true;
     if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)base->steps * (uint64_t)count;
     return VPT_OK;
@@ -417,7 +418,7 @@ extern "C" int vpt_gather_create(vpt_renderer *r, const void *id128, int rank, i
     int rc = VPT_OK;
     hipError_t e;
     {   // the communication stream must overlap the streams the passes run on
-        { int jr = join_side(r); if (jr != VPT_OK) { delete g; return jr; } }
+        { int jr = ensure_split_streams(r); if (jr == VPT_OK) jr = join_side(r); if (jr != VPT_OK) { delete g; return jr; } }
         hipStream_t others[VPT_MAX_SPLIT] = { r->ctx->stream };
         for (int k = 0; k < VPT_MAX_SPLIT - 1; k++) others[1 + k] = r->side[k];
         hipStreamSynchronize(r->ctx->stream);

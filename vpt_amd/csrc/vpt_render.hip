@@ -324,12 +324,14 @@ extern "C" int vpt_renderer_play_into(vpt_renderer *r, const vpt_uniforms *base,
     if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "frame sequences are not defined for the DOS renderer: drive it slice by slice");
     const size_t need = (size_t)r->W * r->local_h * 8;
     if (stride_bytes < need) return fail(VPT_ERR_INVALID, "target stride too small: %zu < %zu", stride_bytes, need);
-    if (!r->split_callers) VPT_TRY(join_side(r));
     HIP_TRY(hipSetDevice(r->ctx->device));
     PassArgs a;
     VPT_TRY(play_args(r, base, count, &a));
     const FrameVar *v = (const FrameVar *)frame_vars;
     r->target_is_callers = true;
+    // the bucket's passes may use every stream of a split pass (MCM: the HIT | MISS kernels of the tile classes); ONE join at the end of the
+    // call puts all of them in front of whatever the caller enqueues on the context's stream next (the collective that moves the bucket)
+    BucketCall bucket_call{ r };
     int i0 = 0;
     // VPT_OPTION_BUCKET_KERNEL: up to VPT_BUCKET_FRAMES frames per launch of each tile class
     while (r->kind == VPT_RENDERER_MCM && r->bucket_kernel && stride_bytes % 8 == 0 && stride_bytes / 8 <= 0xffffffffull && i0 < count) {
@@ -352,6 +354,7 @@ extern "C" int vpt_renderer_play_into(vpt_renderer *r, const vpt_uniforms *base,
         VPT_TRY(launch_fused(r, f));
     }
     HIP_TRY(hipGetLastError());
+    VPT_TRY(join_side(r));
     r->warmed = true;
     if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)base->steps * (uint64_t)count;
     return VPT_OK;
