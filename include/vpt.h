@@ -409,6 +409,9 @@ VPT_API int vpt_gather_read_frame(vpt_gather *g, void *host_dst, size_t nbytes);
 VPT_API int vpt_probe_math(vpt_context *ctx, int which, const float *in, float *out, size_t n);
 /* samples texture(uVolume, p) -> transfer function at n positions (xyz triples); out = n RGBA float4 */
 VPT_API int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n);
+/* the same through the volume's boundary atlas for positions outside the cube (what the MCM kernels execute for out-of-cube events; positions
+ * inside go through the bricks): must equal vpt_probe_sample bit for bit in every volume format */
+VPT_API int vpt_probe_sample_boundary(vpt_renderer *r, const float *xyz, float *rgba, size_t n);
 /* The schedule of frame number `frame` of the gather pipeline as a pure host function (no GPU, no communicator needed): ring
  * buffer, event edges, render destination, RCCL operation.  vpt_gather_render / _play execute exactly this plan; exported so
  * that the multi-rank schedule can be checked without more than one GPU (tests/test_gather_schedule.py). */

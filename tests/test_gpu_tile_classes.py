@@ -11,7 +11,7 @@ import pytest
 
 import vpt_amd
 from vpt_amd import _native as N
-from vpt_amd.synthetic import colour_tf, ramp_tf, GoldenRatioRng
+from vpt_amd.synthetic import colour_tf, ramp_tf, sphere_volume, GoldenRatioRng
 
 from conftest import orbit_camera
 from test_gpu_parity import Scene, to_frame, assert_same_bits, MCM_BUFFERS, env_map
@@ -252,21 +252,131 @@ def test_frame_sequences_after_classified_passes(gpu_ctx, oracle, fast):
     sc.gvol.destroy()
 
 
-def test_classes_need_the_atlas_path(gpu_ctx, oracle):
-    """NEAREST filter, two-channel and float volumes, a switched-off atlas: k_mcm_miss has no sampler for them — such renderers keep
-    the general kernel (and stay bit-identical to the oracle: the parity suites run them)"""
-    sc = far_scene(gpu_ctx, oracle, filt="nearest")
+FORMATS = ["r8-nearest", "rg8-linear", "rg8-nearest", "r32f-linear", "r32f-nearest", "rg32f-linear", "rg32f-nearest"]
+
+
+def format_scene(gpu_ctx, oracle, fmt, w=208, h=144):
+    """far_scene with a volume of another texel format / filter (Volume.js:115-125 setFilter; RAWReader.js:36-38 and the BVP manifests' formats):
+    two channels feed a 2-D transfer function, float texels reach outside [0, 1]"""
+    kind, filt = fmt.split("-")
+    rng = np.random.default_rng(7)
+    base = sphere_volume(0, noise=35.0, dims=(20, 26, 22))
+    if kind == "r8":
+        vol = base
+    elif kind == "rg8":
+        vol = np.stack([base, rng.integers(0, 256, size=base.shape, dtype=np.uint8)], axis=-1)
+    else:
+        f = (base.astype(np.float32) / np.float32(255) * np.float32(1.4) - np.float32(0.2)).astype(np.float32)
+        vol = f if kind == "r32f" else np.stack([f, rng.uniform(-0.2, 1.2, size=base.shape).astype(np.float32)], axis=-1)
+    tf = rng.integers(0, 256, size=(7, 24, 4), dtype=np.uint8) if vol.ndim == 4 else colour_tf(48, 1)
+    sc = Scene.__new__(Scene)
+    sc.vol, sc.w, sc.h, sc.tf, sc.env = vol, w, h, tf, None
+    sc.osc = oracle.OracleScene(vol, filt, tf=tf)
+    sc.gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, filt)
+    sc.camera = orbit_camera(w / h, 0.7, -0.3, 3.2)
+    from vpt_amd.scene import Transform, Node, mvp_inverse_matrix
+    sc.transform = Transform(Node())
+    sc.m = mvp_inverse_matrix(sc.camera, sc.transform)
+    sc.ctx = gpu_ctx
+    return sc
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+@pytest.mark.parametrize("fast", [0, 1])
+def test_classes_for_every_volume_format(gpu_ctx, oracle, fmt, fast):
+    """round 4: NEAREST filter, two-channel and float volumes run the tile classes too — the MISS tiles through k_mcm_miss's sampler of the
+    volume's boundary atlas in that format (one dword or one float4 per cell and channel), the HIT tiles through the general kernel of the
+    volume's variant from a tile list.  Classes on (the default) = classes off, bit for bit, both arithmetic variants; contract arithmetic =
+    the oracle; no event of a MISS tile inside the cube"""
+    sc = format_scene(gpu_ctx, oracle, fmt)
+
+    def run(classes):
+        r = sc.renderer('mcm')
+        r.set_option(N.OPTION_TILE_CLASSES, classes)
+        r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
+        r.set_option(N.OPTION_FAST_MATH, fast)
+        r.extinction = 4; r.steps = 5; r.anisotropy = 0.25
+        r.reset()
+        if classes:
+            hit, miss, _ = r.tile_classes()
+            assert miss > hit > 0, (hit, miss)
+            r.set_profiling(1)
+        outs = []
+        for k in range(5):
+            r.render()
+            if k in (0, 4):
+                outs += all_buffers(r)
+        if classes:
+            assert r.profile_side()[1] == 5, "the MISS-tile kernel did not run"         # five passes put a launch on the side stream
+            r.set_profiling(False)
+        assert r.tile_classes()[2] == 0
+        r.destroy()
+        return outs
+
+    a, b = run(0), run(1)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert_same_bits(y, x, "%s: tile classes on vs off, output %d" % (fmt, k))
+    if not fast:
+        r = sc.renderer('mcm')
+        r.extinction = 4; r.steps = 5; r.anisotropy = 0.25
+        o = oracle.OracleRenderer('mcm', sc.osc, sc.w, sc.h)
+        r.reset()
+        o.reset(oracle.make_frame(sc.w, sc.h, sc.m, seed=np.float32(GoldenRatioRng()())))
+        for _ in range(3):
+            r.render()
+            o.render(to_frame(oracle, sc, r._u))
+        for bb, st in zip(MCM_BUFFERS, o.state):
+            assert_same_bits(r.read(bb), st.reshape(sc.h, sc.w, 4), "%s: state buffer %d against the oracle" % (fmt, bb))
+        r.destroy()
+    sc.gvol.destroy()
+
+
+@pytest.mark.parametrize("fmt", ["r8-linear"] + FORMATS)
+def test_the_boundary_atlas_gives_the_bricks_samples_in_every_format(gpu_ctx, oracle, fmt):
+    """the sample a MISS tile executes and discards is not visible in any buffer — so the atlas sampler itself is probed: texture(uVolume, p) ->
+    transfer function at 40 000 positions outside the cube (one, two and three coordinates out of range, far away, on the faces' edges, +-inf)
+    through the boundary atlas against the same positions through the bricks, bit for bit"""
+    sc = format_scene(gpu_ctx, oracle, fmt) if fmt != "r8-linear" else far_scene(gpu_ctx, oracle)
     r = sc.renderer('mcm')
-    r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
+    rng = np.random.default_rng(3)
+    p = rng.uniform(-0.6, 1.6, size=(40000, 3)).astype(np.float32)
+    out = ((p < 0) | (p > 1)).any(axis=1)
+    p = p[out]
+    p[:200] *= np.float32(40.0)                                  # far away
+    p[200:400, 0] = np.float32(1.0) + np.float32(1e-7)           # a hair beyond a face
+    p[400:500, 1] = np.inf; p[500:600, 2] = -np.inf
+    edge = rng.choice([0.0, 1.0, 0.5 / 22, 1 - 0.5 / 22], size=(300, 2)).astype(np.float32)
+    p[600:900, 1:] = edge                                        # on texel centres and face edges of the in-face axes
+    p[600:900, 0] = np.float32(1.25)
+    got, want = r.probe_sample_boundary(p), r.probe_sample(p)
+    assert_same_bits(got, want, "%s: atlas vs bricks at %d out-of-cube positions" % (fmt, len(p)))
+    r.destroy(); sc.gvol.destroy()
+
+
+def test_a_float_volume_with_non_finite_texels_keeps_the_general_kernel(gpu_ctx, oracle):
+    """lerp(t, t', 0) = fma(0, t' - t, t) is t only while t' - t is finite: a float volume holding inf / NaN / huge texels does not use its
+    boundary atlas (vpt_volume_finalize scans it), so nothing is classified away — and the images still equal the oracle's"""
+    base = sphere_volume(0, noise=35.0, dims=(16, 20, 18)).astype(np.float32) / np.float32(255)
+    base[0, 3, 4] = np.inf; base[15, 7, 2] = np.float32(3e38); base[5, 0, 9] = -np.inf
+    sc = format_scene(gpu_ctx, oracle, "r32f-linear")
+    sc.gvol.destroy()
+    sc.vol = base
+    sc.osc = oracle.OracleScene(base, "linear", tf=sc.tf)
+    sc.gvol = vpt_amd.Volume.from_array(gpu_ctx, base, "linear")
+    r = sc.renderer('mcm')
     r.extinction = 4; r.steps = 4
     o = oracle.OracleRenderer('mcm', sc.osc, sc.w, sc.h)
     r.reset()
     o.reset(oracle.make_frame(sc.w, sc.h, sc.m, seed=np.float32(GoldenRatioRng()())))
+    r.set_profiling(1)
     for _ in range(3):
         r.render()
         o.render(to_frame(oracle, sc, r._u))
-    for b, s in zip(MCM_BUFFERS, o.state):
-        assert_same_bits(r.read(b), s.reshape(sc.h, sc.w, 4), "state buffer %d" % b)
+    assert r.profile_side()[1] == 0                                      # no MISS-tile kernel ran: its sampler reads the atlas
+    with pytest.raises(vpt_amd.VptError):
+        r.probe_sample_boundary(np.float32([[1.5, 0.5, 0.5]]))
+    for bb, st in zip(MCM_BUFFERS, o.state):
+        assert_same_bits(r.read(bb), st.reshape(sc.h, sc.w, 4), "state buffer %d" % bb)
     r.destroy(); sc.gvol.destroy()
 
 

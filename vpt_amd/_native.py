@@ -51,7 +51,7 @@ SYMBOLS = [
     "vpt_gather_unique_id", "vpt_gather_create", "vpt_gather_destroy", "vpt_gather_render", "vpt_gather_play", "vpt_gather_set_root",
     "vpt_gather_synchronize",
     "vpt_gather_read_frame",
-    "vpt_probe_math", "vpt_probe_sample", "vpt_probe_stream_read", "vpt_probe_assemble_rows",
+    "vpt_probe_math", "vpt_probe_sample", "vpt_probe_sample_boundary", "vpt_probe_stream_read", "vpt_probe_assemble_rows",
     "vpt_tonemapper_create", "vpt_tonemapper_destroy", "vpt_tonemapper_resize", "vpt_tonemapper_set_source",
     "vpt_tonemapper_set_source_image", "vpt_tonemapper_render", "vpt_tonemapper_read", "vpt_tonemapper_rows",
     "vpt_tonemapper_output_device", "vpt_tonemapper_set_option",
@@ -162,7 +162,7 @@ def lib():
         "vpt_classify_tiles": [I, I, I, I, I, P, P, SZ, C.POINTER(I), C.POINTER(I)],
         "vpt_renderer_profile": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],
         "vpt_renderer_profile_side": [P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)],
-        "vpt_probe_math": [P, I, P, P, SZ], "vpt_probe_sample": [P, P, P, SZ], "vpt_probe_stream_read": [P, SZ, I, P], "vpt_probe_assemble_rows": [P, P, I, I, I, I, I, P],
+        "vpt_probe_math": [P, I, P, P, SZ], "vpt_probe_sample": [P, P, P, SZ], "vpt_probe_sample_boundary": [P, P, P, SZ], "vpt_probe_stream_read": [P, SZ, I, P], "vpt_probe_assemble_rows": [P, P, I, I, I, I, I, P],
         "vpt_tonemapper_create": [P, I, I, I, P], "vpt_tonemapper_destroy": [P], "vpt_tonemapper_resize": [P, I, I],
         "vpt_tonemapper_set_source": [P, P], "vpt_tonemapper_set_source_image": [P, P, I, I],
         "vpt_tonemapper_render": [P, C.POINTER(TonemapParams)], "vpt_tonemapper_read": [P, P, SZ],

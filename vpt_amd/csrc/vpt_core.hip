@@ -105,15 +105,17 @@ extern "C" int vpt_volume_create(vpt_context *c, int w, int h, int d, int format
     v->brick_bytes = (max_slot + 1) << slot_shift;
     hipError_t e = hipMalloc(&v->linear, (size_t)w * h * d * v->vox_bytes);
     if (e == hipSuccess) e = hipMalloc(&v->bricks, v->brick_bytes + 64);   // +64: the 8-byte tap windows end <= byte 125+7
-    if (e == hipSuccess && v->channels == 1 && !v->f32) {
+    if (e == hipSuccess) {
         // boundary atlas: six face images (axis x: ny x nz cells, y: nx x nz, z: nx x ny; low side, high side) with one common
-        // power-of-two row pitch and one common size, one dword per cell
+        // power-of-two row pitch and one common size, one dword (byte volumes) or one float4 (float volumes) per cell and channel
         int pitch = 1, shift = 0;
         while (pitch < std::max(w, h)) { pitch <<= 1; shift++; }
         v->atlas_shift = (uint32_t)shift;
         v->atlas_face = (uint32_t)pitch * (uint32_t)std::max(h, d);
-        v->atlas_dwords = 6 * (size_t)v->atlas_face;
+        v->atlas_dwords = 6 * (size_t)v->atlas_face * (size_t)v->channels * (v->f32 ? 4 : 1);
         e = hipMalloc(&v->atlas, v->atlas_dwords * 4);
+        v->atlas_ok = true;
+        if (e == hipSuccess && v->f32) e = hipMalloc(&v->atlas_flag, sizeof(uint32_t));
     }
     if (e != hipSuccess) {
         if (v->atlas) hipFree(v->atlas);
@@ -237,8 +239,21 @@ extern "C" int vpt_volume_finalize(vpt_volume *v) {
         hipLaunchKernelGGL(k_brickify, dim3((unsigned)(strips - fast), (unsigned)nby, (unsigned)nbz), dim3(128), 0, c->stream, v->linear, v->bricks, v->nx, v->ny, v->nz, v->channels, v->tabc, fast * VPT_BRICKIFY_RUN);
     if (v->atlas) {
         size_t cells = (size_t)v->ny * v->nz + (size_t)v->nx * v->nz + (size_t)v->nx * v->ny;
-        hipLaunchKernelGGL(k_build_atlas, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, v->linear, v->atlas, v->nx, v->ny, v->nz,
-                           v->atlas_face, v->atlas_shift);
+        if (v->f32) {
+            hipLaunchKernelGGL(k_build_atlas<float>, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, (const float *)v->linear, (void *)v->atlas,
+                               v->nx, v->ny, v->nz, v->channels, v->atlas_face, v->atlas_shift);
+            // (float texels: the atlas stands for the bricks only while every texel is finite and differences cannot overflow — one scan, one
+            // host wait per upload of a float volume)
+            uint32_t bad = 0;
+            HIP_TRY(hipMemsetAsync(v->atlas_flag, 0, sizeof(uint32_t), c->stream));
+            hipLaunchKernelGGL(k_scan_finite, dim3(2048), dim3(256), 0, c->stream, (const float *)v->linear, (size_t)v->nx * v->ny * v->nz * v->channels, v->atlas_flag);
+            HIP_TRY(hipMemcpyAsync(&bad, v->atlas_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            v->atlas_ok = bad == 0;
+        } else {
+            hipLaunchKernelGGL(k_build_atlas<uint8_t>, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)v->linear, (void *)v->atlas,
+                               v->nx, v->ny, v->nz, v->channels, v->atlas_face, v->atlas_shift);
+        }
     }
     HIP_TRY(hipGetLastError());
     v->dirty = false;
@@ -272,6 +287,7 @@ extern "C" int vpt_volume_destroy(vpt_volume *v) {
     if (v->linear) hipFree(v->linear);
     if (v->bricks) hipFree(v->bricks);
     if (v->atlas) hipFree(v->atlas);
+    if (v->atlas_flag) hipFree(v->atlas_flag);
     if (v->records) hipFree(v->records);
     if (v->rtab32) hipFree(v->rtab32);
     if (v->rtabc) hipFree(v->rtabc);
@@ -657,7 +673,7 @@ int make_args(vpt_renderer *r, const vpt_uniforms *u, bool need_volume, PassArgs
         a->vol.filter = v->filter;
         a->vol.channels = v->channels; a->vol.slot_shift = (v->f32 ? 9u : 7u) + (v->channels == 2 ? 1u : 0u);
         a->vol.elem_shift = v->f32 ? 2u : 0u;
-        a->vol.atlas = r->boundary_atlas ? v->atlas : nullptr;
+        a->vol.atlas = (r->boundary_atlas && v->atlas_ok) ? v->atlas : nullptr;
         a->vol.atlas_face = v->atlas_face; a->vol.atlas_shift = v->atlas_shift;
         if (renderer_uses_records(r)) {
             VPT_TRY(volume_records(v));
@@ -1072,13 +1088,14 @@ extern "C" int vpt_probe_math(vpt_context *c, int which, const float *in, float 
     if (e != hipSuccess) return fail(VPT_ERR_HIP, "probe: %s", hipGetErrorString(e));
     return VPT_OK;
 }
-extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n) {
+static int probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n, bool boundary) {
     if (!r || !xyz || !rgba) return fail(VPT_ERR_INVALID, "null argument");
     if (n == 0) return VPT_OK;
     vpt_context *c = r->ctx;
     HIP_TRY(hipSetDevice(c->device));
     PassArgs a;
     VPT_TRY(make_args(r, nullptr, true, &a));
+    if (boundary && !a.vol.atlas) return fail(VPT_ERR_UNSUPPORTED, "the volume's boundary atlas is not in use (switched off, or a float volume with non-finite texels)");
     float *din = nullptr; float4 *dout = nullptr;
     HIP_TRY(hipMalloc(&din, 3 * n * sizeof(float)));
     hipError_t e = hipMalloc(&dout, n * sizeof(float4));
@@ -1087,22 +1104,22 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
     if (e == hipSuccess) {
         dim3 grid((unsigned)((n + 255) / 256));
         switch (variant_of(r)) {
-            case 0: hipLaunchKernelGGL(k_probe_sample<0>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 1: hipLaunchKernelGGL(k_probe_sample<1>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 2: hipLaunchKernelGGL(k_probe_sample<2>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 3: hipLaunchKernelGGL(k_probe_sample<3>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 8: hipLaunchKernelGGL(k_probe_sample<8>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 9: hipLaunchKernelGGL(k_probe_sample<9>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 10: hipLaunchKernelGGL(k_probe_sample<10>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 11: hipLaunchKernelGGL(k_probe_sample<11>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 32: hipLaunchKernelGGL(k_probe_sample<32>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 33: hipLaunchKernelGGL(k_probe_sample<33>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 34: hipLaunchKernelGGL(k_probe_sample<34>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 35: hipLaunchKernelGGL(k_probe_sample<35>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 40: hipLaunchKernelGGL(k_probe_sample<40>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 41: hipLaunchKernelGGL(k_probe_sample<41>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            case 42: hipLaunchKernelGGL(k_probe_sample<42>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
-            default: hipLaunchKernelGGL(k_probe_sample<43>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 0: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<0>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<0>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 1: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<1>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<1>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 2: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<2>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<2>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 3: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<3>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<3>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 8: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<8>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<8>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 9: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<9>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<9>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 10: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<10>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<10>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 11: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<11>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<11>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 32: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<32>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<32>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 33: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<33>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<33>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 34: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<34>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<34>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 35: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<35>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<35>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 40: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<40>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<40>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 41: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<41>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<41>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            case 42: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<42>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<42>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
+            default: if (boundary) hipLaunchKernelGGL(k_probe_sample_boundary<43>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); else hipLaunchKernelGGL(k_probe_sample<43>, grid, dim3(VPT_BLOCK), lds_bytes(r), c->stream, a, din, dout, n); break;
         }
         e = hipGetLastError();
     }
@@ -1112,6 +1129,9 @@ extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, 
     if (e != hipSuccess) return fail(VPT_ERR_HIP, "probe: %s", hipGetErrorString(e));
     return VPT_OK;
 }
+
+extern "C" int vpt_probe_sample(vpt_renderer *r, const float *xyz, float *rgba, size_t n) { return probe_sample(r, xyz, rgba, n, false); }
+extern "C" int vpt_probe_sample_boundary(vpt_renderer *r, const float *xyz, float *rgba, size_t n) { return probe_sample(r, xyz, rgba, n, true); }
 
 extern "C" int vpt_probe_stream_read(vpt_context *c, size_t nbytes, int iterations, double *gb_per_s) {
     if (!c || !gb_per_s) return fail(VPT_ERR_INVALID, "null argument");

@@ -480,9 +480,49 @@ VPT_DEV uint32_t boundary_cell(const DevVolume &v, f3 p, float &out_fa, float &o
     out_fa = fa; out_fb = fb;
     return idx;
 }
+// the same cell per lane, without the wave-uniform fast paths, for either filter (the MISS-tile kernel of NEAREST / two-channel / float
+// volumes): NEAREST takes texel clamp(floor(s N)) of each in-face axis — what nearest_cell gives the brick sampler — and no weights
+template <bool NEAREST>
+VPT_DEV uint32_t boundary_cell_lane(const DevVolume &v, f3 p, float &out_fa, float &out_fb) {
+    const float fnx = v.fnx, fny = v.fny, fnz = v.fnz, hx = v.hx, hy = v.hy, hz = v.hz;
+    const bool ox = (p.x > 1.0f) || (p.x < 0.0f);
+    const bool oy = (p.y > 1.0f) || (p.y < 0.0f);
+    const bool oxy = ox || oy;
+    const float pa = ox ? p.y : p.x, pb = oxy ? p.z : p.y;
+    const float fna = ox ? fny : fnx, ha = ox ? hy : hx, fnb = oxy ? fnz : fny, hb = oxy ? hz : hy;
+    uint32_t a, b; float fa = 0.0f, fb = 0.0f;
+    if (NEAREST) { a = nearest_cell(pa, fna, ha); b = nearest_cell(pb, fnb, hb); }
+    else { linear_cell(pa, fna, ha, a, fa); linear_cell(pb, fnb, hb, b, fb); }
+    const float pk = ox ? p.x : (oy ? p.y : p.z);
+    const uint32_t f = (ox ? 0u : (oy ? 2u : 4u)) + (pk > 1.0f ? 1u : 0u);
+    out_fa = fa; out_fb = fb;
+    return f * v.atlas_face + ((b << v.atlas_shift) + a);
+}
 VPT_DEV float boundary_blend(uint32_t w, float fa, float fb) {
     float c00 = cvt_ubyte<0>(w), c10 = cvt_ubyte<1>(w), c01 = cvt_ubyte<2>(w), c11 = cvt_ubyte<3>(w);
     return lerpf(lerpf(c00, c10, fa), lerpf(c01, c11, fa), fb) * VPT_INV255;
+}
+// texture(uVolume, clamp(p)).rg through the boundary atlas for ANY volume format (V: VPT_V_NEAREST | VPT_V_RG | VPT_V_F32): channel c's faces lie
+// 6 * atlas_face cells behind channel c - 1's; float volumes keep four floats per cell.  Same texels, same order of operations as
+// sample_volume_rg<V> at the clamped position (float texels: finite ones, see vpt_volume_finalize).  Precondition as boundary_cell's.
+template <int V>
+VPT_DEV f2 sample_boundary_rg(const DevVolume &v, f3 p) {
+    constexpr bool NEAREST = (V & VPT_V_NEAREST) != 0, RG = (V & VPT_V_RG) != 0, F32 = (V & VPT_V_F32) != 0;
+    float fa, fb;
+    const uint32_t idx = boundary_cell_lane<NEAREST>(v, p, fa, fb);
+    float val[2] = { 0.0f, 0.0f };
+#pragma unroll
+    for (int c = 0; c < (RG ? 2 : 1); c++) {
+        const uint32_t cell = idx + (uint32_t)c * 6u * v.atlas_face;
+        if (F32) {
+            const float4 t = ((const float4 *)v.atlas)[cell];
+            val[c] = NEAREST ? t.x : lerpf(lerpf(t.x, t.y, fa), lerpf(t.z, t.w, fa), fb);
+        } else {
+            const uint32_t w = v.atlas[cell];
+            val[c] = NEAREST ? cvt_ubyte<0>(w) * VPT_INV255 : boundary_blend(w, fa, fb);
+        }
+    }
+    return f2{ val[0], val[1] };
 }
 VPT_DEV float sample_volume_boundary(const DevVolume &v, f3 p) {
     float fa, fb;

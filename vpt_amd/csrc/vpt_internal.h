@@ -60,8 +60,11 @@ struct vpt_volume {
     bool dirty;            // blocks uploaded since the last brickify
     bool any_upload;
     uint8_t *staging; size_t staging_bytes;
-    uint32_t *atlas;       // boundary atlas: the six outer voxel planes as 2 x 2-footprint dwords (vpt_device.h sample_volume_boundary); one-channel volumes
+    uint32_t *atlas;       // boundary atlas: the six outer voxel planes as 2 x 2-footprint cells (vpt_device.h sample_volume_boundary): one dword per cell
+                           // and channel (byte volumes) or one float4 (float volumes); channel c's faces 6 * atlas_face cells behind c - 1's
     size_t atlas_dwords;
+    bool atlas_ok;         // float volumes: every texel is finite and < 1e37 (k_scan_finite at finalize): else the atlas is not used
+    uint32_t *atlas_flag;
     uint32_t atlas_face, atlas_shift;   // dwords per face image (row pitch x rows), log2 of the row pitch
     // column records (vpt_device.h record_addr; one-channel byte volumes): built on the first MCM pass that wants them (volume_records)
     uint8_t *records; size_t rec_bytes; bool rec_valid, rec_wide;

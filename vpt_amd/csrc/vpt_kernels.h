@@ -115,6 +115,7 @@ struct PassArgs {
     };
     uint32_t multi_passes;       // > 1: the fused (MODE 1) kernels run that many passes per pixel in one launch (VPT_PLAY_FUSED)
     uint32_t miss_load_pos;      // k_mcm_miss: 1 = the position array is up to date (first classified pass after a reset or a whole-image pass): load it
+    uint32_t miss_verify;        // k_mcm_miss of the other volume formats: 1 = count the events inside the cube (VPT_OPTION_VERIFY_TILE_CLASSES; a run-time flag there)
     unsigned long long *violations;   // k_mcm_miss<.., CHECK>: events of "miss" tiles that were inside the cube (must stay 0)
     void *frame;                 // tile order
     void *acc;                   // tile order (ping-pong collapsed: each pixel reads and writes only itself)

@@ -178,7 +178,10 @@ __global__ void __launch_bounds__(256) k_build_records(const uint8_t *lin, uint8
 // boundary atlas (vpt_device.h sample_volume_boundary): thread c of [0, cx + cy + cz) builds cell c of the low-side AND the
 // high-side face of its axis from the linear volume.  Face x: cells (a, b) = (y, z); y: (x, z); z: (x, y); face f = 2 * axis +
 // side at dword f * face, cell (a, b) at (b << shift) + a.
-__global__ void __launch_bounds__(256) k_build_atlas(const uint8_t *lin, uint32_t *atlas, int nx, int ny, int nz, uint32_t face, uint32_t shift) {
+// T = uint8_t: one dword per cell (four bytes); T = float: one 16-byte cell (four floats).  `ch` interleaved channels in the linear volume:
+// channel c's six face images start 6 * face cells behind channel c - 1's.
+template <typename T>
+__global__ void __launch_bounds__(256) k_build_atlas(const T *lin, void *atlas, int nx, int ny, int nz, int ch, uint32_t face, uint32_t shift) {
     size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t cx = (size_t)ny * nz, cy = (size_t)nx * nz, cz = (size_t)nx * ny;
     int axis, na, nb;
@@ -189,14 +192,26 @@ __global__ void __launch_bounds__(256) k_build_atlas(const uint8_t *lin, uint32_
     const int a = (int)(c % (size_t)na), b = (int)(c / (size_t)na);
     const int a1 = min(a + 1, na - 1), b1 = min(b + 1, nb - 1);
     const int nk = axis == 0 ? nx : (axis == 1 ? ny : nz);
-    for (int side = 0; side < 2; side++) {
-        const int k = side ? nk - 1 : 0;
-        auto vox = [&](int p, int q) -> uint32_t {
-            int x = axis == 0 ? k : p, y = axis == 0 ? p : (axis == 1 ? k : q), z = axis == 2 ? k : q;
-            return lin[((size_t)z * ny + y) * nx + x];
-        };
-        atlas[(size_t)(2 * axis + side) * face + ((size_t)b << shift) + a] = vox(a, b) | (vox(a1, b) << 8) | (vox(a, b1) << 16) | (vox(a1, b1) << 24);
-    }
+    for (int chan = 0; chan < ch; chan++)
+        for (int side = 0; side < 2; side++) {
+            const int k = side ? nk - 1 : 0;
+            auto vox = [&](int p, int q) -> T {
+                int x = axis == 0 ? k : p, y = axis == 0 ? p : (axis == 1 ? k : q), z = axis == 2 ? k : q;
+                return lin[(((size_t)z * ny + y) * nx + x) * ch + chan];
+            };
+            const size_t cell = ((size_t)chan * 6 + (size_t)(2 * axis + side)) * face + ((size_t)b << shift) + a;
+            if (sizeof(T) == 1)
+                ((uint32_t *)atlas)[cell] = (uint32_t)vox(a, b) | ((uint32_t)vox(a1, b) << 8) | ((uint32_t)vox(a, b1) << 16) | ((uint32_t)vox(a1, b1) << 24);
+            else
+                ((float4 *)atlas)[cell] = make_float4((float)vox(a, b), (float)vox(a1, b), (float)vox(a, b1), (float)vox(a1, b1));
+        }
+}
+// float volumes: is every texel finite and small enough that a difference of two texels cannot overflow?  Only then is
+// lerp(t, t', 0) = fma(0, t' - t, t) == t, which the boundary atlas (and with it the tile classes) relies on for float texels.
+__global__ void __launch_bounds__(256) k_scan_finite(const float *lin, size_t n, uint32_t *bad) {
+    uint32_t b = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b |= !(fabsf(lin[i]) < 1e37f);
+    if (__builtin_amdgcn_ballot_w64(b != 0) && ((int)threadIdx.x & 63) == 0) atomicOr(bad, 1u);
 }
 
 // streaming read: every lane pulls 16 B per iteration, grid-stride; the xor keeps the loads alive
@@ -241,6 +256,20 @@ __global__ void k_probe_math(int which, const float *in, float *out, size_t n) {
         case 16: r = vpt_powf(in[2 * t], in[2 * t + 1]); break;
     }
     out[t] = r;
+}
+// the same sample through the boundary atlas (positions with a coordinate outside [0, 1]; others through the bricks): what k_mcm_miss and the
+// out-of-cube lanes of k_mcm_integrate execute — must equal k_probe_sample bit for bit
+template <int V>
+__global__ void __launch_bounds__(VPT_BLOCK) k_probe_sample_boundary(PassArgs a, const float *xyz, float4 *out, size_t n) {
+    extern __shared__ float4 lds_raw[];
+    LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 q = { xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] };
+    const bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+    if (!oob) { out[i] = sample_volume_color<V>(a, t, q); return; }
+    const f2 rg = sample_boundary_rg<V>(a.vol, q);
+    out[i] = (V & VPT_V_RG) ? sample_tf2d(a.tf, a.tf_w, a.tf_h, rg.x, rg.y) : sample_tf(t.tf, a.tf_fw, a.tf_hi, rg.x);
 }
 template <int V>
 __global__ void __launch_bounds__(VPT_BLOCK) k_probe_sample(PassArgs a, const float *xyz, float4 *out, size_t n) {

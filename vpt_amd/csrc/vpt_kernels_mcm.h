@@ -590,6 +590,20 @@ VPT_DEV void miss_sample_finish(const PassArgs &a, const float4 *tf, const MissL
     float4 vs = sample_tf(tf, a.tf_fw, a.tf_hi, boundary_blend(l.aw, l.fa, l.fb));
     asm volatile("" : "+v"(vs.w));
 }
+// The same executed-and-discarded sample for the other volume formats (round 4): NEAREST filter, two channels (RG8 / RG32F: the G atlas 6 faces
+// behind the R atlas, the transfer function looked up in 2-D from HBM), float texels (one float4 per cell, no normalisation).  Same texels,
+// same order of operations as sample_volume_rg<V> at the clamped position: bit-identical (float texels: finite ones — the library does not
+// use the atlas of a float volume that holds others, vpt_volume_finalize).  One phase: these variants are not the benchmark's.
+template <int V>
+VPT_DEV void miss_sample_any(const PassArgs &a, const float4 *tf, f3 q) {
+    const f2 rg = sample_boundary_rg<V>(a.vol, q);
+    float4 vs = (V & VPT_V_RG) ? sample_tf2d(a.tf, a.tf_w, a.tf_h, rg.x, rg.y) : sample_tf(tf, a.tf_fw, a.tf_hi, rg.x);
+    asm volatile("" : "+v"(vs.w));
+    if (a.miss_verify) {
+        const bool oob = (vmax(vmax(q.x, q.y), q.z) > 1.0f) || (vmin(vmin(q.x, q.y), q.z) < 0.0f);
+        if (!oob) atomicAdd(a.violations, 1ull);
+    }
+}
 // LATE: the sample is consumed after the path end (under whose arithmetic its load flies) instead of right where the shader samples
 template <int V, bool CHECK, bool LATE>
 VPT_DEV void mcm_events_miss(const PassArgs &a, const float4 *tf, Photon &ph, float px, float py, f3 from0) {
@@ -597,13 +611,16 @@ VPT_DEV void mcm_events_miss(const PassArgs &a, const float4 *tf, Photon &ph, fl
     for (uint32_t s = 0u; s < a.steps; s++) {
         float dist = random_exponential(state, a.inv_extinction);
         ph.position = madd3(ph.position, dist, ph.direction);
-        const MissLoad l = miss_sample_issue<CHECK>(a, ph.position, a.violations);
-        if (!LATE) miss_sample_finish(a, tf, l);
+        constexpr bool OTHER = (V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32)) != 0;      // another volume format: the one-phase sample
+        MissLoad l = { 0u, 0.0f, 0.0f };
+        if (OTHER) miss_sample_any<V>(a, tf, ph.position);
+        else l = miss_sample_issue<CHECK>(a, ph.position, a.violations);
+        if (!LATE && !OTHER) miss_sample_finish(a, tf, l);
         random_uniform(state);                                     // the wheel draw (its value decides nothing out of bounds)
         float4 env = sample_environment(a.env, ph.direction);      // transmittance is (1, 1, 1): radiance = 1 * env, exactly env
         photon_deposit(ph, f3{ env.x, env.y, env.z });
         reset_photon<true>(state, ph, px, py, a, from0);
-        if (LATE) miss_sample_finish(a, tf, l);
+        if (LATE && !OTHER) miss_sample_finish(a, tf, l);
     }
 }
 template <int V, bool CHECK, bool LATE>
@@ -613,12 +630,15 @@ VPT_DEV void mcm_events_miss_fast(const PassArgs &a, const float4 *tf, const Fas
     for (uint32_t s = 0u; s < a.steps; s++) {
         float dist = fmaf(hw_log2(pcg_float(state)), ld, ld32);
         ph.position = madd3(ph.position, dist, ph.direction);
-        const MissLoad l = miss_sample_issue<CHECK>(a, ph.position, a.violations);
-        if (!LATE) miss_sample_finish(a, tf, l);
+        constexpr bool OTHER = (V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32)) != 0;
+        MissLoad l = { 0u, 0.0f, 0.0f };
+        if (OTHER) miss_sample_any<V>(a, tf, ph.position);
+        else l = miss_sample_issue<CHECK>(a, ph.position, a.violations);
+        if (!LATE && !OTHER) miss_sample_finish(a, tf, l);
         state = pcg(state);                                        // the wheel draw
         float4 env = sample_environment(a.env, ph.direction);
         fast_path_end<true>(a, c, state, ph, f3{ env.x, env.y, env.z }, px, py);
-        if (LATE) miss_sample_finish(a, tf, l);
+        if (LATE && !OTHER) miss_sample_finish(a, tf, l);
     }
 }
 template <bool FUSE_RENDER, int V, bool CHECK, bool LATE>

@@ -45,9 +45,30 @@ template <bool FUSE> static PassKernel hit_kernel(int v, bool early) {
 static bool mcm_classes_usable(const vpt_renderer *r, const PassArgs &a) {
     return r->cls.enabled && r->cls.valid && a.blur == 0.0f && memcmp(r->cls.mvp, a.mvp_inv.m, sizeof(r->cls.mvp)) == 0;
 }
-// the kernel side of it: LINEAR one-channel volume with its boundary atlas (what k_mcm_miss samples), no persistent-wave option
+// the kernel side of it: the volume's boundary atlas (what k_mcm_miss samples; every format since round 4), no persistent-wave option
 static bool mcm_classes_runnable(const vpt_renderer *r, const PassArgs &a) {
-    return a.vol.atlas != nullptr && (variant_of(r) & ~VPT_V_WIDE) == 0 && !r->mcm_persistent;
+    return a.vol.atlas != nullptr && !r->mcm_persistent;
+}
+// ... and of the bucket kernels (and of the HIT-tile kernel's early form): LINEAR one-channel byte volumes
+static bool mcm_plain_volume(const vpt_renderer *r) { return (variant_of(r) & ~VPT_V_WIDE) == 0; }
+// NEAREST / two-channel / float volumes: the HIT tiles through the general kernel of the volume's variant (from a tile list), the MISS
+// tiles through the one-phase sampler of k_mcm_miss (miss_sample_any)
+#define FORMAT_CASES(...) switch (v & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32)) { \
+        case VPT_V_NEAREST: { constexpr int F = VPT_V_NEAREST; return __VA_ARGS__; } \
+        case VPT_V_RG: { constexpr int F = VPT_V_RG; return __VA_ARGS__; } \
+        case VPT_V_RG | VPT_V_NEAREST: { constexpr int F = VPT_V_RG | VPT_V_NEAREST; return __VA_ARGS__; } \
+        case VPT_V_F32: { constexpr int F = VPT_V_F32; return __VA_ARGS__; } \
+        case VPT_V_F32 | VPT_V_NEAREST: { constexpr int F = VPT_V_F32 | VPT_V_NEAREST; return __VA_ARGS__; } \
+        case VPT_V_F32 | VPT_V_RG: { constexpr int F = VPT_V_F32 | VPT_V_RG; return __VA_ARGS__; } \
+        default: { constexpr int F = VPT_V_F32 | VPT_V_RG | VPT_V_NEAREST; return __VA_ARGS__; } }
+template <bool FUSE> static PassKernel format_hit_kernel(int v, bool wide, bool fast) {
+    if (wide) { if (fast) FORMAT_CASES((PassKernel)k_mcm_integrate<FUSE, F | VPT_V_WIDE | VPT_V_FAST>) FORMAT_CASES((PassKernel)k_mcm_integrate<FUSE, F | VPT_V_WIDE>) }
+    if (fast) FORMAT_CASES((PassKernel)k_mcm_integrate<FUSE, F | VPT_V_FAST>)
+    FORMAT_CASES((PassKernel)k_mcm_integrate<FUSE, F>)
+}
+template <bool FUSE> static PassKernel format_miss_kernel(int v, bool fast) {
+    if (fast) FORMAT_CASES((PassKernel)k_mcm_miss<FUSE, F | VPT_V_FAST, false, true>)
+    FORMAT_CASES((PassKernel)k_mcm_miss<FUSE, F, false, true>)
 }
 // position / transmittance of the MISS tiles, as the last pass's arithmetic would have stored them
 int mcm_materialize(vpt_renderer *r) {
@@ -82,13 +103,16 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     PassKernel kh, km;
     // the HIT tiles: few enough to be resident at once at 5 waves per SIMD (a shard's share) -> the form with the early path end,
     // whose pass is one wave per SIMD walking a chain of dependent latencies; else the 7-waves form (VPT_HIT_KERNEL_FORM in the environment overrides)
-    const bool early = r->hit_form == 2 || (r->hit_form == 0 && r->cls.n_hit <= 1280);
-    kh = hit_kernel<FUSE>(class_variant(r, a), early);
+    const bool plain = mcm_plain_volume(r);
+    const bool early = plain && (r->hit_form == 2 || (r->hit_form == 0 && r->cls.n_hit <= 1280));
+    if (plain) kh = hit_kernel<FUSE>(class_variant(r, a), early);
+    else kh = format_hit_kernel<FUSE>(variant_of(r), (variant_of(r) & VPT_V_WIDE) != 0, fast);
     // the MISS tiles: the sample consumed after the path end (its gather flies under that arithmetic) — whole frame 80.8 -> 79.3-79.7 us
     // fast-math, 96.1 -> 92.8 bit-exact, rank 3 of 8's share 18.4 -> 17.1 bit-exact but 15.8 -> 16.9 fast-math: there the sample is
     // consumed where the shader takes it
     const bool late = !(fast && early);
-    if (check) km = fast ? (late ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, true, true> : (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, true, false>)
+    if (!plain) km = format_miss_kernel<FUSE>(variant_of(r), fast);
+    else if (check) km = fast ? (late ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, true, true> : (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, true, false>)
                          : (PassKernel)k_mcm_miss<FUSE, 0, true, true>;
     else km = fast ? (late ? (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, false, true> : (PassKernel)k_mcm_miss<FUSE, VPT_V_FAST, false, false>)
                    : (PassKernel)k_mcm_miss<FUSE, 0, false, true>;
@@ -123,6 +147,7 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
         for (int i = 0; i < np; i++) {
             PassArgs part = a;
             part.pm.tile_list = parts[i].list; part.pm.list_n = parts[i].n; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
+            part.miss_verify = check ? 1u : 0u;
             VPT_TIMING_ARG(part, i < hit_parts);
             // profiling: the caller's pair (Timed) brackets both launches; the MISS-tile kernel gets the pair vpt_renderer_profile_side reads
             hipEvent_t e1 = nullptr;
@@ -152,6 +177,7 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
         for (int i = np - 1; i >= 0; i--) {
             PassArgs part = a;
             part.pm.tile_list = parts[i].list; part.pm.list_n = parts[i].n; part.miss_load_pos = r->cls.stale ? 0u : 1u; part.violations = r->cls.violations;
+            part.miss_verify = check ? 1u : 0u;
             VPT_TIMING_ARG(part, i < hit_parts);
             // profiling: the context's stream is bracketed by the caller (Timed); the first side launch gets a pair of its own
             hipEvent_t e1 = nullptr;
@@ -183,7 +209,7 @@ int mcm_bucket_ready(vpt_renderer *r, const PassArgs &a, bool *ready) {
     VPT_TRY(mcm_before_pass(r, a, &same));
     const bool two_streams = r->split >= 2 && !r->no_split && (!r->target_is_callers || r->bucket_call);
     if (two_streams) VPT_TRY(ensure_split_streams(r));
-    *ready = same && r->cls.enabled && mcm_classes_runnable(r, a) && two_streams && !r->cls.verify;
+    *ready = same && r->cls.enabled && mcm_classes_runnable(r, a) && mcm_plain_volume(r) && two_streams && !r->cls.verify;
     return VPT_OK;
 }
 template <bool DISPLAY> static BucketKernel bucket_hit_kernel(int v, bool early) {

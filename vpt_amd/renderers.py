@@ -328,6 +328,14 @@ class AbstractRenderer(PropertyBag):
         N.check(N.lib().vpt_probe_sample(self._h, xyz.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), xyz.shape[0]))
         return out
 
+    def probe_sample_boundary(self, xyz):
+        """the same samples with the positions outside the cube taken from the volume's boundary atlas (vpt_probe_sample_boundary)"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        out = np.empty((xyz.shape[0], 4), dtype=np.float32)
+        self._bind_volume()
+        N.check(N.lib().vpt_probe_sample_boundary(self._h, xyz.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), xyz.shape[0]))
+        return out
+
 
 AbstractRenderer._BASE = AbstractRenderer
 
