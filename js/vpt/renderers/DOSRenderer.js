@@ -3,7 +3,7 @@
 // slices per render() call until the sweep has passed the far corner of the volume
 const { AbstractRenderer, U, installChangeHandler, transferFunctionProperty } = require('./AbstractRenderer.js');
 const { PerspectiveCamera } = require('../scene.js');
-const { vec3, mat4 } = require('../math.js');
+const { occlusionTaps, viewDepthRange, sliceTriples } = require('./dosSweep.js');
 const { native } = require('../native.js');
 
 class DOSRenderer extends AbstractRenderer {
@@ -33,46 +33,18 @@ constructor(gl, volume, camera, environmentTexture, options) {
 }
 
 generateOcclusionSamples() {                                                                   // :103-140
-    const data = new Float32Array(this.samples * 2);
-    let averagex = 0;
-    let averagey = 0;
-    for (let i = 0; i < this.samples; i++) {
-        const r = Math.sqrt(this.rng());
-        const phi = this.rng() * 2 * Math.PI;
-        const x = r * Math.cos(phi);
-        const y = r * Math.sin(phi);
-        averagex += x / this.samples;
-        averagey += y / this.samples;
-        data[2 * i + 0] = x;
-        data[2 * i + 1] = y;
-    }
-    for (let i = 0; i < this.samples; i++) {
-        data[2 * i + 0] -= averagex;
-        data[2 * i + 1] -= averagey;
-    }
-    this._occlusionSamples = data;
-    native().rendererSetOcclusionSamples(this._h, data);
+    this._occlusionSamples = occlusionTaps(this.rng, this.samples);
+    native().rendererSetOcclusionSamples(this._h, this._occlusionSamples);
 }
 
 calculateDepth() {                                                                             // :142-167
-    const centerMatrix = mat4.fromTranslation(mat4.create(), [-0.5, -0.5, -0.5]);
-    const modelMatrix = this._volumeTransform.globalMatrix;
-    const viewMatrix = this._camera.transform.inverseGlobalMatrix;
-    const matrix = mat4.create();
-    mat4.multiply(matrix, centerMatrix, matrix);
-    mat4.multiply(matrix, modelMatrix, matrix);
-    mat4.multiply(matrix, viewMatrix, matrix);
-    const corners = [
-        [0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1],
-        [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1],
-    ];
-    const depths = corners.map(v => -vec3.transformMat4(v, v, matrix)[2]);
-    return [Math.min(...depths), Math.max(...depths)];
+    return viewDepthRange(this._volumeTransform.globalMatrix, this._camera.transform.inverseGlobalMatrix);
 }
 
 _resetFrame() {                                                                                // :169-185
-    [this._minDepth, this._maxDepth] = this.calculateDepth();
-    this._minDepth = Math.max(this._minDepth, 0);
+    const [nearest, farthest] = this.calculateDepth();
+    this._minDepth = Math.max(nearest, 0);
+    this._maxDepth = farthest;
     this._depth = this._minDepth;
     native().rendererReset(this._h, null);
 }
@@ -83,20 +55,10 @@ _prepareSlices() {
     u.setFloat32(U.EXTINCTION, this.extinction, true);
     const sliceDistance = (this._maxDepth - this._minDepth) / this.slices;
     u.setFloat32(U.STEP, sliceDistance, true);
-    const projectionMatrix = this._camera.getComponent(PerspectiveCamera).projectionMatrix;
-    const rows = [];
-    for (let step = 0; step < this.steps; step++) {
-        if (this._depth > this._maxDepth) { break; }
-        const correction = [1, 1, -this._depth];
-        vec3.transformMat4(correction, correction, projectionMatrix);
-        const occlusionExtent = sliceDistance * Math.tan(this.aperture * Math.PI / 180);
-        correction[0] *= occlusionExtent;
-        correction[1] *= occlusionExtent;
-        rows.push(correction[0], correction[1], correction[2]);
-        this._depth += sliceDistance;
-    }
+    const sweep = { depth: this._depth, farthest: this._maxDepth };
+    this._slices = sliceTriples(sweep, this.steps, sliceDistance, this.aperture, this._camera.getComponent(PerspectiveCamera).projectionMatrix);
+    this._depth = sweep.depth;
     this._u = u;
-    this._slices = new Float32Array(rows);
     return u;
 }
 _generateFrame() {}                                                                            // AbstractRenderer.js:122-124

@@ -773,65 +773,34 @@ class DOSRenderer(AbstractRenderer):
         self.generateOcclusionSamples()
 
     def generateOcclusionSamples(self):                            # :103-140
+        from .dos_sweep import occlusion_taps
         n = int(self.samples)
-        data = np.zeros(2 * n, dtype=np.float32)                   # Float32Array: every store rounds
-        averagex = 0.0
-        averagey = 0.0
-        for i in range(n):
-            r = math.sqrt(self.rng())
-            phi = self.rng() * 2 * math.pi
-            x = r * math.cos(phi)
-            y = r * math.sin(phi)
-            averagex += x / n
-            averagey += y / n
-            data[2 * i + 0] = x
-            data[2 * i + 1] = y
-        for i in range(n):
-            data[2 * i + 0] = float(data[2 * i + 0]) - averagex
-            data[2 * i + 1] = float(data[2 * i + 1]) - averagey
-        self._occlusionSamples = data
-        N.check(N.lib().vpt_renderer_set_occlusion_samples(self._h, data.ctypes.data_as(C.c_void_p), n))
+        self._occlusionSamples = occlusion_taps(self.rng, n)
+        N.check(N.lib().vpt_renderer_set_occlusion_samples(self._h, self._occlusionSamples.ctypes.data_as(C.c_void_p), n))
 
     def calculateDepth(self):                                      # :142-167
-        from .scene import mat4, vec3
-        centerMatrix = mat4.fromTranslation(mat4.create(), [-0.5, -0.5, -0.5])
-        modelMatrix = self._volumeTransform.globalMatrix
-        viewMatrix = self._camera.transform.inverseGlobalMatrix
-        matrix = mat4.create()
-        mat4.multiply(matrix, centerMatrix, matrix)
-        mat4.multiply(matrix, modelMatrix, matrix)
-        mat4.multiply(matrix, viewMatrix, matrix)
-        corners = [[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)]
-        depths = [-vec3.transformMat4(v, v, matrix)[2] for v in corners]      # plain arrays: double results
-        return [min(depths), max(depths)]
+        from .dos_sweep import view_depth_range
+        return view_depth_range(self._volumeTransform.globalMatrix, self._camera.transform.inverseGlobalMatrix)
 
     def _resetFrame(self):                                         # :169-185
-        self._minDepth, self._maxDepth = self.calculateDepth()
-        self._minDepth = max(self._minDepth, 0)
+        nearest, farthest = self.calculateDepth()
+        self._minDepth, self._maxDepth = max(nearest, 0), farthest
         self._depth = self._minDepth
         N.check(N.lib().vpt_renderer_reset(self._h, None))
 
     def _prepare_slices(self):
         """the uniforms of :212-236 and, per pass of the loop :240-259, (uOcclusionScale.x, uOcclusionScale.y, uDepth)"""
-        from .scene import PerspectiveCamera, vec3
+        from .scene import PerspectiveCamera
+        from .dos_sweep import slice_triples
         u = self._new_uniforms()
         u.extinction = _f32(self.extinction)
         sliceDistance = (self._maxDepth - self._minDepth) / self.slices
         u.step_size = _f32(sliceDistance)
-        projectionMatrix = self._camera.getComponent(PerspectiveCamera).projectionMatrix
-        rows = []
-        for _ in range(int(self.steps)):
-            if self._depth > self._maxDepth:
-                break
-            correction = [1, 1, -self._depth]
-            vec3.transformMat4(correction, correction, projectionMatrix)
-            occlusionExtent = sliceDistance * math.tan(self.aperture * math.pi / 180)
-            correction[0] *= occlusionExtent
-            correction[1] *= occlusionExtent
-            rows.append(correction)
-            self._depth += sliceDistance
+        sweep = {'depth': self._depth, 'farthest': self._maxDepth}
+        slices = slice_triples(sweep, int(self.steps), sliceDistance, self.aperture, self._camera.getComponent(PerspectiveCamera).projectionMatrix)
+        self._depth = sweep['depth']
         self._u = u
-        return u, np.array(rows, dtype=np.float32).reshape(-1, 3)
+        return u, slices
 
     def _integrateFrame(self):                                     # :187-262
         self._bind_volume()
