@@ -44,7 +44,17 @@ def test_mcm_kernels_use_no_scratch_and_fit_seven_waves():
     for name, u in frames.items():
         assert u.get("ScratchSize", 0) == 0 and u.get("VGPRs", 999) <= 128 and u.get("Occupancy", 0) >= 4, (name, u)
     # the MISS-tile kernels of the tile classes: 8 waves per SIMD, no scratch
-    miss = {k: v for k, v in usage.items() if k.startswith("_Z10k_mcm_missILb")}
+    miss = {k: v for k, v in usage.items() if re.match(r"_Z10k_mcm_missILb[01]ELi(0|16)ELb", k)}
     assert len(miss) == 12, sorted(miss)
     for name, u in miss.items():
         assert u.get("ScratchSize", 0) == 0 and u.get("VGPRs", 999) <= 64 and u.get("Occupancy", 0) >= 8, (name, u)
+    # ... of the other volume formats (NEAREST / two channels / float texels, round 4): 14 variants x fused or not, no scratch, >= 7 waves
+    other = {k: v for k, v in usage.items() if k.startswith("_Z10k_mcm_missILb") and k not in miss}
+    assert len(other) == 28, sorted(other)
+    for name, u in other.items():
+        assert u.get("ScratchSize", 0) == 0 and u.get("Occupancy", 0) >= 7, (name, u)
+    # the HIT-tile kernel sampling the column records (VPT_V_REC = 64): the same budget as the brick form
+    rec = {k: v for k, v in usage.items() if re.match(r"_Z15k_mcm_integrateILb[01]ELi(64|65|80|81)EE", k)}
+    assert len(rec) == 8, sorted(rec)
+    for name, u in rec.items():
+        assert u.get("ScratchSize", 0) == 0 and u.get("VGPRs", 999) <= 72 and u.get("Occupancy", 0) >= 7, (name, u)

@@ -641,8 +641,10 @@ VPT_DEV void mcm_events_miss_fast(const PassArgs &a, const float4 *tf, const Fas
         if (LATE && !OTHER) miss_sample_finish(a, tf, l);
     }
 }
+// (8 waves per SIMD = 64 VGPRs; the contract arithmetic of the other volume formats needs two more: 7 waves there instead of a spill)
 template <bool FUSE_RENDER, int V, bool CHECK, bool LATE>
-__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_mcm_miss(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK)
+__attribute__((amdgpu_waves_per_eu(((V & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32)) && !(V & VPT_V_FAST)) ? 7 : 8, 8))) k_mcm_miss(PassArgs a) {
     apply_frame_table(a);
     Pix p = map_pixel(a.pm);
     float4 s1 = make_float4(0.0f, 0.0f, 1.0f, 0.0f), s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
