@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default="")
 ap.add_argument("--tag", default="")
 ap.add_argument("--fast", type=int, default=1)
-ap.add_argument("--split", type=int, default=3)
+ap.add_argument("--split", type=int, default=0, help="VPT_OPTION_SPLIT_STREAMS; 0 = the library's default")
 ap.add_argument("--classes", type=int, default=1, help="VPT_OPTION_TILE_CLASSES: 0 off, 1 on, 2 on even on one stream (each class kernel alone on the chip)")
 ap.add_argument("--volume", type=int, default=512)
 ap.add_argument("--width", type=int, default=1920)
@@ -90,7 +90,8 @@ except vpt_amd.VptError:
     pass                                              # a build from before the option existed
 if args.records >= 0 and args.renderer == "mcm":
     r.set_option(N.OPTION_COLUMN_RECORDS, args.records)
-r.set_option(N.OPTION_SPLIT_STREAMS, max(1, args.split))
+if args.split >= 1:                                   # 0: the library's own default
+    r.set_option(N.OPTION_SPLIT_STREAMS, args.split)
 r.reset()
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.3:

@@ -380,14 +380,33 @@ VPT_DEV float trilinear_blend(uint32_t l0, uint32_t h0, uint32_t l1, uint32_t h1
     float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
     return lerpf(c0, c1, fz) * VPT_INV255;
 }
+// the two 12-byte windows of the ALIGNED form, by GLOBAL loads: `a` = the (byte-aligned) address of the cell's first tap.  The dword-aligned
+// address is formed by pointer arithmetic — round 3 went through uintptr_t, which loses the address space: the compiler emitted flat_load,
+// whose completion also counts on lgkmcnt, so every wait for an LDS table lookup of the NEXT sample waited for the bricks of THIS one (round 4)
+struct TapWindow { uint32_t a, b, c; };
+VPT_DEV TapWindow load_window(const uint8_t *a, uint32_t phase) {
+    TapWindow w;
+    __builtin_memcpy(&w, __builtin_assume_aligned(a - phase, 4), 12);
+    return w;
+}
+// the same with the address still in its two parts — the uniform base of the brick array and the 32-bit offset of the cell (volumes up to
+// 4 GiB of bricks) —: the dword alignment is taken off the OFFSET, and the load keeps global_load's SGPR-base + VGPR-offset form (no 64-bit
+// address arithmetic per window).  The brick array is 256-byte aligned, so the byte phase of the address is the offset's.
+VPT_DEV float aligned_taps(const uint8_t *base, uint32_t off, float fx, float fy, float fz) {
+    const uint32_t o1 = off + 25u, s0 = off & 3u, s1 = o1 & 3u;
+    TapWindow q0, q1;
+    __builtin_memcpy(&q0, __builtin_assume_aligned(base + (off - s0), 4), 12);
+    __builtin_memcpy(&q1, __builtin_assume_aligned(base + (o1 - s1), 4), 12);
+    const uint32_t l0 = __builtin_amdgcn_alignbyte(q0.b, q0.a, s0), h0 = __builtin_amdgcn_alignbyte(q0.c, q0.b, s0);
+    const uint32_t l1 = __builtin_amdgcn_alignbyte(q1.b, q1.a, s1), h1 = __builtin_amdgcn_alignbyte(q1.c, q1.b, s1);
+    return trilinear_blend(l0, h0, l1, h1, fx, fy, fz);
+}
 template <int V>
 VPT_DEV float trilinear_taps(const uint8_t *a, float fx, float fy, float fz) {
     uint32_t l0, h0, l1, h1;
     if (V & VPT_V_ALIGNED) {
-        struct W3 { uint32_t a, b, c; };
-        uintptr_t p0 = (uintptr_t)a, p1 = p0 + 25;
-        W3 q0 = *(const W3 *)(p0 & ~(uintptr_t)3), q1 = *(const W3 *)(p1 & ~(uintptr_t)3);
-        uint32_t s0 = (uint32_t)p0 & 3u, s1 = (uint32_t)p1 & 3u;
+        const uint32_t s0 = (uint32_t)(uintptr_t)a & 3u, s1 = ((uint32_t)(uintptr_t)a + 25u) & 3u;   // (v_alignbyte_b32 reads S2[4:0] on CDNA: mask)
+        const TapWindow q0 = load_window(a, s0), q1 = load_window(a + 25, s1);
         l0 = __builtin_amdgcn_alignbyte(q0.b, q0.a, s0); h0 = __builtin_amdgcn_alignbyte(q0.c, q0.b, s0);
         l1 = __builtin_amdgcn_alignbyte(q1.b, q1.a, s1); h1 = __builtin_amdgcn_alignbyte(q1.c, q1.b, s1);
     } else {
@@ -575,6 +594,10 @@ VPT_DEV f2 sample_volume_rg(const DevVolume &v, const LdsTables &t, f3 p) {
     if (V & VPT_V_REC) {                                          // (one channel: the launch code never combines REC with RG)
         const uint64_t w = record_load(record_addr<WIDE>(v, t, x, y, z));
         return f2{ record_blend((uint32_t)w, (uint32_t)(w >> 32), fx, fy, fz), 0.0f };
+    }
+    if ((V & VPT_V_ALIGNED) && !WIDE) {
+        const uint32_t off = t.tx[x] + t.ty[y] + t.tz[z];
+        return f2{ aligned_taps(v.bricks, off, fx, fy, fz), RG ? aligned_taps(v.bricks, off + 128u, fx, fy, fz) : 0.0f };
     }
     const uint8_t *a = cell_addr<WIDE>(v, t, x, y, z);
     return f2{ trilinear_taps<V>(a, fx, fy, fz), RG ? trilinear_taps<V>(a + 128, fx, fy, fz) : 0.0f };

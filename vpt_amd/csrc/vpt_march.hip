@@ -9,8 +9,11 @@
 #define K_MIP1(V) (k_mip<1, V | VPT_V_ALIGNED>)
 #define K_EAM0(V) (k_eam<0, V | VPT_V_ALIGNED>)
 #define K_EAM1(V) (k_eam<1, V | VPT_V_ALIGNED>)
-#define K_MCS0(V) (k_mcs<0, V>)
-#define K_MCS1(V) (k_mcs<1, V>)
+#ifndef VPT_MCS_TAPS
+#define VPT_MCS_TAPS 0
+#endif
+#define K_MCS0(V) (k_mcs<0, V | VPT_MCS_TAPS>)
+#define K_MCS1(V) (k_mcs<1, V | VPT_MCS_TAPS>)
 #define LAUNCH(kernel, r, a, lds) hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), (lds), (r)->ctx->stream, (a))
 
 #ifdef VPT_WITH_PERSISTENT_KERNELS
