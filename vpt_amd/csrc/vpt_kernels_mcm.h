@@ -144,6 +144,11 @@ VPT_DEV SampleLoads mcm_sample_issue(const PassArgs &a, const LdsTables &t, f3 p
     constexpr bool WIDE = (V & VPT_V_WIDE) != 0;
     SampleLoads s;
     s.aw = 0u; s.w0 = 0ull; s.w1 = 0ull; s.f0 = 0.0f; s.f1 = 0.0f; s.f2 = 0.0f;
+    // The destination registers of BOTH kinds of load get their zeros HERE, before either load is issued (round 4).  Left to itself the compiler
+    // sank `w0 = w1 = 0` into the out-of-cube side and re-used those registers there as scratch: in a divergent wave that side then had to
+    // wait (s_waitcnt vmcnt) for the in-cube lanes' brick windows before it could even compute its atlas address — the two gathers this
+    // function exists to overlap ran one after the other.
+    asm volatile("" : "+v"(s.w0), "+v"(s.w1), "+v"(s.aw));
     const bool at = oob && a.vol.atlas != nullptr;
     if (at) {
         s.aw = a.vol.atlas[boundary_cell(a.vol, p, s.f0, s.f1)];
@@ -167,9 +172,13 @@ VPT_DEV SampleLoads mcm_sample_issue(const PassArgs &a, const LdsTables &t, f3 p
 template <int V>
 VPT_DEV float4 mcm_sample_finish(const PassArgs &a, const LdsTables &t, const SampleLoads &s) {
     float r;
-    if (s.atlas) r = boundary_blend(s.aw, s.f0, s.f1);
-    else if (V & VPT_V_REC) r = record_blend((uint32_t)s.w0, (uint32_t)(s.w0 >> 32), s.f0, s.f1, s.f2);
-    else r = trilinear_blend((uint32_t)s.w0, (uint32_t)(s.w0 >> 32), (uint32_t)s.w1, (uint32_t)(s.w1 >> 32), s.f0, s.f1, s.f2);
+    // (the brick windows were issued first and return first: their blend runs while the atlas dword is still on its way)
+    if (!s.atlas) {
+        if (V & VPT_V_REC) r = record_blend((uint32_t)s.w0, (uint32_t)(s.w0 >> 32), s.f0, s.f1, s.f2);
+        else r = trilinear_blend((uint32_t)s.w0, (uint32_t)(s.w0 >> 32), (uint32_t)s.w1, (uint32_t)(s.w1 >> 32), s.f0, s.f1, s.f2);
+    } else {
+        r = boundary_blend(s.aw, s.f0, s.f1);
+    }
     float4 vs = sample_tf(t.tf, a.tf_fw, a.tf_hi, r);
     asm volatile("" : "+v"(vs.w));
     return vs;
