@@ -529,3 +529,35 @@ def test_a_distant_camera_runs_every_tile_as_a_hit_tile(gpu_ctx, oracle):
     for k, (x, y) in enumerate(zip(*outs)):
         assert_same_bits(y, x, "distant camera, output %d" % k)
     sc.gvol.destroy()
+
+
+def test_resets_with_moving_and_resting_cameras_reuse_or_rebuild_the_lists(gpu_ctx, oracle):
+    """round 4: the class lists are cached per (matrix, geometry) and otherwise uploaded from two pinned staging buffers in turn without a host
+    wait.  Seven resets — the camera moves, rests, moves back, the image is resized — each followed by passes: classes on = classes off"""
+    cams = [(0.7, -0.3, 3.2), (0.7, -0.3, 3.2), (1.9, 0.4, 2.6), (-0.8, 0.2, 3.0), (0.7, -0.3, 3.2), (0.7, -0.3, 3.2), (2.5, -0.5, 2.2)]
+
+    def run(classes):
+        sc = far_scene(gpu_ctx, oracle)
+        r = sc.renderer('mcm')
+        r.set_option(N.OPTION_TILE_CLASSES, classes)
+        r.set_option(N.OPTION_VERIFY_TILE_CLASSES, 1)
+        r.extinction = 4; r.steps = 4
+        outs, counts = [], []
+        for k, cam in enumerate(cams):
+            if k == 5:
+                r.setResolution((176, 128))                 # new geometry: the cached lists are void
+            c = orbit_camera((176 / 128) if k >= 5 else (sc.w / sc.h), *cam)
+            r._camera = c
+            r.reset()
+            counts.append(r.tile_classes()[:2])
+            r.render(); r.render()
+            outs.append(r.getTexture().copy())
+            outs.append(r.read(N.BUFFER_MCM_RADIANCE).copy())
+        assert r.tile_classes()[2] == 0
+        r.destroy(); sc.gvol.destroy()
+        return outs, counts
+
+    (a, ca), (b, cb) = run(0), run(1)
+    assert cb[0] == cb[1] == cb[4] and cb[2] != cb[0]          # the same camera gives the same lists; another camera others
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert_same_bits(y, x, "output %d" % k)
