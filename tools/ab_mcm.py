@@ -29,6 +29,8 @@ ap.add_argument("--extinction", type=float, default=0.0)
 ap.add_argument("--tf", default="", help="'ramp': the 256x1 grey ramp with alpha = v instead of the default 2x1 transfer function")
 ap.add_argument("--kernel-times", type=int, default=0, help="1: HIP events around every 4th launch: per-kernel averages (context stream | side stream)")
 ap.add_argument("--digest", type=int, default=0, help="1: print a digest of the radiance buffer after the run (same seeds: equal across bit-identical builds / options)")
+ap.add_argument("--format", default="r8", help="r8 | rg8 | f32 | rg32f: the volume's texel format (the synthetic bytes, second channel = 255 - v)")
+ap.add_argument("--play-fused", type=int, default=0, help="n > 0: time vpt_renderer_play(n, VPT_PLAY_FUSED) per pass instead of render()")
 ap.add_argument("--torch-stream", type=int, default=0, help="1: the context runs on a torch.cuda.Stream, as in bench.py")
 ap.add_argument("--dummy-contexts", type=int, default=0, help="contexts (one HIP stream each) created and used BEFORE the measured one: shifts which hardware queue each later stream lands on")
 args = ap.parse_args()
@@ -67,6 +69,10 @@ if args.torch_stream:
     ctx = vpt_amd.Context(0, stream=_ts.cuda_stream)
 else:
     ctx = vpt_amd.Context(0)
+if args.format in ("rg8", "rg32f"):
+    vol = np.stack([vol, 255 - vol], axis=-1)
+if args.format in ("f32", "rg32f"):
+    vol = vol.astype(np.float32) / 255.0
 gvol = vpt_amd.Volume.from_array(ctx, vol, 'linear')
 W, H = args.width, args.height
 opts = {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()}
@@ -93,19 +99,24 @@ if args.records >= 0 and args.renderer == "mcm":
 if args.split >= 1:                                   # 0: the library's own default
     r.set_option(N.OPTION_SPLIT_STREAMS, args.split)
 r.reset()
+def frames(n):
+    if args.play_fused:
+        for _ in range(max(1, n // args.play_fused)):
+            r.play(args.play_fused, fused=True)
+    else:
+        for _ in range(n):
+            r.render()
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.3:
-    for _ in range(50):
-        r.render()
+    frames(50)
     ctx.synchronize()
 blocks = []
 for _ in range(args.blocks):
     ctx.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.frames):
-        r.render()
+    frames(args.frames)
     ctx.synchronize()
-    blocks.append((time.perf_counter() - t0) / args.frames * 1e6)
+    blocks.append((time.perf_counter() - t0) / (max(1, args.frames // args.play_fused) * args.play_fused if args.play_fused else args.frames) * 1e6)
 blocks.sort()
 med = blocks[len(blocks) // 2]
 extra = ""

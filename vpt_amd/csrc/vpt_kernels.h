@@ -18,6 +18,36 @@
 #define VPT_UNROLL      4          // samples in flight per ray in the EAM / ISO / Depth marches (8: EAM 4 %, ISO 8 % slower —
                                    // their early exits throw the speculative samples away)
 #define VPT_UNROLL_MIP  8          // MIP has no early exit: 8 in flight is 3 % faster than 4
+// waves per SIMD a kernel is compiled for (its register budget): VPT_WAVES_ATTR(n) = amdgpu_waves_per_eu(n, 8), n = 0 leaves the choice
+// to the compiler.  The per-kernel values are measured ones (profiles/experiments.md, "occupancy")
+#define VPT_WAVES_ATTR(n)  VPT_WAVES_ATTR_(n)
+#define VPT_WAVES_ATTR_(n) VPT_WAVES_ATTR_##n
+#define VPT_WAVES_ATTR_0
+#define VPT_WAVES_ATTR_2 __attribute__((amdgpu_waves_per_eu(2, 8)))
+#define VPT_WAVES_ATTR_3 __attribute__((amdgpu_waves_per_eu(3, 8)))
+#define VPT_WAVES_ATTR_4 __attribute__((amdgpu_waves_per_eu(4, 8)))
+#define VPT_WAVES_ATTR_5 __attribute__((amdgpu_waves_per_eu(5, 8)))
+#define VPT_WAVES_ATTR_6 __attribute__((amdgpu_waves_per_eu(6, 8)))
+#define VPT_WAVES_ATTR_7 __attribute__((amdgpu_waves_per_eu(7, 8)))
+#define VPT_WAVES_ATTR_8 __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef VPT_MIP_WAVES
+#define VPT_MIP_WAVES 6
+#endif
+#ifndef VPT_EAM_WAVES
+#define VPT_EAM_WAVES 0
+#endif
+#ifndef VPT_MCS_WAVES
+#define VPT_MCS_WAVES 0
+#endif
+#ifndef VPT_DEPTH_WAVES
+#define VPT_DEPTH_WAVES 0
+#endif
+#ifndef VPT_LAO_WAVES
+#define VPT_LAO_WAVES 0
+#endif
+#ifndef VPT_DOS_WAVES
+#define VPT_DOS_WAVES 0
+#endif
 
 struct PixMap {
     int W, H;          // full image plane

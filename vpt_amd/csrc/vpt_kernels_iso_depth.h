@@ -70,8 +70,11 @@ VPT_DEV uint2 iso_shade(const PassArgs &a, const LdsTables &t, uint2 closest, ui
     return pack_half4(material.x * lambert, material.y * lambert, material.z * lambert, 1.0f);
 }
 // MODE 0: _generateFrame only.  MODE 1: the whole render(): generate, integrate, renderFrame in one pass.
+#ifndef VPT_ISO_WAVES
+#define VPT_ISO_WAVES 7
+#endif
 template <int MODE, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_iso(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(VPT_ISO_WAVES, 8))) k_iso(PassArgs a) {
     if (a.multi_passes > 1u) multi_pass_select(a, a.frame_base, 0); else apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
@@ -148,7 +151,7 @@ VPT_DEV float depth_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, u
     return depth;
 }
 template <int MODE, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) k_depth(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) VPT_WAVES_ATTR(VPT_DEPTH_WAVES) k_depth(PassArgs a) {
     apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
@@ -292,7 +295,7 @@ VPT_DEV uint32_t lao_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, 
 }
 // MODE 0: _generateFrame only.  MODE 1: the whole render(): generate, integrate (copy, LAORenderer.glsl:225-227), renderFrame
 template <int MODE, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) k_lao(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) VPT_WAVES_ATTR(VPT_LAO_WAVES) k_lao(PassArgs a) {
     extern __shared__ float4 lds_raw[];
     __shared__ float pow_table[LAO_POW_TABLE];
     if (threadIdx.x < 64) {                                   // lane l evaluates taps l, l + 64, ...: every lane walks the same u chain
@@ -349,7 +352,7 @@ VPT_DEV void repeat_taps_u(float u, int n, int &i0, int &i1, float &f) {
 }
 // integrate/fragment main(): DOSRenderer.glsl:73-89; vertex :17-23 (vPosition3D = the unprojected (position, uDepth))
 template <int V>
-__global__ void __launch_bounds__(VPT_BLOCK) k_dos_slice(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) VPT_WAVES_ATTR(VPT_DOS_WAVES) k_dos_slice(PassArgs a) {
     extern __shared__ float4 lds_raw[];
     // plain 2-D grid over the tiles of the launch rectangle (row-major buffers: no tile order, no XCD interleave to keep)
     const DosParams &d = a.dos;

@@ -48,7 +48,7 @@ VPT_DEV uint32_t mip_pixel(const PassArgs &a, const LdsTables &t, const Pix &p, 
 // MODE 0: _generateFrame only (frame <- value).  MODE 1: whole render(): generate, integrate
 // (MIPRenderer.glsl:105-109, max on unorm8), renderFrame (:141-144) in one pass.
 template <int MODE, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) k_mip(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) VPT_WAVES_ATTR(VPT_MIP_WAVES) k_mip(PassArgs a) {
     apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
@@ -147,7 +147,7 @@ VPT_DEV uint32_t eam_mix(uint32_t acc, uint32_t frame, float m) {
     return r;
 }
 template <int MODE, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) k_eam(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) VPT_WAVES_ATTR(VPT_EAM_WAVES) k_eam(PassArgs a) {
     apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);
@@ -252,7 +252,7 @@ VPT_DEV float4 mcs_mix(float4 acc, float4 frame, float inv) {   // MCSRenderer.g
                        fmaf(frame.z - acc.z, inv, acc.z), fmaf(frame.w - acc.w, inv, acc.w));
 }
 template <int MODE, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) k_mcs(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) VPT_WAVES_ATTR(VPT_MCS_WAVES) k_mcs(PassArgs a) {
     apply_frame_table(a);
     extern __shared__ float4 lds_raw[];
     LdsTables t = stage_lds<(V & VPT_V_WIDE) != 0>(lds_raw, a);

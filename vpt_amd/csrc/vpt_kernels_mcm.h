@@ -505,13 +505,19 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
 
 #endif
 
+#ifndef VPT_MCM_RG_WAVES
+#define VPT_MCM_RG_WAVES 6
+#endif
+#ifndef VPT_MULTI_WAVES
+#define VPT_MULTI_WAVES 7
+#endif
 #ifndef VPT_MCM_WAVES
 #define VPT_MCM_WAVES 7          // waves per SIMD the integrate kernel is compiled for (72 VGPRs; 8 needs 64: A/B in DESIGN.md section 5)
 #endif
 // integrate/fragment main(): MCMRenderer.glsl:116-172.  FUSE_RENDER additionally performs
 // _renderFrame (MCMRenderer.glsl:204-206) on the radiance it just produced.
 template <bool FUSE_RENDER, int V>
-__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(VPT_MCM_WAVES, 8))) k_mcm_integrate(PassArgs a) {
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu((V & VPT_V_RG) ? VPT_MCM_RG_WAVES : VPT_MCM_WAVES, 8))) k_mcm_integrate(PassArgs a) {
 #ifdef VPT_EVENT_TIMING
     EventClock evc; ev_start(evc);
 #endif
@@ -729,7 +735,7 @@ VPT_DEV void mcm_multi_body(PassArgs &a, uint32_t npasses, uint2 *ring, uint32_t
     store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
 }
 template <int V>
-__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) k_mcm_multi(PassArgs a, uint32_t npasses) {
+__global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(VPT_MULTI_WAVES, 8))) k_mcm_multi(PassArgs a, uint32_t npasses) {
     mcm_multi_body<V, false>(a, npasses, nullptr, 0u);
 }
 // the same with every pass's frame written to the ring: one more live address per lane (and, since the sample's loads are issued in
