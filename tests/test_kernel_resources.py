@@ -14,11 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
 def test_mcm_kernels_use_no_scratch_and_fit_seven_waves():
-    # (the MCM kernels live in their own translation unit: vpt_mcm.hip -> vpt_mcm.s + the compiler's resource remarks in vpt_mcm.resources.txt)
+    # (the MCM kernels live in three translation units: vpt_mcm{,_hit,_seq}.hip -> *.s + the compiler's resource remarks in *.resources.txt)
     csrc = os.path.join(ROOT, "vpt_amd", "csrc")
-    res = subprocess.run(["make", "-C", csrc, "-B", "vpt_mcm.s"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    units = ["vpt_mcm", "vpt_mcm_hit", "vpt_mcm_seq"]
+    res = subprocess.run(["make", "-C", csrc, "-B"] + [u + ".s" for u in units], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert res.returncode == 0, res.stdout.decode()[-2000:]
-    text = open(os.path.join(csrc, "vpt_mcm.resources.txt")).read()
+    text = "".join(open(os.path.join(csrc, u + ".resources.txt")).read() for u in units)
     usage = {}
     cur = None
     for line in text.splitlines():

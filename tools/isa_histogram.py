@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Instruction histogram of a kernel in vpt_amd/csrc/vpt_mcm.s (make -C vpt_amd/csrc asm).
+"""Instruction histogram of a kernel in vpt_amd/csrc/vpt_mcm{_hit,,_seq}.s (make -C vpt_amd/csrc asm).
 
   python tools/isa_histogram.py [mangled-name-substring] [--json out.json]
 
@@ -43,8 +43,9 @@ def main():
     out_json = None
     if "--json" in sys.argv:
         out_json = sys.argv[sys.argv.index("--json") + 1]
-    path = "vpt_amd/csrc/vpt_mcm.s"
-    lines = open(path).read().split("\n")
+    lines = []
+    for unit in ("vpt_mcm_hit", "vpt_mcm", "vpt_mcm_seq"):
+        lines += open("vpt_amd/csrc/%s.s" % unit).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^[A-Za-z_][\w$]*:", l) and want in l.split(":")[0])
     name = lines[start].split(":")[0]
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
@@ -87,7 +88,7 @@ def main():
         return h, other, ops
 
     loop_blocks = [b for b in blocks if b["loop"] == hot]
-    res = {"kernel": name, "source": path, "cost_model_cycles_per_wave_instruction": COST, "event_loop_header": hot}
+    res = {"kernel": name, "source": "vpt_amd/csrc/vpt_mcm{_hit,,_seq}.s", "cost_model_cycles_per_wave_instruction": COST, "event_loop_header": hot}
     for key, bl in (("whole_kernel_static", blocks), ("event_loop_static", loop_blocks)):
         h, other, ops = hist(bl)
         res[key] = {"valu_by_class": h, "valu_total": sum(h.values()), "other": other,

@@ -1,12 +1,14 @@
 // vpt_internal.h — what the translation units of libvpt_hip.so share: the objects behind the C-ABI handles (include/vpt.h), the
 // error plumbing and the launch helpers.  Translation units (Makefile; built in parallel, linked into one library):
 //   vpt_core.hip    context, volume (upload, re-layout), renderer life cycle, tile classification, options, read-back, probes
-//   vpt_mcm.hip     the MCM passes (vpt_kernels_mcm.h): general kernel, tile classes, bucket kernels, frame sequences in one launch
+//   vpt_mcm.hip     the MCM passes (vpt_kernels_mcm.h): tile classes, bucket kernels, reset / render / materialise
+//   vpt_mcm_hit.hip the MCM integrate kernels of every variant (k_mcm_integrate*), handed to vpt_mcm.hip by variant (vpt_mcm_select.h)
+//   vpt_mcm_seq.hip MCM frame sequences in one launch (k_mcm_multi, k_mcm_frames)
 //   vpt_march.hip   MIP, EAM, MCS passes (vpt_kernels_march.h)
 //   vpt_extra.hip   ISO, Depth, LAO, DOS passes (vpt_kernels_iso_depth.h)
 //   vpt_render.hip  the renderer entry points: the four hooks, render(), frame sequences (vpt_renderer_play*)
 //   vpt_post.hip    what follows a frame: tone mappers, the RCCL frame gather
-// Nothing device-side crosses a translation unit: every kernel is launched by the unit that includes its header.
+// Nothing device-side crosses a translation unit: a kernel is compiled by the unit that names it (the three MCM units share one header).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>

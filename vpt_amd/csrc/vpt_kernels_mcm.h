@@ -73,6 +73,7 @@ VPT_DEV void photon_deposit(Photon &ph, f3 rad) {
 }
 
 // reset/fragment main(): MCMRenderer.glsl:259-275 (seeded from the NDC position)
+#ifdef VPT_MCM_PLAIN_KERNELS   // the two non-template kernels are compiled by one translation unit (vpt_mcm.hip)
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
     Pix p = map_pixel(a.pm);
     if (!p.tile) return;
@@ -90,6 +91,7 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_reset(PassArgs a) {
     ((f3 *)a.st2)[p.k] = f3{ 1.0f, 1.0f, 1.0f };
     a.st3[p.k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
+#endif
 
 // the `steps` delta-tracking events of one pixel on its persistent photon: MCMRenderer.glsl:128-166
 // sampleVolumeColor of an event.  The reference samples BEFORE its bounds test (MCMRenderer.glsl:132-142), so the sample of an
@@ -833,9 +835,11 @@ k_mcm_bucket_miss(PassArgs a, FrameSeeds fs, uint32_t nframes, void *ring, uint3
     a.st3[p.k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
     if (a.render) store_frame_texel(&a.render[(size_t)p.l * a.pm.W + p.i], pack_half4(ph.radiance.x, ph.radiance.y, ph.radiance.z, 1.0f));
 }
+#ifdef VPT_MCM_PLAIN_KERNELS
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcm_render(PassArgs a) {   // MCMRenderer.glsl:204-206
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;
     float4 r = a.st3[p.k];
     a.render[(size_t)p.l * a.pm.W + p.i] = pack_half4(r.x, r.y, r.z, 1.0f);
 }
+#endif

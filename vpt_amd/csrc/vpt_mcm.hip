@@ -1,15 +1,11 @@
-// vpt_mcm.hip — the MCM renderer's passes (vpt_kernels_mcm.h) behind vpt_render.hip's entry points: the general kernel, the tile
-// classes (HIT | MISS kernels on two streams), the bucket kernels and frame sequences in one launch.  MCMRenderer.js:85-199.
-#include "vpt_internal.h"
+// vpt_mcm.hip — the MCM renderer's passes (vpt_kernels_mcm.h) behind vpt_render.hip's entry points: the tile classes (HIT | MISS kernels
+// on two streams), the bucket kernels, reset / render / materialise.  The integrate kernels themselves are compiled in vpt_mcm_hit.hip, the
+// frame sequences in one launch in vpt_mcm_seq.hip (three translation units: the build is parallel).  MCMRenderer.js:85-199.
+#include "vpt_mcm_select.h"
+#define VPT_MCM_PLAIN_KERNELS
 #include "vpt_kernels_mcm.h"
 
-#define K_MCM0(V) (k_mcm_integrate<false, V>)
-#define K_MCM1(V) (k_mcm_integrate<true, V>)
-#define K_MCM0F(V) (k_mcm_integrate<false, V | VPT_V_FAST>)
-#define K_MCM1F(V) (k_mcm_integrate<true, V | VPT_V_FAST>)
-
 // ---- MCM passes over the tile classes ---------------------------------------------------------------------------------
-typedef void (*PassKernel)(PassArgs);
 #ifdef VPT_EVENT_TIMING
 #define VPT_TIMING_ARG(part, hit) do { if (hit) (part).violations = timing; } while (0)
 #else
@@ -25,23 +21,6 @@ static unsigned long long *timing_buffer(vpt_renderer *r) {
     return g_timing;
 }
 #endif
-// the sampler variant of the tile-class kernels (LINEAR one-channel byte volumes): VPT_V_WIDE | VPT_V_FAST | VPT_V_REC
-static int class_variant(const vpt_renderer *r, const PassArgs &a) {
-    return (variant_of(r) & VPT_V_WIDE) | (r->fast_math ? VPT_V_FAST : 0) | (a.vol.records ? VPT_V_REC : 0);
-}
-#define VARIANT_CASES(...) switch (v) { \
-        case 0: { constexpr int V = 0; return __VA_ARGS__; } \
-        case VPT_V_WIDE: { constexpr int V = VPT_V_WIDE; return __VA_ARGS__; } \
-        case VPT_V_FAST: { constexpr int V = VPT_V_FAST; return __VA_ARGS__; } \
-        case VPT_V_FAST | VPT_V_WIDE: { constexpr int V = VPT_V_FAST | VPT_V_WIDE; return __VA_ARGS__; } \
-        case VPT_V_REC: { constexpr int V = VPT_V_REC; return __VA_ARGS__; } \
-        case VPT_V_REC | VPT_V_WIDE: { constexpr int V = VPT_V_REC | VPT_V_WIDE; return __VA_ARGS__; } \
-        case VPT_V_REC | VPT_V_FAST: { constexpr int V = VPT_V_REC | VPT_V_FAST; return __VA_ARGS__; } \
-        default: { constexpr int V = VPT_V_REC | VPT_V_FAST | VPT_V_WIDE; return __VA_ARGS__; } }
-template <bool FUSE> static PassKernel hit_kernel(int v, bool early) {
-    if (early) VARIANT_CASES((PassKernel)k_mcm_integrate_early<FUSE, V>)
-    VARIANT_CASES((PassKernel)k_mcm_integrate<FUSE, V>)
-}
 static bool mcm_classes_usable(const vpt_renderer *r, const PassArgs &a) {
     return r->cls.enabled && r->cls.valid && a.blur == 0.0f && memcmp(r->cls.mvp, a.mvp_inv.m, sizeof(r->cls.mvp)) == 0;
 }
@@ -51,21 +30,6 @@ static bool mcm_classes_runnable(const vpt_renderer *r, const PassArgs &a) {
 }
 // ... and of the bucket kernels (and of the HIT-tile kernel's early form): LINEAR one-channel byte volumes
 static bool mcm_plain_volume(const vpt_renderer *r) { return (variant_of(r) & ~VPT_V_WIDE) == 0; }
-// NEAREST / two-channel / float volumes: the HIT tiles through the general kernel of the volume's variant (from a tile list), the MISS
-// tiles through the one-phase sampler of k_mcm_miss (miss_sample_any)
-#define FORMAT_CASES(...) switch (v & (VPT_V_NEAREST | VPT_V_RG | VPT_V_F32)) { \
-        case VPT_V_NEAREST: { constexpr int F = VPT_V_NEAREST; return __VA_ARGS__; } \
-        case VPT_V_RG: { constexpr int F = VPT_V_RG; return __VA_ARGS__; } \
-        case VPT_V_RG | VPT_V_NEAREST: { constexpr int F = VPT_V_RG | VPT_V_NEAREST; return __VA_ARGS__; } \
-        case VPT_V_F32: { constexpr int F = VPT_V_F32; return __VA_ARGS__; } \
-        case VPT_V_F32 | VPT_V_NEAREST: { constexpr int F = VPT_V_F32 | VPT_V_NEAREST; return __VA_ARGS__; } \
-        case VPT_V_F32 | VPT_V_RG: { constexpr int F = VPT_V_F32 | VPT_V_RG; return __VA_ARGS__; } \
-        default: { constexpr int F = VPT_V_F32 | VPT_V_RG | VPT_V_NEAREST; return __VA_ARGS__; } }
-template <bool FUSE> static PassKernel format_hit_kernel(int v, bool wide, bool fast) {
-    if (wide) { if (fast) FORMAT_CASES((PassKernel)k_mcm_integrate<FUSE, F | VPT_V_WIDE | VPT_V_FAST>) FORMAT_CASES((PassKernel)k_mcm_integrate<FUSE, F | VPT_V_WIDE>) }
-    if (fast) FORMAT_CASES((PassKernel)k_mcm_integrate<FUSE, F | VPT_V_FAST>)
-    FORMAT_CASES((PassKernel)k_mcm_integrate<FUSE, F>)
-}
 template <bool FUSE> static PassKernel format_miss_kernel(int v, bool fast) {
     if (fast) FORMAT_CASES((PassKernel)k_mcm_miss<FUSE, F | VPT_V_FAST, false, true>)
     FORMAT_CASES((PassKernel)k_mcm_miss<FUSE, F, false, true>)
@@ -105,8 +69,8 @@ static int launch_mcm_classes(vpt_renderer *r, const PassArgs &a) {
     // whose pass is one wave per SIMD walking a chain of dependent latencies; else the 7-waves form (VPT_HIT_KERNEL_FORM in the environment overrides)
     const bool plain = mcm_plain_volume(r);
     const bool early = plain && (r->hit_form == 2 || (r->hit_form == 0 && r->cls.n_hit <= 1280));
-    if (plain) kh = hit_kernel<FUSE>(class_variant(r, a), early);
-    else kh = format_hit_kernel<FUSE>(variant_of(r), (variant_of(r) & VPT_V_WIDE) != 0, fast);
+    if (plain) kh = mcm_hit_kernel(FUSE, class_variant(r, a), early);
+    else kh = mcm_format_hit_kernel(FUSE, variant_of(r), (variant_of(r) & VPT_V_WIDE) != 0, fast);
     // the MISS tiles: the sample consumed after the path end (its gather flies under that arithmetic) — whole frame 80.8 -> 79.3-79.7 us
     // fast-math, 96.1 -> 92.8 bit-exact, rank 3 of 8's share 18.4 -> 17.1 bit-exact but 15.8 -> 16.9 fast-math: there the sample is
     // consumed where the shader takes it
@@ -315,13 +279,7 @@ static int launch_mcm_pass(vpt_renderer *r, const PassArgs &a) {
 #ifdef VPT_WITH_PERSISTENT_KERNELS
     if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) { LAUNCH_MCM_PERSIST(FUSE, r, a); return VPT_OK; }
 #endif
-    if (a.vol.records) {                                   // (LINEAR one-channel byte volume: variant_of is 0 or VPT_V_WIDE)
-        const unsigned g_ = (unsigned)r->ntiles;
-        return launch_sampling(hit_kernel<FUSE>(class_variant(r, a), false), r, a, g_);
-    }
-    if (r->fast_math) { if (FUSE) LAUNCH_S(K_MCM1F, r, a); else LAUNCH_S(K_MCM0F, r, a); }
-    else { if (FUSE) LAUNCH_S(K_MCM1, r, a); else LAUNCH_S(K_MCM0, r, a); }
-    return VPT_OK;
+    return mcm_general_pass(r, a, FUSE);
 }
 
 // ---- what vpt_render.hip calls ------------------------------------------------------------------------------------------
@@ -338,53 +296,6 @@ int mcm_render_frame(vpt_renderer *r, const PassArgs &a) {
     LAUNCH(k_mcm_render, r, a, 0);
     return VPT_OK;
 }
-template <typename K>
-static int launch_multi(K kernel, vpt_renderer *r, const PassArgs &a, uint32_t npasses) {
-    size_t lds = lds_bytes(r);
-    if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a, npasses);
-    return VPT_OK;
-}
-template <typename K>
-static int launch_frames(K kernel, vpt_renderer *r, const PassArgs &a, uint32_t npasses, uint2 *ring) {
-    size_t lds = lds_bytes(r);
-    if (lds > 160 * 1024) return fail(VPT_ERR_UNSUPPORTED, "transfer function + volume tables need %zu B of LDS (> 160 KiB)", lds);
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), lds, r->ctx->stream, a, npasses, ring, (uint32_t)((size_t)r->W * r->local_h));
-    return VPT_OK;
-}
-int mcm_multi(vpt_renderer *r, const PassArgs &a, uint32_t npasses, uint2 *ring) {
-    r->tm_valid = false;
-    VPT_TRY(mcm_before_pass(r, a, nullptr));
-    VPT_TRY(mcm_materialize(r));                      // a whole-image kernel: every tile's full photon state
-    if (r->side_busy) VPT_TRY(join_side(r));
-    if (a.vol.records) {                              // column records: LINEAR one-channel byte volumes
-        const int v = class_variant(r, a);
-        VARIANT_CASES(ring ? launch_frames(k_mcm_frames<V>, r, a, npasses, ring) : launch_multi(k_mcm_multi<V>, r, a, npasses))
-    }
-#define MULTI_CASES(F) switch (variant_of(r)) { \
-        case 0: return ring ? launch_frames(k_mcm_frames<0 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<0 | F>, r, a, npasses); \
-        case 1: return ring ? launch_frames(k_mcm_frames<1 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<1 | F>, r, a, npasses); \
-        case 2: return ring ? launch_frames(k_mcm_frames<2 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<2 | F>, r, a, npasses); \
-        case 3: return ring ? launch_frames(k_mcm_frames<3 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<3 | F>, r, a, npasses); \
-        case 8: return ring ? launch_frames(k_mcm_frames<8 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<8 | F>, r, a, npasses); \
-        case 9: return ring ? launch_frames(k_mcm_frames<9 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<9 | F>, r, a, npasses); \
-        case 10: return ring ? launch_frames(k_mcm_frames<10 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<10 | F>, r, a, npasses); \
-        case 11: return ring ? launch_frames(k_mcm_frames<11 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<11 | F>, r, a, npasses); \
-        case 32: return ring ? launch_frames(k_mcm_frames<32 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<32 | F>, r, a, npasses); \
-        case 33: return ring ? launch_frames(k_mcm_frames<33 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<33 | F>, r, a, npasses); \
-        case 34: return ring ? launch_frames(k_mcm_frames<34 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<34 | F>, r, a, npasses); \
-        case 35: return ring ? launch_frames(k_mcm_frames<35 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<35 | F>, r, a, npasses); \
-        case 40: return ring ? launch_frames(k_mcm_frames<40 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<40 | F>, r, a, npasses); \
-        case 41: return ring ? launch_frames(k_mcm_frames<41 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<41 | F>, r, a, npasses); \
-        case 42: return ring ? launch_frames(k_mcm_frames<42 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<42 | F>, r, a, npasses); \
-        default: return ring ? launch_frames(k_mcm_frames<43 | F>, r, a, npasses, ring) : launch_multi(k_mcm_multi<43 | F>, r, a, npasses); }
-    if (r->fast_math) MULTI_CASES(VPT_V_FAST)
-    MULTI_CASES(0)
-#undef MULTI_CASES
-}
-
 #ifdef VPT_EVENT_TIMING
 // instrumented builds only (tools/r04_event_timing.py binds it by name): the HIT-tile kernel's phase clocks summed over its waves since the last
 // call, in 10 ns ticks — [0..4] per event: free path | cell + tables | load flight | blend + transfer function | decision + path end;
