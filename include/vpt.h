@@ -140,6 +140,22 @@ VPT_API int vpt_renderer_destroy(vpt_renderer *r);                              
 VPT_API int vpt_renderer_set_volume(vpt_renderer *r, vpt_volume *vol);               /* setVolume() :94-97 (caller resets) */
 VPT_API int vpt_renderer_set_transfer_function(vpt_renderer *r, const uint8_t *rgba, int width, int height); /* :99-104 */
 VPT_API int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba, int width, int height);       /* RenderingContext.js:90-101,136-141 */
+/* The transfer-function widget's canvas as data (src/js/ui/TransferFunction/TransferFunction.js:110-121, src/glsl/TransferFunction.glsl:32-35):
+ * `count` Gaussian bumps drawn in order into a cleared width x height RGBA8 target with gl.blendFunc(ONE, ONE_MINUS_SRC_ALPHA) —
+ * src = color * exp(-|(position - uv) / size|^2) at the pixel centre uv, dst = src + dst * (1 - src.a), stored as UNORM8 after every
+ * bump like the canvas's own 8-bit buffer — then handed over as texImage2D(canvas) hands it to setTransferFunction
+ * (AbstractRenderer.js:99-104): texel row 0 = the canvas's TOP row (uv.y = 1 - 0.5 / height), and with `unpremultiply` != 0 the colour
+ * divided by alpha again (what a browser does for a premultiplied WebGL canvas when UNPACK_PREMULTIPLY_ALPHA_WEBGL is false, the
+ * reference's case; rounding to nearest).  Contract arithmetic (IEEE sqrt and division, the library's exp): one result on every host.
+ * Parity unpinned: a browser's exp in `precision mediump` and its un-premultiplication are implementation-defined.
+ * rgba_out: width * height * 4 bytes of HOST memory, the layout vpt_renderer_set_transfer_function takes. */
+typedef struct vpt_tf_bump {
+    float x, y;             /* position.x, position.y in [0, 1]^2 (y = 1: the top of the widget = the first texel row) */
+    float sx, sy;           /* size.x, size.y */
+    float r, g, b, a;       /* color */
+} vpt_tf_bump;
+VPT_API int vpt_transfer_function_rasterize(vpt_context *ctx, const vpt_tf_bump *bumps, int count, int width, int height,
+                                            int unpremultiply, uint8_t *rgba_out);
 VPT_API int vpt_renderer_resize(vpt_renderer *r, int width, int height);             /* setResolution() :106-112 (caller resets) */
 
 /* the four hooks; integrate and reset include the DoubleBuffer swap (AbstractRenderer.js:60-76) */

@@ -367,6 +367,16 @@ static napi_value TonemapperRead(napi_env env, napi_callback_info info) {
     return undefined(env);
 }
 
+// transferFunctionRasterize(ctx, bumps: Float32Array [count][8], width, height, unpremultiply, out: Uint8Array [height][width][4])
+static napi_value TransferFunctionRasterize(napi_env env, napi_callback_info info) {
+    napi_value a[6]; vpt_context *c; void *bumps, *dst; size_t nb, nd; int32_t w, h, unpre;
+    if (!get_args(env, info, 6, a) || !get_handle(env, a[0], &c) || !get_bytes(env, a[1], &bumps, &nb) || !get_i32(env, a[2], &w) ||
+        !get_i32(env, a[3], &h) || !get_i32(env, a[4], &unpre) || !get_bytes(env, a[5], &dst, &nd)) return nullptr;
+    if (w < 1 || h < 1 || nd < (size_t)w * (size_t)h * 4) { napi_throw_range_error(env, nullptr, "the output holds width * height * 4 bytes"); return nullptr; }
+    VPT_CHECK(vpt_transfer_function_rasterize(c, (const vpt_tf_bump *)bumps, (int)(nb / sizeof(vpt_tf_bump)), w, h, unpre, (uint8_t *)dst));
+    return undefined(env);
+}
+
 // ---- multi-GPU frame gather ---------------------------------------------------------------------------
 static napi_value GatherUniqueId(napi_env env, napi_callback_info info) {
     (void)info;
@@ -446,6 +456,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     EXPORT("tonemapperSetOption", TonemapperSetOption); CONST(VPT_TONEMAPPER_OPTION_TABLE); CONST(VPT_TONEMAPPER_OPTION_FUSE); CONST(VPT_TONEMAPPER_TABLE_NEVER);
     CONST(VPT_TONEMAPPER_TABLE_ALWAYS); CONST(VPT_TONEMAPPER_TABLE_AUTO);
     EXPORT("tonemapperRender", TonemapperRender); EXPORT("tonemapperRows", TonemapperRows); EXPORT("tonemapperRead", TonemapperRead);
+    EXPORT("transferFunctionRasterize", TransferFunctionRasterize);
     CONST(VPT_TONEMAPPER_ARTISTIC); CONST(VPT_TONEMAPPER_RANGE); CONST(VPT_TONEMAPPER_REINHARD); CONST(VPT_TONEMAPPER_REINHARD2);
     CONST(VPT_TONEMAPPER_UNCHARTED2); CONST(VPT_TONEMAPPER_FILMIC); CONST(VPT_TONEMAPPER_UNREAL); CONST(VPT_TONEMAPPER_ACES);
     CONST(VPT_TONEMAPPER_LOTTES); CONST(VPT_TONEMAPPER_UCHIMURA);

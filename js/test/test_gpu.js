@@ -319,6 +319,30 @@ async function main() {
         try { await mk(new Uint16Array(n * n * n), GL.GL_RED, 33322, 5123).load(); } catch (e) { threw = /Unknown volume datatype/.test(e.message); }
         assert.ok(threw, 'UNSIGNED_SHORT volumes raise the reference error');
     }
+    {   // the transfer-function widget as data: the bump files of tests/golden/tf_bumps_r04.json -> the texels the oracle's restatement makes
+        const crypto = require('crypto');
+        const fx = JSON.parse(require('fs').readFileSync(require('path').join(__dirname, '../../tests/golden/tf_bumps_r04.json'), 'utf8'));
+        for (const [name, entry] of Object.entries(fx.files)) {
+            for (const [key, want] of Object.entries(entry.sha256)) {
+                const [size, form] = key.split('_'), [w, h] = size.split('x').map(Number);
+                const tf = new vpt.TransferFunction(ctx, entry.bumps, w, h);
+                const t = tf.texture(form === 'unpremultiplied');
+                assert.strictEqual(t.width, w); assert.strictEqual(t.height, h); assert.strictEqual(t.data.length, w * h * 4);
+                assert.strictEqual(crypto.createHash('sha256').update(t.data).digest('hex'), want, 'transfer function ' + name + ' ' + key);
+            }
+        }
+        const tf = new vpt.TransferFunction(ctx);
+        assert.strictEqual(tf.addBump(), 0);
+        assert.deepStrictEqual(tf.bumps, fx.files.default_bump.bumps);                 // addBump() defaults (TransferFunction.js:129-144)
+        assert.deepStrictEqual(new vpt.TransferFunction(ctx).loads(tf.dumps()).bumps, tf.bumps);
+        const r = new (vpt.RendererFactory('mip'))(ctx, volume, camera, null, { resolution: { width: W, height: H }, transform, rng: goldenRng() });
+        r.setTransferFunction(tf.value);                                               // what Application.js does with the widget's canvas
+        r.reset(); r.render();
+        r.destroy();
+        let threw = false;
+        try { new vpt.TransferFunction(ctx, [{ size: { x: 0 } }]).texture(); } catch (e) { threw = /zero size/.test(e.message); }
+        assert.ok(threw, 'a bump of zero size is refused');
+    }
     volume.destroy();
     ctx.destroy();
     console.log('js gpu ok');

@@ -7,4 +7,4 @@ module.exports = Object.assign({},
     require('./renderers/MCSRenderer.js'), require('./renderers/MCMRenderer.js'), require('./renderers/ISORenderer.js'),
     require('./renderers/DepthRenderer.js'), require('./renderers/LAORenderer.js'), require('./renderers/DOSRenderer.js'), require('./renderers/RendererFactory.js'),
     require('./tonemappers/AbstractToneMapper.js'), require('./tonemappers/ArtisticToneMapper.js'), require('./tonemappers/RangeToneMapper.js'),
-    require('./tonemappers/CurveToneMappers.js'), require('./tonemappers/ToneMapperFactory.js'), require('./RenderingContext.js'));
+    require('./tonemappers/CurveToneMappers.js'), require('./tonemappers/ToneMapperFactory.js'), require('./RenderingContext.js'), require('./TransferFunction.js'));

@@ -99,6 +99,14 @@ def tonemap(kind, rgba16f, **params):
 _lib = None
 
 
+def tf_rasterize(bumps, width, height, unpremultiply=True):
+    """the transfer-function widget's canvas (vpo_tf_rasterize): bumps [count][8] float32 -> [height][width][4] uint8"""
+    b = np.ascontiguousarray(bumps, dtype=np.float32).reshape(-1, 8)
+    out = np.empty((height, width, 4), dtype=np.uint8)
+    lib().vpo_tf_rasterize(_ptr(b) if len(b) else None, len(b), width, height, 1 if unpremultiply else 0, _ptr(out))
+    return out
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -156,6 +164,7 @@ def lib():
         L.vpo_powf.restype = C.c_float; L.vpo_powf.argtypes = [C.c_float, C.c_float]
         L.vpo_f16_to_f32.restype = C.c_float; L.vpo_f16_to_f32.argtypes = [C.c_uint16]
         L.vpo_tonemap.restype = C.c_int; L.vpo_tonemap.argtypes = [C.c_int, C.POINTER(TonemapParams), P, P, C.c_size_t]
+        L.vpo_tf_rasterize.restype = C.c_int; L.vpo_tf_rasterize.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, P]
         _lib = L
     return _lib
 

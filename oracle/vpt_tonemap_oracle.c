@@ -180,3 +180,42 @@ VPO_API int vpo_tonemap(int kind, const vpo_tonemap_params *p, const uint16_t *s
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * The transfer-function widget's canvas (ui/TransferFunction/TransferFunction.js:110-121: clear, then one full-target draw per bump
+ * with gl.blendFunc(ONE, ONE_MINUS_SRC_ALPHA); glsl/TransferFunction.glsl:32-35: oColor = uColor * exp(-r * r),
+ * r = length((uPosition - vPosition) / uSize), vPosition = the pixel centre in [0, 1]^2), handed over as texImage2D(canvas) does
+ * (AbstractRenderer.js:99-104): texel row 0 = the canvas's top row; `unpremultiply`: the colour divided by alpha again (a premultiplied
+ * WebGL canvas uploaded with UNPACK_PREMULTIPLY_ALPHA_WEBGL = false).  bumps: 8 floats each = position.xy, size.xy, color.rgba.
+ * Parity unpinned: `precision mediump` exp and the browser's un-premultiplication are implementation-defined; this is the restatement
+ * vpt_transfer_function_rasterize is compared with, bit for bit.
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+VPO_API int vpo_tf_rasterize(const float *bumps, int count, int width, int height, int unpremultiply, uint8_t *out) {
+    for (int j = 0; j < height; j++) {
+        for (int i = 0; i < width; i++) {
+            float u = ((float)i + 0.5f) / (float)width;
+            float v = ((float)(height - 1 - j) + 0.5f) / (float)height;
+            uint32_t d[4] = { 0u, 0u, 0u, 0u };
+            for (int k = 0; k < count; k++) {
+                const float *b = bumps + 8 * k;
+                float dx = (b[0] - u) / b[2], dy = (b[1] - v) / b[3];
+                float xx = dx * dx, yy = dy * dy;
+                float r = sqrtf(xx + yy);
+                float e = vpo_expf(-(r * r));
+                float s[4];
+                for (int q = 0; q < 4; q++) s[q] = clamp01(b[4 + q] * e);
+                float k1 = 1.0f - s[3];
+                for (int q = 0; q < 4; q++) {
+                    float t = ((float)d[q] / 255.0f) * k1;
+                    d[q] = to_unorm8(s[q] + t);
+                }
+            }
+            if (unpremultiply) {
+                if (d[3] == 0u) d[0] = d[1] = d[2] = 0u;
+                else for (int q = 0; q < 3; q++) { uint32_t c = (d[q] * 255u + d[3] / 2u) / d[3]; d[q] = c > 255u ? 255u : c; }
+            }
+            for (int q = 0; q < 4; q++) out[((size_t)j * width + i) * 4 + q] = (uint8_t)d[q];
+        }
+    }
+    return 0;
+}

@@ -16,6 +16,7 @@ from .tonemappers import (AbstractToneMapper, ArtisticToneMapper, RangeToneMappe
                           UchimuraToneMapper, ToneMapperFactory)
 from .rendering_context import RenderingContext
 from .animators import CircleAnimator, OrbitCameraAnimator
+from .transfer_function import TransferFunction
 from ._native import VptError
 
 __all__ = [
@@ -25,5 +26,5 @@ __all__ = [
     'AbstractRenderer', 'MIPRenderer', 'EAMRenderer', 'MCSRenderer', 'MCMRenderer', 'ISORenderer', 'DepthRenderer', 'LAORenderer', 'DOSRenderer', 'RendererFactory', 'VptError',
     'AbstractToneMapper', 'ArtisticToneMapper', 'RangeToneMapper', 'ReinhardToneMapper', 'Reinhard2ToneMapper',
     'Uncharted2ToneMapper', 'FilmicToneMapper', 'UnrealToneMapper', 'AcesToneMapper', 'LottesToneMapper',
-    'UchimuraToneMapper', 'ToneMapperFactory', 'RenderingContext', 'CircleAnimator', 'OrbitCameraAnimator',
+    'UchimuraToneMapper', 'ToneMapperFactory', 'RenderingContext', 'CircleAnimator', 'OrbitCameraAnimator', 'TransferFunction',
 ]

@@ -54,7 +54,7 @@ SYMBOLS = [
     "vpt_probe_math", "vpt_probe_sample", "vpt_probe_sample_boundary", "vpt_probe_stream_read", "vpt_probe_assemble_rows",
     "vpt_tonemapper_create", "vpt_tonemapper_destroy", "vpt_tonemapper_resize", "vpt_tonemapper_set_source",
     "vpt_tonemapper_set_source_image", "vpt_tonemapper_render", "vpt_tonemapper_read", "vpt_tonemapper_rows",
-    "vpt_tonemapper_output_device", "vpt_tonemapper_set_option",
+    "vpt_tonemapper_output_device", "vpt_tonemapper_set_option", "vpt_transfer_function_rasterize",
 ]
 
 
@@ -167,6 +167,7 @@ def lib():
         "vpt_tonemapper_set_source": [P, P], "vpt_tonemapper_set_source_image": [P, P, I, I],
         "vpt_tonemapper_render": [P, C.POINTER(TonemapParams)], "vpt_tonemapper_read": [P, P, SZ],
         "vpt_tonemapper_rows": [P, P], "vpt_tonemapper_output_device": [P, P, P], "vpt_tonemapper_set_option": [P, I, I],
+        "vpt_transfer_function_rasterize": [P, P, I, I, I, I, P],
         "vpt_gather_unique_id": [P], "vpt_gather_create": [P, P, I, I, PP], "vpt_gather_destroy": [P],
         "vpt_gather_render": [P, UP], "vpt_gather_synchronize": [P], "vpt_gather_read_frame": [P, P, SZ],
     }

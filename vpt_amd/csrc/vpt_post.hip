@@ -253,6 +253,58 @@ extern "C" int vpt_renderer_play_into_display(vpt_renderer *r, vpt_tonemapper *t
     if (r->kind == VPT_RENDERER_MCM) r->samples_host += r->valid_pixels * (uint64_t)base->steps * (uint64_t)count;
     return VPT_OK;
 }
+// ---------------------------------------------------------------------------------------------
+// the transfer-function widget's canvas (ui/TransferFunction/TransferFunction.js:110-121, glsl/TransferFunction.glsl:32-35) as data:
+// one thread per texel walks the bumps in drawing order; the 8-bit target is re-read between two bumps like the canvas's own buffer
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tf_rasterize(const vpt_tf_bump *bumps, int count, int W, int H, int unpremultiply, uint32_t *out) {
+    const int i = (int)(blockIdx.x * 16u + (threadIdx.x & 15u)), j = (int)(blockIdx.y * 16u + (threadIdx.x >> 4));
+    if (i >= W || j >= H) return;
+    const float u = ((float)i + 0.5f) / (float)W;
+    const float v = ((float)(H - 1 - j) + 0.5f) / (float)H;            // texel row 0 = the top row of the canvas
+    uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;                       // gl.clear: (0, 0, 0, 0)
+    for (int k = 0; k < count; k++) {
+        const vpt_tf_bump b = bumps[k];
+        const float dx = (b.x - u) / b.sx, dy = (b.y - v) / b.sy;
+        const float r = sqrtf(dx * dx + dy * dy);                       // length()
+        const float e = vpt_expf(-(r * r));
+        // a fixed-point target: the fragment's colour is clamped to [0, 1] before the blend, the result again before the store
+        const float s0 = vclamp01(b.r * e), s1 = vclamp01(b.g * e), s2 = vclamp01(b.b * e), s3 = vclamp01(b.a * e);
+        const float k1 = 1.0f - s3;
+        d0 = to_unorm8(s0 + ((float)d0 / 255.0f) * k1); d1 = to_unorm8(s1 + ((float)d1 / 255.0f) * k1);
+        d2 = to_unorm8(s2 + ((float)d2 / 255.0f) * k1); d3 = to_unorm8(s3 + ((float)d3 / 255.0f) * k1);
+    }
+    if (unpremultiply) {
+        if (d3 == 0u) { d0 = d1 = d2 = 0u; }
+        else {
+            d0 = min(255u, (d0 * 255u + d3 / 2u) / d3); d1 = min(255u, (d1 * 255u + d3 / 2u) / d3); d2 = min(255u, (d2 * 255u + d3 / 2u) / d3);
+        }
+    }
+    out[(size_t)j * W + i] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
+}
+extern "C" int vpt_transfer_function_rasterize(vpt_context *c, const vpt_tf_bump *bumps, int count, int width, int height, int unpremultiply,
+                                               uint8_t *rgba_out) {
+    if (!c || !rgba_out || (count > 0 && !bumps)) return fail(VPT_ERR_INVALID, "null argument");
+    if (count < 0 || count > 65536) return fail(VPT_ERR_INVALID, "bump count %d not in [0, 65536]", count);
+    if (width < 1 || height < 1 || width > 16384 || height > 16384) return fail(VPT_ERR_INVALID, "transfer function %d x %d not in [1, 16384]^2", width, height);
+    for (int k = 0; k < count; k++)
+        if (bumps[k].sx == 0.0f || bumps[k].sy == 0.0f) return fail(VPT_ERR_INVALID, "bump %d has a zero size", k);
+    HIP_TRY(hipSetDevice(c->device));
+    vpt_tf_bump *dev_bumps = nullptr; uint32_t *dev_out = nullptr;
+    const size_t nb = (size_t)std::max(count, 1) * sizeof(vpt_tf_bump), no = (size_t)width * height * 4;
+    HIP_TRY(hipMalloc(&dev_bumps, nb));
+    if (hipMalloc(&dev_out, no) != hipSuccess) { hipFree(dev_bumps); return fail(VPT_ERR_HIP, "hipMalloc of %zu bytes failed", no); }
+    int rc = VPT_OK;
+    do {
+        if (count > 0 && hipMemcpyAsync(dev_bumps, bumps, (size_t)count * sizeof(vpt_tf_bump), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(VPT_ERR_HIP, "bump upload failed"); break; }
+        hipLaunchKernelGGL(k_tf_rasterize, dim3((unsigned)((width + 15) / 16), (unsigned)((height + 15) / 16)), dim3(256), 0, c->stream,
+                           dev_bumps, count, width, height, unpremultiply, dev_out);
+        if (hipGetLastError() != hipSuccess) { rc = fail(VPT_ERR_HIP, "k_tf_rasterize launch failed"); break; }
+        if (hipMemcpyAsync(rgba_out, dev_out, no, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(VPT_ERR_HIP, "transfer function read-back failed"); break; }
+    } while (0);
+    hipFree(dev_bumps); hipFree(dev_out);
+    return rc;
+}
 extern "C" int vpt_tonemapper_rows(vpt_tonemapper *t, int *rows) {
     if (!t || !rows) return fail(VPT_ERR_INVALID, "null argument");
     *rows = t->rows ? t->rows : (t->source ? t->source->local_h : t->H);
