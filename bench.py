@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FAST_MATH_BOUNDS = {"max_abs_d_missing": 1e-6, "min_equal_counts_crossing": 0.97, "mean_abs_d_crossing": 8e-6,
                     "p999_abs_d_crossing": 1.2e-3, "max_abs_d_crossing": 2e-3}
 # VPT_OPTION_SPLIT_STREAMS as the library sets it by itself (vpt_core.hip default_split): what a run without --split-streams uses
-DEFAULT_SPLIT = {"mcm": 2, "mip": 3, "eam": 3, "iso": 3, "depth": 3, "mcs": 1, "lao": 1}
+DEFAULT_SPLIT = {"mcm": 2, "mip": 3, "eam": 3, "iso": 2, "depth": 3, "mcs": 2, "lao": 2}
 
 
 def parse():
@@ -245,7 +245,7 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
             out[name] = {"ms_per_frame": t * 1e3, "samples_per_s": ns / t, "bytes_per_sample": b, "frac": b * ns / t / (HBM_PEAK_GBS * 1e9),
                          "tile_classes": tc is None or bool(tc), "streams": sp or DEFAULT_SPLIT["eam"], "options_set": [] if sp is None else ["split_streams", "tile_classes"]}
         g256.destroy()
-        for name, sp in (("C3_mcs_512_1080p", None), ("C3_mcs_512_1080p_three_streams", 3)):
+        for name, sp in (("C3_mcs_512_1080p", None), ("C3_mcs_512_1080p_one_stream", 1)):
             t, ns = run('mcs', gvol512, split=sp)
             # algorithmic bytes per sample: 8 + 48 B of frame / accumulator traffic per pixel and pass — priced on the pixels a
             # pass actually LAUNCHES (after the first frame: the HIT tiles only; round 3 charged all W x H pixels for traffic not performed)
@@ -255,6 +255,28 @@ def other_configs(ctx, gvol512, vol512, args, W, H, torch):
             out[name] = {"ms_per_frame": t * 1e3, "ms_per_256_spp": t * 256e3, "samples_per_s": ns / t, "samples_per_pixel_per_frame": ns / (W * H),
                          "pixels_launched_per_frame": launched, "hit_tiles": tiles[0] if tiles else None, "miss_tiles": tiles[1] if tiles else None,
                          "bytes_per_sample": b, "frac": b * ns / t / (HBM_PEAK_GBS * 1e9), "streams": sp or DEFAULT_SPLIT["mcs"]}
+        # C3 asks for the image after 256 samples per pixel, not for its 256 intermediate frames: vpt_renderer_play(16, VPT_PLAY_FUSED) runs 16
+        # passes per launch with the running mean in registers and writes the render buffer after the 16th — bit-identical to 16 render()
+        # calls (tests/test_gpu_parity.py frame sequences); the frame-by-frame rows above are what the reference's own loop does
+        r = vpt_amd.RendererFactory('mcs')(ctx, gvol512, default_camera(W / H), None, {'resolution': (W, H), 'transform': Transform(Node()), 'rng': GoldenRatioRng()})
+        r.reset()
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.3:
+            r.play(16, fused=True)
+            ctx.synchronize()
+        blocks = []
+        for _ in range(3):
+            r.clear_sample_count()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(16):
+                r.play(16, fused=True)
+            ctx.synchronize()
+            blocks.append((time.perf_counter() - t0, r.sample_count()))
+        dt, ns = sorted(blocks)[1]
+        r.destroy()
+        out["C3_mcs_512_1080p_256_spp_in_16_launches"] = {"ms_per_256_spp": dt * 1e3, "ms_per_pass": dt / 256 * 1e3, "samples_per_s": ns / dt, "passes_per_launch": 16,
+                                                          "note": "the converged image C3 names, without its intermediate frames: 16 passes per launch, one render-buffer write per launch"}
         n = 1024
         v = np.empty((n, n, n), dtype=np.uint8)
 

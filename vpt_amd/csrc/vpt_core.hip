@@ -410,14 +410,17 @@ extern "C" int vpt_renderer_set_environment(vpt_renderer *r, const uint8_t *rgba
 }
 // VPT_OPTION_SPLIT_STREAMS as the library sets it itself (round 4: the measured best form is the default, not an option a caller has to know).
 // MCM: the HIT | MISS kernels of the tile classes need two streams (1080p headline frame 80 us against 108 for the general kernel on one).
-// MIP, EAM, ISO, Depth: three ranges on three streams (EAM 256^3 63.6 -> 52.0 us, MIP 56.2 -> 45.0, ISO 60.6 -> 56.9, Depth 62.3 -> 57.0).
-// MCS, LAO: one (unmeasured gains; the MCS pass is 16 us).  DOS cannot split.  VPT_DEFAULT_SPLIT=1 in the environment: one stream everywhere.
+// MIP, EAM, Depth: three ranges on three streams (EAM 256^3 60.0 -> 48.4 us, MIP 50.5 -> 41.3, Depth 55.5 -> 46.7; two: 50.2 / 41.9 / 47.8).
+// ISO: two (512^3: 47.0 -> 41.3 us, 256^3: 41.6 -> 42.2; three: 43.6 / 46.2 — its 7-sample shading of the few surface pixels does not balance).
+// MCS, LAO: two (MCS 512^3 1080p 16.1 -> 13.8 us, extinction 50: 158 -> 124, extinction 200: 435 -> 358, 1024^3: 19.4 -> 16.6; LAO 2.11 -> 1.73 ms;
+// three or four streams are no better and less stable from box to box).  DOS cannot split.  VPT_DEFAULT_SPLIT=1 in the environment: one stream everywhere.
 static int default_split(int kind) {
     static const bool one = []() { const char *e = getenv("VPT_DEFAULT_SPLIT"); return e && e[0] == '1' && !e[1]; }();
     if (one) return 1;
     switch (kind) {
         case VPT_RENDERER_MCM: return 2;
-        case VPT_RENDERER_MIP: case VPT_RENDERER_EAM: case VPT_RENDERER_ISO: case VPT_RENDERER_DEPTH: return 3;
+        case VPT_RENDERER_MIP: case VPT_RENDERER_EAM: case VPT_RENDERER_DEPTH: return 3;
+        case VPT_RENDERER_ISO: case VPT_RENDERER_MCS: case VPT_RENDERER_LAO: return 2;
         default: return 1;
     }
 }
