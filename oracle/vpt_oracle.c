@@ -10,9 +10,16 @@
  * (texture filtering, unorm8 / half-float render-target conversion).  Each function
  * cites the reference file:line (relative to /root/reference) it follows.
  *
- * PARITY STATUS: "parity unpinned" by the reference's own tests — the reference ships
- * no tests, golden images or fixtures for this path (package.json:9), and its GLSL cannot
- * execute in this container (no WebGL2 / GLSL compiler).  What IS pinned:
+ * PARITY STATUS: the reference ships no tests, golden images or fixtures for this path
+ * (package.json:9) and no WebGL2 driver exists in this container, so no GPU run of the
+ * reference pins this file.  Since round 4 it is pinned by the reference's own shader
+ * TEXT, executed: oracle/glsl_interp.py interprets src/glsl/renderers/*.glsl and
+ * src/glsl/tonemappers/*.glsl as read from the reference tree (tests/golden/
+ * make_glsl_fixtures.py -> tests/golden/glsl_r04.json) and tests/test_glsl_reference.py
+ * holds this oracle to the results — MIP, EAM and the tone mappers byte for byte, MCS /
+ * ISO / Depth within rounding with identical control flow, MCM with identical photon
+ * histories.  Where WebGL leaves the rounding to the implementation the interpreter rounds
+ * as the contract below does.  Also pinned:
  *   - the inverse-MVP recipe, against outputs of the reference's vendored gl-matrix 3.4.1
  *     run under node (tests/golden/mvp_inverse.json, made by tests/golden/make_mvp_fixture.js);
  *   - the PCG hash / squash / uniform chain, against known answers (tests/golden/pcg_kat.json);

@@ -1,0 +1,311 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/glsl_r04.json: what THE REFERENCE'S OWN SHADER TEXT computes on small scenes, fragment by fragment.
+
+The shader files are read from the reference tree at generation time (default /root/reference/src/glsl; they are never copied into this
+repository), cooked as src/js/WebGL.js:85-99 cooks them (`@mixin` substitution) and executed by oracle/glsl_interp.py — vertex stage at the
+three corners of the full-screen triangle, fragment stage at every pixel — with the uniforms the reference's renderers upload
+(src/js/renderers/*Renderer.js, cited per program below) and the framebuffer formats their buffer specs name (values are stored the way
+the attachment stores them: UNORM8 rounding, half floats, floats).  The fixture holds the scenes (volume, transfer function, environment,
+matrix, per-frame uniforms) and every buffer after every frame.  tests/test_glsl_reference.py holds oracle/vpt_oracle.c to it.
+
+Implementation-defined in WebGL and fixed here as the numeric contract fixes them: fp32 without contraction, IEEE division and sqrt, the
+contract's log / exp / sin / cos / atan / asin, fp32 texture filtering, exact interpolation of the (affine) varyings."""
+import argparse
+import base64
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import glsl_interp as G
+from vpt_amd.scene import Node, Transform, PerspectiveCamera, quat, mvp_inverse_matrix
+
+F = np.float32
+
+
+# ---- scene pieces ------------------------------------------------------------------------------------------------------------
+def make_volume(dims, seed):
+    rng = np.random.default_rng(seed)
+    nz, ny, nx = dims
+    z, y, x = np.meshgrid(np.linspace(-1, 1, nz), np.linspace(-1, 1, ny), np.linspace(-1, 1, nx), indexing="ij")
+    v = 235.0 * np.clip(1.15 - np.sqrt(x * x + 0.8 * y * y + 1.3 * z * z), 0, 1) + rng.normal(0, 14, size=dims)
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def make_tf(width, seed):
+    rng = np.random.default_rng(seed)
+    tf = rng.integers(0, 256, size=(1, width, 4), dtype=np.uint8)
+    tf[0, :, 3] = np.clip(np.linspace(0, 255, width) + rng.normal(0, 20, size=width), 0, 255).astype(np.uint8)
+    tf[0, 0, 3] = 0
+    return tf
+
+
+def srgb_to_linear(byte):
+    c = byte / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
+def volume_sampler(vol, linear=True):          # R8: texture() returns (r, 0, 0, 1)  (OpenGL ES 3.0 table 3.12)
+    t = np.zeros(vol.shape + (4,), np.float32)
+    t[..., 0] = vol.astype(np.float32) / np.float32(255.0)
+    t[..., 3] = 1.0
+    return G.Sampler(t, linear)
+
+
+def tf_sampler(tf):                             # SRGB8_ALPHA8, LINEAR (AbstractRenderer.js:31-44, 99-104): rgb decoded, alpha linear
+    t = np.zeros(tf.shape, np.float32)
+    t[..., :3] = srgb_to_linear(tf[..., :3].astype(np.float64)).astype(np.float32)
+    t[..., 3] = tf[..., 3].astype(np.float32) / np.float32(255.0)
+    return G.Sampler(t, True)
+
+
+def env_sampler(env):                           # RGBA8, LINEAR (RenderingContext.js:90-101)
+    return G.Sampler(env.astype(np.float32) / np.float32(255.0), True)
+
+
+def state_sampler(buf):                         # an attachment read back at pixel centres (NEAREST): [h][w][4] float32, row 0 = bottom
+    return G.Sampler(buf, False)
+
+
+def camera_matrix(aspect, yaw, pitch, dist, fovy=1.0):
+    node = Node()
+    import math
+    qy = quat.setAxisAngle(quat.create(), [0, 1, 0], yaw)
+    qx = quat.setAxisAngle(quat.create(), [1, 0, 0], pitch)
+    node.transform.localRotation = quat.multiply(quat.create(), qy, qx)
+    cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+    node.transform.localTranslation = [dist * sy * cp, -dist * sp, dist * cy * cp]
+    cam = PerspectiveCamera(node, {'fovy': fovy, 'aspect': aspect, 'near': 0.1, 'far': 100.0})
+    node.components.append(cam)
+    return np.asarray(mvp_inverse_matrix(node, Transform(Node())), dtype=np.float32).reshape(16)
+
+
+# ---- attachment formats ------------------------------------------------------------------------------------------------------------
+def store_unorm8(x):
+    x = np.asarray(x, np.float32)
+    x = np.where(np.isnan(x), np.float32(0), x)
+    return (np.rint(np.clip(x, 0, 1) * np.float32(255.0)) / np.float32(255.0)).astype(np.float32)
+
+
+def store_f16(x):
+    with np.errstate(over="ignore"):
+        return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def store_f32(x):
+    return np.asarray(x, np.float32)
+
+
+def b64(a):
+    return base64.b64encode(np.ascontiguousarray(a).tobytes()).decode()
+
+
+def comps(v, n):
+    """the first n components an attachment keeps of a fragment output"""
+    if isinstance(v, G.Vec):
+        c = [float(x) for x in v.c]
+    else:
+        c = [float(v)]
+    return (c + [0.0, 0.0, 0.0, 1.0][len(c):])[:n] if len(c) < n else c[:n]
+
+
+def run_pass(prog, uniforms, W, H, outputs, progress=None):
+    """one full-screen draw: {output name: [H][W][4] float32 (unstored values)}"""
+    corners = prog.varyings(uniforms)
+    res = {o: np.zeros((H, W, 4), np.float32) for o in outputs}
+    for j in range(H):
+        for i in range(W):
+            out = prog.fragment(uniforms, corners, i, j, W, H)
+            for o in outputs:
+                v = comps(out[o], 4)
+                res[o][j, i] = v
+        if progress:
+            progress(j)
+    return res
+
+
+# ---- the renderers ------------------------------------------------------------------------------------------------------------
+def gen_mip(parts, sc, frames):
+    """MIPRenderer.js:70-131 (generate: uStepSize = 1 / steps, uOffset = random; integrate: max; render), buffers R8 (MIPRenderer.js:133-157)"""
+    W, H = sc["W"], sc["H"]
+    P = {k: G.Program(parts, "/glsl/shaders/renderers/MIP/" + k) for k in ("generate", "integrate", "render", "reset")}
+    base = {"uVolume": sc["vol_s"], "uTransferFunction": sc["tf_s"], "uMvpInverseMatrix": G.mat4(sc["matrix"])}
+    acc = store_unorm8(run_pass(P["reset"], base, W, H, ["oColor"])["oColor"])
+    out = {"reset": {"acc": b64(acc[..., 0])}, "frames": []}
+    for fr in frames:
+        u = dict(base, uStepSize=F(fr["step"]), uOffset=F(fr["offset"]))
+        frame = store_unorm8(run_pass(P["generate"], u, W, H, ["oColor"])["oColor"])
+        u2 = dict(base, uAccumulator=state_sampler(acc), uFrame=state_sampler(frame))
+        acc = store_unorm8(run_pass(P["integrate"], u2, W, H, ["oColor"])["oColor"])
+        img = store_f16(run_pass(P["render"], dict(base, uAccumulator=state_sampler(acc)), W, H, ["oColor"])["oColor"])
+        out["frames"].append({"frame": b64(frame[..., 0]), "acc": b64(acc[..., 0]), "image": b64(img)})
+    return out
+
+
+def gen_eam(parts, sc, frames):
+    """EAMRenderer.js:92-153 (uStepSize = 1 / slices, uExtinction, uOffset; integrate: uMix = 1 / frameNumber), buffers RGBA8 (:155-179)"""
+    W, H = sc["W"], sc["H"]
+    P = {k: G.Program(parts, "/glsl/shaders/renderers/EAM/" + k) for k in ("generate", "integrate", "render", "reset")}
+    base = {"uVolume": sc["vol_s"], "uTransferFunction": sc["tf_s"], "uMvpInverseMatrix": G.mat4(sc["matrix"])}
+    acc = store_unorm8(run_pass(P["reset"], base, W, H, ["oColor"])["oColor"])
+    out = {"reset": {"acc": b64(acc)}, "frames": []}
+    for fr in frames:
+        u = dict(base, uStepSize=F(fr["step"]), uOffset=F(fr["offset"]), uExtinction=F(fr["extinction"]))
+        frame = store_unorm8(run_pass(P["generate"], u, W, H, ["oColor"])["oColor"])
+        u2 = dict(base, uAccumulator=state_sampler(acc), uFrame=state_sampler(frame), uMix=F(fr["mix"]))
+        acc = store_unorm8(run_pass(P["integrate"], u2, W, H, ["oColor"])["oColor"])
+        img = store_f16(run_pass(P["render"], dict(base, uAccumulator=state_sampler(acc)), W, H, ["oColor"])["oColor"])
+        out["frames"].append({"frame": b64(frame), "acc": b64(acc), "image": b64(img)})
+    return out
+
+
+def gen_mcs(parts, sc, frames):
+    """MCSRenderer.js:80-153 (uRandSeed, uExtinction, uScatteringDirection; integrate: uInvFrameNumber), buffers RGBA32F (:156-180)"""
+    W, H = sc["W"], sc["H"]
+    P = {k: G.Program(parts, "/glsl/shaders/renderers/MCS/" + k) for k in ("generate", "integrate", "render", "reset")}
+    base = {"uVolume": sc["vol_s"], "uTransferFunction": sc["tf_s"], "uEnvironment": sc["env_s"], "uMvpInverseMatrix": G.mat4(sc["matrix"])}
+    acc = store_f32(run_pass(P["reset"], base, W, H, ["oColor"])["oColor"])
+    out = {"reset": {"acc": b64(acc)}, "frames": []}
+    for fr in frames:
+        u = dict(base, uRandSeed=F(fr["seed"]), uExtinction=F(fr["extinction"]), uScatteringDirection=G.vec(*fr["light"]))
+        frame = store_f32(run_pass(P["generate"], u, W, H, ["oColor"])["oColor"])
+        u2 = dict(base, uAccumulator=state_sampler(acc), uFrame=state_sampler(frame), uInvFrameNumber=F(fr["mix"]))
+        acc = store_f32(run_pass(P["integrate"], u2, W, H, ["oColor"])["oColor"])
+        img = store_f16(run_pass(P["render"], dict(base, uAccumulator=state_sampler(acc)), W, H, ["oColor"])["oColor"])
+        out["frames"].append({"frame": b64(frame), "acc": b64(acc), "image": b64(img)})
+    return out
+
+
+def gen_mcm(parts, sc, frames):
+    """MCMRenderer.js:85-199 (reset + integrate: uInverseResolution, uRandSeed, uBlur = 0, uExtinction, uAnisotropy, uMaxBounces, uSteps),
+    four RGBA32F attachments (:214-263)"""
+    W, H = sc["W"], sc["H"]
+    P = {k: G.Program(parts, "/glsl/shaders/renderers/MCM/" + k) for k in ("integrate", "render", "reset")}
+    names = ["oPosition", "oDirection", "oTransmittance", "oRadiance"]
+    base = {"uVolume": sc["vol_s"], "uTransferFunction": sc["tf_s"], "uEnvironment": sc["env_s"], "uMvpInverseMatrix": G.mat4(sc["matrix"]),
+            "uInverseResolution": G.vec(F(1.0) / F(W), F(1.0) / F(H)), "uBlur": F(0.0)}
+    r = run_pass(P["reset"], dict(base, uRandSeed=F(sc["reset_seed"])), W, H, names)
+    state = [store_f32(r[n]) for n in names]
+    out = {"reset": {"state": [b64(s) for s in state]}, "frames": []}
+    for fr in frames:
+        u = dict(base, uRandSeed=F(fr["seed"]), uExtinction=F(fr["extinction"]), uAnisotropy=F(fr["anisotropy"]),
+                 uMaxBounces=G.UInt(fr["max_bounces"]), uSteps=G.UInt(fr["steps"]),
+                 uPosition=state_sampler(state[0]), uDirection=state_sampler(state[1]), uTransmittance=state_sampler(state[2]), uRadiance=state_sampler(state[3]))
+        r = run_pass(P["integrate"], u, W, H, names)
+        state = [store_f32(r[n]) for n in names]
+        img = store_f16(run_pass(P["render"], dict(base, uColor=state_sampler(state[3])), W, H, ["oColor"])["oColor"])
+        out["frames"].append({"state": [b64(s) for s in state], "image": b64(img)})
+    return out
+
+
+def gen_iso(parts, sc, frames):
+    """ISORenderer.js (generate: uSteps, uOffset, uIsovalue; integrate: closest hit; render: uLight, uGradientStep), closest = RGBA16F"""
+    W, H = sc["W"], sc["H"]
+    P = {k: G.Program(parts, "/glsl/shaders/renderers/ISO/" + k) for k in ("generate", "integrate", "render", "reset")}
+    base = {"uVolume": sc["vol_s"], "uTransferFunction": sc["tf_s"], "uMvpInverseMatrix": G.mat4(sc["matrix"])}
+    acc = store_f16(run_pass(P["reset"], base, W, H, ["oClosest"])["oClosest"])
+    out = {"reset": {"acc": b64(acc)}, "frames": []}
+    for fr in frames:
+        u = dict(base, uSteps=G.UInt(fr["steps"]), uOffset=F(fr["offset"]), uIsovalue=F(fr["isovalue"]))
+        frame = store_f16(run_pass(P["generate"], u, W, H, ["oClosest"])["oClosest"])
+        acc = store_f16(run_pass(P["integrate"], dict(base, uAccumulator=state_sampler(acc), uFrame=state_sampler(frame)), W, H, ["oClosest"])["oClosest"])
+        u3 = dict(base, uClosest=state_sampler(acc), uLight=G.vec(*fr["light"]), uGradientStep=F(fr["gradient_step"]))
+        img = store_f16(run_pass(P["render"], u3, W, H, ["oColor"])["oColor"])
+        out["frames"].append({"frame": b64(frame), "acc": b64(acc), "image": b64(img)})
+    return out
+
+
+def gen_depth(parts, sc, frames):
+    """DepthRenderer.js (generate: uStepSize, uOffset, uExtinction, uThreshold; integrate: uMix), buffers R32F"""
+    W, H = sc["W"], sc["H"]
+    P = {k: G.Program(parts, "/glsl/shaders/renderers/DepthRenderer/" + k) for k in ("generate", "integrate", "render", "reset")}
+    base = {"uVolume": sc["vol_s"], "uTransferFunction": sc["tf_s"], "uMvpInverseMatrix": G.mat4(sc["matrix"])}
+    acc = store_f32(run_pass(P["reset"], base, W, H, ["oColor"])["oColor"])
+    out = {"reset": {"acc": b64(acc[..., 0])}, "frames": []}
+    for fr in frames:
+        u = dict(base, uStepSize=F(fr["step"]), uOffset=F(fr["offset"]), uExtinction=F(fr["extinction"]), uThreshold=F(fr["threshold"]))
+        frame = store_f32(run_pass(P["generate"], u, W, H, ["oDepth"])["oDepth"])
+        u2 = dict(base, uAccumulator=state_sampler(acc), uFrame=state_sampler(frame), uMix=F(fr["mix"]))
+        acc = store_f32(run_pass(P["integrate"], u2, W, H, ["oColor"])["oColor"])
+        img = store_f16(run_pass(P["render"], dict(base, uAccumulator=state_sampler(acc)), W, H, ["oColor"])["oColor"])
+        out["frames"].append({"frame": b64(frame[..., 0]), "acc": b64(acc[..., 0]), "image": b64(img)})
+    return out
+
+
+TONEMAPPERS = ["Artistic", "Range", "Reinhard", "Reinhard2", "Uncharted2", "Filmic", "Unreal", "Aces", "Lottes", "Uchimura"]
+
+
+def gen_tonemappers(parts, image, params):
+    """src/js/tonemappers/*ToneMapper.js _renderFrame(): uTexture + the operator's uniforms; output RGBA8"""
+    H, W = image.shape[:2]
+    out = {}
+    for name in TONEMAPPERS:
+        prog = G.Program(parts, "/glsl/shaders/tonemappers/%sToneMapper" % name)
+        u = {"uTexture": state_sampler(image)}
+        fs_uniforms = {d[3] for d in prog.fs.globals_decl if "uniform" in d[1]}
+        for k, v in params.items():
+            if k in fs_uniforms:
+                u[k] = F(v)
+        missing = fs_uniforms - set(u)
+        if missing:
+            raise SystemExit("tone mapper %s: uniforms %s not provided" % (name, sorted(missing)))
+        r = run_pass(prog, u, W, H, ["oColor"])["oColor"]
+        out[name] = {"uniforms": sorted(fs_uniforms - {"uTexture"}), "rgba8": b64((store_unorm8(r) * 255.0 + 0.5).astype(np.uint8))}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--glsl", default="/root/reference/src/glsl")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "glsl_r04.json"))
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    parts = G.read_parts(args.glsl)
+    W, H = 20, 14
+    dims = (9, 11, 13)
+    vol = make_volume(dims, 3)
+    tf = make_tf(8, 4)
+    env = np.random.default_rng(5).integers(40, 256, size=(3, 4, 4), dtype=np.uint8)
+    matrix = camera_matrix(W / H, 0.55, -0.3, 1.75)
+    sc = {"W": W, "H": H, "matrix": matrix, "vol_s": volume_sampler(vol), "tf_s": tf_sampler(tf), "env_s": env_sampler(env), "reset_seed": 0.6180339887}
+    fixture = {"_what": __doc__.strip().split("\n\n")[0].replace("\n", " "),
+               "scene": {"width": W, "height": H, "volume_dims_zyx": list(dims), "volume_u8": b64(vol), "tf_rgba8": b64(tf), "tf_shape": list(tf.shape),
+                         "env_rgba8": b64(env), "env_shape": list(env.shape), "mvp_inverse_f32": b64(matrix), "filter": "linear", "mcm_reset_seed": sc["reset_seed"]},
+               "renderers": {}}
+    if os.path.exists(args.out) and args.only:
+        fixture = json.load(open(args.out))
+    seeds = [0.3819660113, 0.7639320225, 0.1458980338]
+    plans = {
+        "mip": (gen_mip, [{"step": 1.0 / 24, "offset": s} for s in seeds[:2]]),
+        "eam": (gen_eam, [{"step": 1.0 / 20, "offset": s, "extinction": 40.0, "mix": 1.0 / (k + 1)} for k, s in enumerate(seeds[:2])]),
+        "mcs": (gen_mcs, [{"seed": s, "extinction": 12.0, "light": l, "mix": 1.0 / (k + 1)}
+                          for k, (s, l) in enumerate(zip(seeds, ([0.3, 0.5, 0.8124038], [-0.6, 0.64, 0.48], [0.0, -1.0, 0.0])))]),
+        "mcm": (gen_mcm, [{"seed": s, "extinction": 9.0, "anisotropy": g, "max_bounces": 8, "steps": 6} for s, g in zip(seeds, (0.0, 0.35, -0.5))]),
+        "iso": (gen_iso, [{"steps": 24, "offset": s, "isovalue": 0.25, "light": [0.48, 0.6, 0.64], "gradient_step": 0.02} for s in seeds[:2]]),
+        "depth": (gen_depth, [{"step": 1.0 / 24, "offset": s, "extinction": 60.0, "threshold": 0.3, "mix": 1.0 / (k + 1)} for k, s in enumerate(seeds[:2])]),
+    }
+    for name, (fn, frames) in plans.items():
+        if args.only and name not in args.only.split(","):
+            continue
+        t0 = time.time()
+        r = fn(parts, sc, frames)
+        r["uniforms_per_frame"] = frames
+        fixture["renderers"][name] = r
+        print("%s: %d frames in %.1f s" % (name, len(frames), time.time() - t0), flush=True)
+    if not args.only or "tonemappers" in args.only.split(","):
+        rng = np.random.default_rng(9)
+        img = np.concatenate([rng.uniform(0, 1.2, size=(4, 8, 4)), rng.uniform(0, 6, size=(2, 8, 4)), np.zeros((1, 8, 4)), np.ones((1, 8, 4))]).astype(np.float16).astype(np.float32)
+        params = {"uLow": 0.05, "uMid": 0.4, "uHigh": 0.9, "uSaturation": 0.7, "uMin": 0.1, "uMax": 0.8, "uExposure": 1.3, "uGamma": 2.2}
+        t0 = time.time()
+        fixture["tonemappers"] = {"image_f16": b64(img.astype(np.float16)), "image_shape": list(img.shape), "params": params, "out": gen_tonemappers(parts, img, params)}
+        print("tonemappers in %.1f s" % (time.time() - t0), flush=True)
+    with open(args.out, "w") as f:
+        json.dump(fixture, f, indent=1)
+    print("wrote", args.out, os.path.getsize(args.out), "bytes")
+
+
+if __name__ == "__main__":
+    main()

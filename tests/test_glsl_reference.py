@@ -1,0 +1,213 @@
+"""The CPU oracle (oracle/vpt_oracle.c, oracle/vpt_tonemap_oracle.c) against what the REFERENCE'S OWN SHADER TEXT computes.
+
+tests/golden/glsl_r04.json was produced by executing the reference's fragment programs — src/glsl/renderers/{MIP,EAM,MCS,MCM,ISO,Depth}
+Renderer.glsl and src/glsl/tonemappers/*.glsl with their mixins, read from the reference tree, cooked as src/js/WebGL.js:85-99 cooks them —
+with the GLSL interpreter of oracle/glsl_interp.py (tests/golden/make_glsl_fixtures.py; the shader text itself is not in this
+repository).  So the formulas, the control flow, the order of the random draws and the meaning of every uniform are the reference's, not a
+reading of them.  The oracle follows the numeric contract: explicit fma where the shader writes a * b + c, rcp_nr for
+some divisions — the interpreter evaluates the shader text literally in fp32 — so the comparison is within a few ulp per pixel where
+the pixel's control flow agrees, and a stochastic pixel whose comparison against a random draw falls the other way may differ: the
+tests bound how many do (none, on these scenes, for most buffers).
+
+A live part (skipped where the reference tree is absent, e.g. on the GPU box) re-executes a few fragments from the reference tree and
+compares them with the committed fixture: the fixture is what the reference's text gives today."""
+import base64
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FX = json.load(open(os.path.join(ROOT, "tests", "golden", "glsl_r04.json")))
+GLSL_ROOT = "/root/reference/src/glsl"
+
+
+def arr(b64, dtype, shape):
+    return np.frombuffer(base64.b64decode(b64), dtype=dtype).reshape(shape).copy()
+
+
+def scene(oracle):
+    s = FX["scene"]
+    vol = arr(s["volume_u8"], np.uint8, s["volume_dims_zyx"])
+    tf = arr(s["tf_rgba8"], np.uint8, s["tf_shape"])
+    env = arr(s["env_rgba8"], np.uint8, s["env_shape"])
+    m = arr(s["mvp_inverse_f32"], np.float32, (16,))
+    return oracle.OracleScene(vol, s["filter"], tf=tf, env=env), m, s["width"], s["height"]
+
+
+def close(got, want, rel, abs_, what, max_outliers=0):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    bad = ~(np.abs(got - want) <= abs_ + rel * np.abs(want))
+    bad &= ~(np.isnan(got) & np.isnan(want))
+    n = int(bad.reshape(bad.shape[0] * bad.shape[1], -1).any(axis=1).sum()) if bad.ndim >= 2 else int(bad.sum())
+    assert n <= max_outliers, "%s: %d pixels differ (allowed %d); worst |d| = %g" % (what, n, max_outliers, float(np.nanmax(np.abs(got - want) * bad)))
+    return n
+
+
+def test_mip_follows_the_reference_shader(oracle):
+    sc, m, W, H = scene(oracle)
+    fx = FX["renderers"]["mip"]
+    o = oracle.OracleRenderer("mip", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m))
+    assert (o.acc.reshape(H, W) == np.rint(arr(fx["reset"]["acc"], np.float32, (H, W)) * 255)).all()
+    for k, (u, f) in enumerate(zip(fx["uniforms_per_frame"], fx["frames"])):
+        o.render(oracle.make_frame(W, H, m, offset=u["offset"], steps=round(1.0 / u["step"])))
+        # R8 attachments: the maximum of transfer-function alphas along the ray, stored as UNORM8 — byte for byte
+        close(o.frame.reshape(H, W, 1), np.rint(arr(f["frame"], np.float32, (H, W, 1)) * 255), 0, 0, "MIP frame %d" % k)
+        close(o.acc.reshape(H, W, 1), np.rint(arr(f["acc"], np.float32, (H, W, 1)) * 255), 0, 0, "MIP accumulator %d" % k)
+        close(o.image_f16().astype(np.float32), arr(f["image"], np.float32, (H, W, 4)), 0, 0, "MIP image %d" % k)
+        assert np.rint(arr(f["frame"], np.float32, (H, W)) * 255).max() > 100       # (the rays do meet the volume)
+
+
+def test_eam_follows_the_reference_shader(oracle):
+    sc, m, W, H = scene(oracle)
+    fx = FX["renderers"]["eam"]
+    o = oracle.OracleRenderer("eam", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m))
+    assert (o.acc.reshape(H, W, 4) == np.rint(arr(fx["reset"]["acc"], np.float32, (H, W, 4)) * 255)).all()
+    for k, (u, f) in enumerate(zip(fx["uniforms_per_frame"], fx["frames"])):
+        o.render(oracle.make_frame(W, H, m, offset=u["offset"], steps=round(1.0 / u["step"]), extinction=u["extinction"], mix=u["mix"]))
+        want = np.rint(arr(f["frame"], np.float32, (H, W, 4)) * 255)
+        close(o.frame.reshape(H, W, 4), want, 0, 0, "EAM frame %d" % k)                   # RGBA8, byte for byte
+        close(o.acc.reshape(H, W, 4), np.rint(arr(f["acc"], np.float32, (H, W, 4)) * 255), 0, 0, "EAM accumulator %d" % k)
+        close(o.image_f16().astype(np.float32), arr(f["image"], np.float32, (H, W, 4)), 0, 0, "EAM image %d" % k)
+        assert want[:, :, :3].max() > 60 and (want[:, :, 3] == 255).all()
+
+
+def test_mcs_follows_the_reference_shader(oracle):
+    sc, m, W, H = scene(oracle)
+    fx = FX["renderers"]["mcs"]
+    o = oracle.OracleRenderer("mcs", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m))
+    close(o.acc.reshape(H, W, 4), arr(fx["reset"]["acc"], np.float32, (H, W, 4)), 0, 0, "MCS reset")
+    flipped = 0
+    for k, (u, f) in enumerate(zip(fx["uniforms_per_frame"], fx["frames"])):
+        o.render(oracle.make_frame(W, H, m, seed=u["seed"], extinction=u["extinction"], light_dir=u["light"], mix=u["mix"]))
+        want = arr(f["frame"], np.float32, (H, W, 4))
+        # a pixel is a chain of random draws compared with transfer-function alphas: equal draws (the PCG stream is integer arithmetic),
+        # values within rounding — unless a comparison falls the other way, which the counts below bound
+        flipped += close(o.frame.reshape(H, W, 4), want, 3e-4, 2e-6, "MCS frame %d" % k, max_outliers=0)
+        close(o.acc.reshape(H, W, 4), arr(f["acc"], np.float32, (H, W, 4)), 2e-4, 2e-6, "MCS accumulator %d" % k, max_outliers=flipped)
+        close(o.image_f16().astype(np.float32), arr(f["image"], np.float32, (H, W, 4)), 2e-3, 1e-4, "MCS image %d" % k, max_outliers=flipped)
+        inside = (np.abs(want[:, :, :3] - want[0, 0, :3]).sum(axis=2) > 1e-3).sum()
+        assert inside > 40, inside                                            # (pixels whose ray scattered in the volume)
+    assert flipped == 0
+
+
+def test_mcm_follows_the_reference_shader(oracle):
+    sc, m, W, H = scene(oracle)
+    fx = FX["renderers"]["mcm"]
+    o = oracle.OracleRenderer("mcm", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m, seed=FX["scene"]["mcm_reset_seed"]))
+    names = ["position", "direction (+ bounces)", "transmittance", "radiance (+ samples)"]
+    for q in range(4):
+        # (the position of a ray that misses the cube is from + tnear * direction with tnear in the hundreds: ill-conditioned, 1e-4 relative)
+        close(o.state[q].reshape(H, W, 4), arr(fx["reset"]["state"][q], np.float32, (H, W, 4)), 1e-3 if q == 0 else 2e-5, 2e-6, "MCM reset %s" % names[q])
+    diverged = np.zeros((H, W), bool)
+    for k, (u, f) in enumerate(zip(fx["uniforms_per_frame"], fx["frames"])):
+        o.render(oracle.make_frame(W, H, m, seed=u["seed"], extinction=u["extinction"], anisotropy=u["anisotropy"], max_bounces=u["max_bounces"], mcm_steps=u["steps"]))
+        for q in range(4):
+            got, want = o.state[q].reshape(H, W, 4).astype(np.float64), arr(f["state"][q], np.float32, (H, W, 4)).astype(np.float64)
+            bad = (~(np.abs(got - want) <= 1e-4 + (2e-3 if q == 0 else 5e-4) * np.abs(want))).any(axis=2)
+            diverged |= bad
+        # the integer parts of the state — bounces so far, paths ended — are exact wherever the photon's history is the same
+        same = ~diverged
+        assert (o.state[1].reshape(H, W, 4)[same][:, 3] == arr(f["state"][1], np.float32, (H, W, 4))[same][:, 3]).all(), "bounces, pass %d" % k
+        assert (o.state[3].reshape(H, W, 4)[same][:, 3] == arr(f["state"][3], np.float32, (H, W, 4))[same][:, 3]).all(), "samples, pass %d" % k
+        assert diverged.sum() == 0, "MCM pass %d: %d of %d photons took another branch than the shader text's" % (k, diverged.sum(), W * H)
+        got, want = o.image_f16().astype(np.float32), arr(f["image"], np.float32, (H, W, 4))
+        assert (np.abs(got - want)[same] <= 2e-3 + 2e-3 * np.abs(want[same])).all(), "MCM image, pass %d" % k
+    # the scene exercises every branch of the event loop: paths ended (samples), scattering (bounces), photons inside the volume
+    last = fx["frames"][-1]["state"]
+    assert arr(last[3], np.float32, (H, W, 4))[:, :, 3].max() >= 3 and arr(last[1], np.float32, (H, W, 4))[:, :, 3].max() >= 1
+    pos = arr(last[0], np.float32, (H, W, 4))[:, :, :3]
+    assert ((pos > 0) & (pos < 1)).all(axis=2).sum() > 20
+
+
+def test_iso_follows_the_reference_shader(oracle):
+    sc, m, W, H = scene(oracle)
+    fx = FX["renderers"]["iso"]
+    o = oracle.OracleRenderer("iso", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m))
+    close(o.acc.view(np.float16).reshape(H, W, 4).astype(np.float32), arr(fx["reset"]["acc"], np.float32, (H, W, 4)), 0, 0, "ISO reset")
+    for k, (u, f) in enumerate(zip(fx["uniforms_per_frame"], fx["frames"])):
+        # (the oracle's frame carries uSteps twice: the loop count and the shader's 1.0 / float(uSteps), ISORenderer.glsl:64)
+        o.render(oracle.make_frame(W, H, m, offset=u["offset"], steps=u["steps"], mcm_steps=u["steps"], isovalue=u["isovalue"], light_dir=u["light"], gradient_step=u["gradient_step"]))
+        want = arr(f["frame"], np.float32, (H, W, 4))
+        # the closest hit (position, distance) in half floats: one half ulp
+        close(o.frame.view(np.float16).reshape(H, W, 4).astype(np.float32), want, 1e-3, 1e-3, "ISO closest hit of frame %d" % k, max_outliers=1)
+        close(o.acc.view(np.float16).reshape(H, W, 4).astype(np.float32), arr(f["acc"], np.float32, (H, W, 4)), 1e-3, 1e-3, "ISO accumulated closest hit %d" % k, max_outliers=1)
+        close(o.image_f16().astype(np.float32), arr(f["image"], np.float32, (H, W, 4)), 2e-2, 4e-3, "ISO shaded image %d" % k, max_outliers=2)
+        assert (want[:, :, 3] > 0).sum() > 20                                  # (rays that found the isosurface)
+
+
+def test_depth_follows_the_reference_shader(oracle):
+    sc, m, W, H = scene(oracle)
+    fx = FX["renderers"]["depth"]
+    o = oracle.OracleRenderer("depth", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m))
+    close(o.acc.reshape(H, W, 1), arr(fx["reset"]["acc"], np.float32, (H, W, 1)), 0, 0, "Depth reset")
+    for k, (u, f) in enumerate(zip(fx["uniforms_per_frame"], fx["frames"])):
+        o.render(oracle.make_frame(W, H, m, offset=u["offset"], steps=round(1.0 / u["step"]), extinction=u["extinction"], threshold=u["threshold"], mix=u["mix"]))
+        want = arr(f["frame"], np.float32, (H, W, 1))
+        close(o.frame.reshape(H, W, 1), want, 1e-5, 1e-6, "Depth frame %d" % k, max_outliers=1)
+        close(o.acc.reshape(H, W, 1), arr(f["acc"], np.float32, (H, W, 1)), 1e-5, 1e-6, "Depth accumulator %d" % k, max_outliers=1)
+        close(o.image_f16().astype(np.float32), arr(f["image"], np.float32, (H, W, 4)), 2e-3, 1e-3, "Depth image %d" % k, max_outliers=1)
+        assert len(np.unique(want)) > 30
+
+
+def test_tone_mappers_follow_the_reference_shaders(oracle):
+    t = FX["tonemappers"]
+    img = arr(t["image_f16"], np.float16, t["image_shape"])
+    p = t["params"]
+    params = dict(low=p["uLow"], mid=p["uMid"], high=p["uHigh"], saturation=p["uSaturation"], min=p["uMin"], max=p["uMax"], exposure=p["uExposure"], gamma=p["uGamma"])
+    worst = {}
+    for name, entry in t["out"].items():
+        want = arr(entry["rgba8"], np.uint8, (img.shape[0], img.shape[1], 4)).astype(np.int32)
+        got = oracle.tonemap(name.lower(), img, **params).reshape(want.shape).astype(np.int32)
+        worst[name] = int(np.abs(got - want).max())
+        assert worst[name] == 0, (name, worst[name])                          # RGBA8, byte for byte: the operators are straight-line arithmetic
+    assert len(worst) == 10
+
+
+@pytest.mark.skipif(not os.path.isdir(GLSL_ROOT), reason="the reference tree is not here (GPU box): the committed fixture stands")
+def test_the_fixture_is_what_the_reference_text_gives_today(oracle):
+    """re-executes the reference's MCM integrate program (the headline path) for one row of pixels and its MIP generate program for another
+    from the reference tree and compares with the committed fixture, bit for bit"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_glsl_fixtures as M
+    from oracle import glsl_interp as G
+    parts = G.read_parts(GLSL_ROOT)
+    s = FX["scene"]
+    W, H = s["width"], s["height"]
+    vol = arr(s["volume_u8"], np.uint8, s["volume_dims_zyx"]); tf = arr(s["tf_rgba8"], np.uint8, s["tf_shape"]); env = arr(s["env_rgba8"], np.uint8, s["env_shape"])
+    m = arr(s["mvp_inverse_f32"], np.float32, (16,))
+    base = {"uVolume": M.volume_sampler(vol), "uTransferFunction": M.tf_sampler(tf), "uEnvironment": M.env_sampler(env), "uMvpInverseMatrix": G.mat4(m)}
+    # MIP generate, frame 0, row 7
+    u = FX["renderers"]["mip"]["uniforms_per_frame"][0]
+    prog = G.Program(parts, "/glsl/shaders/renderers/MIP/generate")
+    un = dict(base, uStepSize=np.float32(u["step"]), uOffset=np.float32(u["offset"]))
+    corners = prog.varyings(un)
+    row = [float(prog.fragment(un, corners, i, 7, W, H)["oColor"]) for i in range(W)]
+    want = arr(FX["renderers"]["mip"]["frames"][0]["frame"], np.float32, (H, W))[7]
+    assert (M.store_unorm8(row) == want).all()
+    # MCM integrate, pass 0 from the reset state, row 6
+    fm = FX["renderers"]["mcm"]
+    state = [arr(b, np.float32, (H, W, 4)) for b in fm["reset"]["state"]]
+    u = fm["uniforms_per_frame"][0]
+    prog = G.Program(parts, "/glsl/shaders/renderers/MCM/integrate")
+    un = dict(base, uInverseResolution=G.vec(np.float32(1.0) / np.float32(W), np.float32(1.0) / np.float32(H)), uBlur=np.float32(0.0),
+              uRandSeed=np.float32(u["seed"]), uExtinction=np.float32(u["extinction"]), uAnisotropy=np.float32(u["anisotropy"]),
+              uMaxBounces=G.UInt(u["max_bounces"]), uSteps=G.UInt(u["steps"]),
+              uPosition=M.state_sampler(state[0]), uDirection=M.state_sampler(state[1]), uTransmittance=M.state_sampler(state[2]), uRadiance=M.state_sampler(state[3]))
+    corners = prog.varyings(un)
+    names = ["oPosition", "oDirection", "oTransmittance", "oRadiance"]
+    for i in range(W):
+        out = prog.fragment(un, corners, i, 6, W, H)
+        for q, n in enumerate(names):
+            got = np.array(M.comps(out[n], 4), np.float32)
+            want = arr(fm["frames"][0]["state"][q], np.float32, (H, W, 4))[6, i]
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), (i, n, got, want)
