@@ -167,26 +167,27 @@ def convert_scalar(v, kind):
 class Sampler:
     """texels: float32 array [h][w][4] (2-D) or [d][h][w][4] (3-D), already converted from the storage format (UNORM8 / sRGB / float)"""
 
-    def __init__(self, texels, linear):
+    def __init__(self, texels, linear, repeat=False):
         self.t = np.ascontiguousarray(texels, dtype=np.float32)
         self.dim = self.t.ndim - 1
         self.linear = bool(linear)
+        self.repeat = bool(repeat)            # TEXTURE_WRAP_* = REPEAT (the GL default, what a texture created without wrap modes has)
         self.glsl_type = "sampler3D" if self.dim == 3 else "sampler2D"
 
     def _axis(self, coord, n):
         """texel indices and weight along one axis: OpenGL ES 3.0 section 3.8.10 (u = s * n; i0 = floor(u - 0.5), clamped to the edge)"""
         u = F(coord) * F(n)
+        wrap = (lambda i: i % n) if self.repeat else (lambda i: min(max(i, 0), n - 1))
         if not self.linear:
             i = int(math.floor(float(u))) if math.isfinite(float(u)) else 0
-            i = min(max(i, 0), n - 1)
-            return i, i, F(0.0)
+            return wrap(i), wrap(i), F(0.0)
         um = u - F(0.5)
         fl = F(np.floor(um))
         w = um - fl
         if not math.isfinite(float(fl)):
             return 0, 0, F(0.0)
         i0 = int(fl)
-        return min(max(i0, 0), n - 1), min(max(i0 + 1, 0), n - 1), w
+        return wrap(i0), wrap(i0 + 1), w
 
     @staticmethod
     def _lerp(a, b, w):

@@ -70,7 +70,7 @@ def state_sampler(buf):                         # an attachment read back at pix
     return G.Sampler(buf, False)
 
 
-def camera_matrix(aspect, yaw, pitch, dist, fovy=1.0):
+def camera_node(aspect, yaw, pitch, dist, fovy=1.0):
     node = Node()
     import math
     qy = quat.setAxisAngle(quat.create(), [0, 1, 0], yaw)
@@ -80,7 +80,11 @@ def camera_matrix(aspect, yaw, pitch, dist, fovy=1.0):
     node.transform.localTranslation = [dist * sy * cp, -dist * sp, dist * cy * cp]
     cam = PerspectiveCamera(node, {'fovy': fovy, 'aspect': aspect, 'near': 0.1, 'far': 100.0})
     node.components.append(cam)
-    return np.asarray(mvp_inverse_matrix(node, Transform(Node())), dtype=np.float32).reshape(16)
+    return node
+
+
+def camera_matrix(aspect, yaw, pitch, dist, fovy=1.0):
+    return np.asarray(mvp_inverse_matrix(camera_node(aspect, yaw, pitch, dist, fovy), Transform(Node())), dtype=np.float32).reshape(16)
 
 
 # ---- attachment formats ------------------------------------------------------------------------------------------------------------
@@ -235,6 +239,67 @@ def gen_depth(parts, sc, frames):
     return out
 
 
+def gen_lao(parts, sc, frames, lao):
+    """LAORenderer.js:146-186 (generate: uStepSize = 1 / slices, uExtinction, the LAO / soft-shadow switches and weights, uLightPosition,
+    uOffset; integrate: the frame replaces the accumulator), buffers RGBA8 (:220-247)"""
+    W, H = sc["W"], sc["H"]
+    P = {k: G.Program(parts, "/glsl/shaders/renderers/LAO/" + k) for k in ("generate", "integrate", "render", "reset")}
+    base = {"uVolume": sc["vol_s"], "uTransferFunction": sc["tf_s"], "uMvpInverseMatrix": G.mat4(sc["matrix"])}
+    acc = store_unorm8(run_pass(P["reset"], base, W, H, ["oColor"])["oColor"])
+    out = {"reset": {"acc": b64(acc)}, "frames": [], "lao": lao}
+    for fr in frames:
+        u = dict(base, uStepSize=F(fr["step"]), uOffset=F(fr["offset"]), uExtinction=F(fr["extinction"]),
+                 uLocalAmbientOcclusion=bool(lao["local_ambient_occlusion"]), uLAOWeight=F(lao["lao_weight"]), uNumLAOSamples=G.Int(lao["num_lao_samples"]),
+                 uLAOStepSize=F(lao["lao_step_size"]), uSoftShadows=bool(lao["soft_shadows"]), uShadowsWeight=F(lao["shadows_weight"]),
+                 uNumShadowSamples=G.Int(lao["num_shadow_samples"]), uLightRadious=F(lao["light_radius"]), uLightCoeficient=F(lao["light_coefficient"]),
+                 uLightPosition=G.vec(*lao["light_position"]))
+        frame = store_unorm8(run_pass(P["generate"], u, W, H, ["oColor"])["oColor"])
+        acc = store_unorm8(run_pass(P["integrate"], dict(base, uAccumulator=state_sampler(acc), uFrame=state_sampler(frame)), W, H, ["oColor"])["oColor"])
+        img = store_f16(run_pass(P["render"], dict(base, uAccumulator=state_sampler(acc)), W, H, ["oColor"])["oColor"])
+        out["frames"].append({"frame": b64(frame), "acc": b64(acc), "image": b64(img)})
+    return out
+
+
+def gen_dos(parts, sc, sweep):
+    """DOSRenderer.js:199-259: reset, then one draw of the integrate program per slice (uDepth in the vertex stage; uOcclusionScale,
+    uSliceDistance, uExtinction, the occlusion sample texture RG32F), ping-ponging colour RGBA32F (NEAREST) and occlusion R32F (LINEAR, the
+    default REPEAT wrap: :287-313), then render"""
+    W, H = sc["W"], sc["H"]
+    P = {k: G.Program(parts, "/glsl/shaders/renderers/DOS/" + k) for k in ("integrate", "render", "reset")}
+    base = {"uVolume": sc["vol_s"], "uTransferFunction": sc["tf_s"], "uMvpInverseMatrix": G.mat4(sc["matrix"])}
+    r = run_pass(P["reset"], base, W, H, ["oColor", "oOcclusion"])
+    color, occ = store_f32(r["oColor"]), store_f32(r["oOcclusion"])
+    taps = np.asarray(sweep["samples"], np.float32).reshape(-1, 2)
+    tap_tex = np.zeros((1, len(taps), 4), np.float32); tap_tex[0, :, :2] = taps; tap_tex[0, :, 3] = 1
+    out = {"reset": {"color": b64(color), "occlusion": b64(occ[..., 0])}, "slices": [], "sweep": sweep}
+    for (sx, sy, depth) in sweep["slices"]:
+        u = dict(base, uDepth=F(depth), uExtinction=F(sweep["extinction"]), uSliceDistance=F(sweep["slice_distance"]), uOcclusionScale=G.vec(sx, sy),
+                 uOcclusionSamplesCount=G.UInt(len(taps)), uOcclusionSamples=G.Sampler(tap_tex, False),
+                 uColor=state_sampler(color), uOcclusion=G.Sampler(np.repeat(occ[..., :1], 4, axis=2), True, repeat=True))
+        r = run_pass(P["integrate"], u, W, H, ["oColor", "oOcclusion"])
+        color, occ = store_f32(r["oColor"]), store_f32(r["oOcclusion"])
+        out["slices"].append({"color": b64(color), "occlusion": b64(occ[..., 0])})
+    img = store_f16(run_pass(P["render"], dict(base, uAccumulator=state_sampler(color)), W, H, ["oColor"])["oColor"])
+    out["image"] = b64(img)
+    return out
+
+
+def gen_tf_bump(parts, bumps, W, H):
+    """ui/TransferFunction/TransferFunction.js:110-121: one draw of /glsl/shaders/TransferFunction per bump; the blending and the 8-bit
+    canvas are the host's (gl.blendFunc(ONE, ONE_MINUS_SRC_ALPHA)), done here as the GL does them; rows as the framebuffer has them (0 = bottom)"""
+    prog = G.Program(parts, "/glsl/shaders/TransferFunction")
+    dst = np.zeros((H, W, 4), np.float32)
+    draws = []
+    for b in bumps:
+        u = {"uPosition": G.vec(b["position"]["x"], b["position"]["y"]), "uSize": G.vec(b["size"]["x"], b["size"]["y"]),
+             "uColor": G.vec(b["color"]["r"], b["color"]["g"], b["color"]["b"], b["color"]["a"])}
+        src = run_pass(prog, u, W, H, ["oColor"])["oColor"]
+        draws.append(b64(src))
+        srcc = np.clip(src, 0, 1)
+        dst = store_unorm8(srcc + dst * (np.float32(1.0) - srcc[..., 3:4]))
+    return {"bumps": bumps, "width": W, "height": H, "fragment_outputs": draws, "canvas_rgba8": b64((dst * 255.0 + 0.5).astype(np.uint8))}
+
+
 TONEMAPPERS = ["Artistic", "Range", "Reinhard", "Reinhard2", "Uncharted2", "Filmic", "Unreal", "Aces", "Lottes", "Uchimura"]
 
 
@@ -287,6 +352,9 @@ def main():
         "iso": (gen_iso, [{"steps": 24, "offset": s, "isovalue": 0.25, "light": [0.48, 0.6, 0.64], "gradient_step": 0.02} for s in seeds[:2]]),
         "depth": (gen_depth, [{"step": 1.0 / 24, "offset": s, "extinction": 60.0, "threshold": 0.3, "mix": 1.0 / (k + 1)} for k, s in enumerate(seeds[:2])]),
     }
+    lao = {"local_ambient_occlusion": 1, "lao_weight": 0.69, "num_lao_samples": 2, "lao_step_size": 0.05, "soft_shadows": 1, "shadows_weight": 0.54,
+           "num_shadow_samples": 3, "light_radius": 0.19, "light_coefficient": 1.0, "light_position": [2.0, 12.0, 3.0]}
+    plans["lao"] = (lambda p, s_, f: gen_lao(p, s_, f, lao), [{"step": 1.0 / 12, "offset": s, "extinction": 30.0} for s in seeds[:2]])
     for name, (fn, frames) in plans.items():
         if args.only and name not in args.only.split(","):
             continue
@@ -295,6 +363,25 @@ def main():
         r["uniforms_per_frame"] = frames
         fixture["renderers"][name] = r
         print("%s: %d frames in %.1f s" % (name, len(frames), time.time() - t0), flush=True)
+    if not args.only or "dos" in args.only.split(","):
+        fwd = np.linalg.inv(matrix.reshape(4, 4).T.astype(np.float64))                    # column-major inverse-MVP -> the MVP itself
+        corners = np.array([[x, y, z, 1.0] for x in (0, 1) for y in (0, 1) for z in (0, 1)])
+        clip = corners @ fwd.T
+        depths = clip[:, 2] / clip[:, 3]
+        rng = np.random.default_rng(11)
+        n = 9
+        ds = np.linspace(depths.min(), depths.max(), n + 2)[1:-1]
+        ang, rad = rng.uniform(0, 2 * np.pi, 5), np.sqrt(rng.uniform(0, 1, 5))
+        sweep = {"slices": [[float(np.float32(0.03 + 0.004 * k)), float(np.float32(0.045 + 0.006 * k)), float(np.float32(d))] for k, d in enumerate(ds)],
+                 "samples": [float(np.float32(v)) for a, r in zip(ang, rad) for v in (r * np.cos(a), r * np.sin(a))],
+                 "extinction": 25.0, "slice_distance": float(np.float32(1.0 / 10)), "steps": 10}
+        t0 = time.time()
+        fixture["renderers"]["dos"] = gen_dos(parts, sc, sweep)
+        print("dos: %d slices in %.1f s" % (n, time.time() - t0), flush=True)
+    if not args.only or "tf" in args.only.split(","):
+        bumps = json.load(open(os.path.join(ROOT, "tests", "golden", "tf_bumps_r04.json")))["files"]["three_overlapping"]["bumps"]
+        fixture["transfer_function"] = gen_tf_bump(parts, bumps, 24, 10)
+        print("transfer function: %d bumps" % len(bumps), flush=True)
     if not args.only or "tonemappers" in args.only.split(","):
         rng = np.random.default_rng(9)
         img = np.concatenate([rng.uniform(0, 1.2, size=(4, 8, 4)), rng.uniform(0, 6, size=(2, 8, 4)), np.zeros((1, 8, 4)), np.ones((1, 8, 4))]).astype(np.float16).astype(np.float32)

@@ -1,7 +1,8 @@
 """The CPU oracle (oracle/vpt_oracle.c, oracle/vpt_tonemap_oracle.c) against what the REFERENCE'S OWN SHADER TEXT computes.
 
-tests/golden/glsl_r04.json was produced by executing the reference's fragment programs — src/glsl/renderers/{MIP,EAM,MCS,MCM,ISO,Depth}
-Renderer.glsl and src/glsl/tonemappers/*.glsl with their mixins, read from the reference tree, cooked as src/js/WebGL.js:85-99 cooks them —
+tests/golden/glsl_r04.json was produced by executing the reference's programs — src/glsl/renderers/{MIP,EAM,MCS,MCM,ISO,Depth,LAO,DOS}
+Renderer.glsl, src/glsl/tonemappers/*.glsl and src/glsl/TransferFunction.glsl with their mixins, read from the reference tree, cooked as
+src/js/WebGL.js:85-99 cooks them —
 with the GLSL interpreter of oracle/glsl_interp.py (tests/golden/make_glsl_fixtures.py; the shader text itself is not in this
 repository).  So the formulas, the control flow, the order of the random draws and the meaning of every uniform are the reference's, not a
 reading of them.  The oracle follows the numeric contract: explicit fma where the shader writes a * b + c, rcp_nr for
@@ -158,6 +159,58 @@ def test_depth_follows_the_reference_shader(oracle):
         assert len(np.unique(want)) > 30
 
 
+def test_lao_follows_the_reference_shader(oracle):
+    sc, m, W, H = scene(oracle)
+    fx = FX["renderers"]["lao"]
+    o = oracle.OracleRenderer("lao", sc, W, H)
+    o.lao = oracle.lao_params(**fx["lao"])
+    o.reset(oracle.make_frame(W, H, m))
+    assert (o.acc.reshape(H, W, 4) == np.rint(arr(fx["reset"]["acc"], np.float32, (H, W, 4)) * 255)).all()
+    for k, (u, f) in enumerate(zip(fx["uniforms_per_frame"], fx["frames"])):
+        o.render(oracle.make_frame(W, H, m, offset=u["offset"], steps=round(1.0 / u["step"]), extinction=u["extinction"]))
+        want = np.rint(arr(f["frame"], np.float32, (H, W, 4)) * 255)
+        # RGBA8, byte for byte — although the shader's occlusion and shadow rays draw their directions from fract(cos(x) * 1235.68)
+        close(o.frame.reshape(H, W, 4), want, 0, 0, "LAO frame %d" % k)
+        close(o.acc.reshape(H, W, 4), np.rint(arr(f["acc"], np.float32, (H, W, 4)) * 255), 0, 0, "LAO accumulator %d" % k)
+        close(o.image_f16().astype(np.float32), arr(f["image"], np.float32, (H, W, 4)), 0, 0, "LAO image %d" % k)
+        assert want[:, :, :3].max() > 40
+
+
+def test_dos_follows_the_reference_shader(oracle):
+    sc, m, W, H = scene(oracle)
+    fx = FX["renderers"]["dos"]
+    sw = fx["sweep"]
+    o = oracle.OracleRenderer("dos", sc, W, H)
+    fr = oracle.make_frame(W, H, m, steps=sw["steps"], extinction=sw["extinction"])
+    assert np.float32(fr.step) == np.float32(sw["slice_distance"])
+    o.reset(fr)
+    close(o.color[o.cur].reshape(H, W, 4), arr(fx["reset"]["color"], np.float32, (H, W, 4)), 0, 0, "DOS reset colour")
+    close(o.occlusion[o.cur].reshape(H, W, 1), arr(fx["reset"]["occlusion"], np.float32, (H, W, 1)), 0, 0, "DOS reset occlusion")
+    lit = 0
+    for k, (sl, f) in enumerate(zip(sw["slices"], fx["slices"])):
+        o.integrate_slices(fr, [sl], sw["samples"])
+        want = arr(f["color"], np.float32, (H, W, 4))
+        close(o.color[o.cur].reshape(H, W, 4), want, 2e-4, 2e-6, "DOS colour after slice %d" % k)
+        close(o.occlusion[o.cur].reshape(H, W, 1), arr(f["occlusion"], np.float32, (H, W, 1)), 2e-4, 2e-6, "DOS occlusion after slice %d" % k)
+        lit = max(lit, int((want[:, :, 3] > 0).sum()))
+    o.render_frame(fr)
+    close(o.image_f16().astype(np.float32), arr(fx["image"], np.float32, (H, W, 4)), 2e-3, 1e-3, "DOS image")
+    assert lit > 40                                                           # (pixels whose slices met the volume)
+
+
+def test_transfer_function_bumps_follow_the_reference_shader(oracle):
+    """the widget's fragment program (src/glsl/TransferFunction.glsl) executed per bump, blended as the GL blends: what
+    vpo_tf_rasterize (and through it vpt_transfer_function_rasterize) restates — rows flipped: the fixture keeps the framebuffer's order"""
+    t = FX["transfer_function"]
+    W, H = t["width"], t["height"]
+    bumps = np.array([[b["position"]["x"], b["position"]["y"], b["size"]["x"], b["size"]["y"], b["color"]["r"], b["color"]["g"], b["color"]["b"], b["color"]["a"]]
+                      for b in t["bumps"]], np.float32)
+    got = oracle.tf_rasterize(bumps, W, H, unpremultiply=False)[::-1]
+    want = arr(t["canvas_rgba8"], np.uint8, (H, W, 4))
+    assert (got == want).all(), int((got != want).sum())
+    assert want[:, :, 3].max() > 150 and (want[:, :, 3] == 0).any()
+
+
 def test_tone_mappers_follow_the_reference_shaders(oracle):
     t = FX["tonemappers"]
     img = arr(t["image_f16"], np.float16, t["image_shape"])
@@ -211,3 +264,57 @@ def test_the_fixture_is_what_the_reference_text_gives_today(oracle):
             got = np.array(M.comps(out[n], 4), np.float32)
             want = arr(fm["frames"][0]["state"][q], np.float32, (H, W, 4))[6, i]
             assert (got.view(np.uint32) == want.view(np.uint32)).all(), (i, n, got, want)
+
+
+# ---- the HIP library itself against the reference's text (not only through the oracle) -----------------------------------------------
+@pytest.mark.gpu
+def test_hip_library_against_the_reference_text(gpu_ctx, oracle):
+    """MIP (byte for byte) and MCM (the same photon histories) of libvpt_hip.so through the Python host, on the fixture's scene with the
+    fixture's seeds: the product path held directly to what the reference's shader text computes"""
+    import vpt_amd
+    from vpt_amd import _native as N
+    sys_path = os.path.join(ROOT, "tests", "golden")
+    import sys
+    sys.path.insert(0, sys_path)
+    import make_glsl_fixtures as M
+    s = FX["scene"]
+    W, H = s["width"], s["height"]
+    vol = arr(s["volume_u8"], np.uint8, s["volume_dims_zyx"]); tf = arr(s["tf_rgba8"], np.uint8, s["tf_shape"]); env = arr(s["env_rgba8"], np.uint8, s["env_shape"])
+    m = arr(s["mvp_inverse_f32"], np.float32, (16,))
+    gvol = vpt_amd.Volume.from_array(gpu_ctx, vol, "linear")
+
+    class Camera:                                          # the host computes the matrix from a camera: hand it the fixture's
+        pass
+
+    def renderer(kind, seeds):
+        it = iter(seeds)
+        r = vpt_amd.RendererFactory(kind)(gpu_ctx, gvol, M.camera_node(W / H, 0.55, -0.3, 1.75), env, {'resolution': (W, H), 'transform': vpt_amd.Transform(vpt_amd.Node()), 'rng': lambda: next(it)})
+        r.setTransferFunction(tf)
+        return r
+    # MIP
+    fx = FX["renderers"]["mip"]
+    r = renderer('mip', [u["offset"] for u in fx["uniforms_per_frame"]])
+    r.steps = round(1.0 / fx["uniforms_per_frame"][0]["step"])
+    r.reset()
+    for k, f in enumerate(fx["frames"]):
+        r.render()
+        assert (np.array(list(r._u.mvp_inverse), np.float32).view(np.uint32) == m.view(np.uint32)).all()
+        assert (r.read(N.BUFFER_ACCUM).reshape(H, W) == np.rint(arr(f["acc"], np.float32, (H, W)) * 255)).all(), "MIP accumulator %d" % k
+        assert (r.getTexture().astype(np.float32) == arr(f["image"], np.float32, (H, W, 4))).all(), "MIP image %d" % k
+    r.destroy()
+    # MCM
+    fx = FX["renderers"]["mcm"]
+    r = renderer('mcm', [s["mcm_reset_seed"]] + [u["seed"] for u in fx["uniforms_per_frame"]])
+    u0 = fx["uniforms_per_frame"][0]
+    r.extinction = u0["extinction"]; r.bounces = u0["max_bounces"]; r.steps = u0["steps"]
+    r.reset()
+    bufs = [N.BUFFER_MCM_POSITION, N.BUFFER_MCM_DIRECTION, N.BUFFER_MCM_TRANSMITTANCE, N.BUFFER_MCM_RADIANCE]
+    for k, (u, f) in enumerate(zip(fx["uniforms_per_frame"], fx["frames"])):
+        r.anisotropy = u["anisotropy"]
+        r.render()
+        for q, b in enumerate(bufs):
+            got, want = r.read(b).reshape(H, W, 4).astype(np.float64), arr(f["state"][q], np.float32, (H, W, 4)).astype(np.float64)
+            assert (np.abs(got - want) <= 1e-4 + (2e-3 if q == 0 else 5e-4) * np.abs(want)).all(), "MCM pass %d buffer %d" % (k, q)
+        assert (r.read(bufs[1])[..., 3] == arr(f["state"][1], np.float32, (H, W, 4))[..., 3]).all(), "bounces, pass %d" % k
+        assert (r.read(bufs[3])[..., 3] == arr(f["state"][3], np.float32, (H, W, 4))[..., 3]).all(), "paths ended, pass %d" % k
+    r.destroy(); gvol.destroy()
