@@ -48,9 +48,12 @@ def srgb_to_linear(byte):
     return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
 
 
-def volume_sampler(vol, linear=True):          # R8: texture() returns (r, 0, 0, 1)  (OpenGL ES 3.0 table 3.12)
-    t = np.zeros(vol.shape + (4,), np.float32)
-    t[..., 0] = vol.astype(np.float32) / np.float32(255.0)
+def volume_sampler(vol, linear=True):          # R8 / RG8: texture() returns (r, g or 0, 0, 1)  (OpenGL ES 3.0 table 3.12)
+    t = np.zeros(vol.shape[:3] + (4,), np.float32)
+    if vol.ndim == 4:
+        t[..., :2] = vol.astype(np.float32) / np.float32(255.0)
+    else:
+        t[..., 0] = vol.astype(np.float32) / np.float32(255.0)
     t[..., 3] = 1.0
     return G.Sampler(t, linear)
 
@@ -363,6 +366,23 @@ def main():
         r["uniforms_per_frame"] = frames
         fixture["renderers"][name] = r
         print("%s: %d frames in %.1f s" % (name, len(frames), time.time() - t0), flush=True)
+    # a second scene: a two-channel (RG8) volume — texture(uVolume, p).rg has both channels, the transfer function is looked up in 2-D —
+    # with the NEAREST filter (Volume.js:115-125), and a bounce limit of 1 (MCMRenderer.glsl:137-141)
+    if not args.only or "rg8" in args.only.split(","):
+        vol2 = np.ascontiguousarray(np.stack([vol, make_volume(dims, 21)], axis=-1))
+        tf2 = np.random.default_rng(22).integers(0, 256, size=(3, 6, 4), dtype=np.uint8)
+        tf2[:, 0, 3] = 0
+        sc2 = dict(sc, vol_s=volume_sampler(vol2, linear=False), tf_s=tf_sampler(tf2))
+        fixture["scene_rg8_nearest"] = {"volume_u8": b64(vol2), "volume_shape": list(vol2.shape), "tf_rgba8": b64(tf2), "tf_shape": list(tf2.shape), "filter": "nearest"}
+        fixture["renderers_rg8_nearest"] = {}
+        for name in ("mip", "eam", "mcs", "mcm"):
+            fn, frames = plans[name]
+            frames = [dict(f, max_bounces=1) if "max_bounces" in f else f for f in frames[:2]]
+            t0 = time.time()
+            r = fn(parts, sc2, frames)
+            r["uniforms_per_frame"] = frames
+            fixture["renderers_rg8_nearest"][name] = r
+            print("rg8 / nearest %s: %d frames in %.1f s" % (name, len(frames), time.time() - t0), flush=True)
     if not args.only or "dos" in args.only.split(","):
         fwd = np.linalg.inv(matrix.reshape(4, 4).T.astype(np.float64))                    # column-major inverse-MVP -> the MVP itself
         corners = np.array([[x, y, z, 1.0] for x in (0, 1) for y in (0, 1) for z in (0, 1)])

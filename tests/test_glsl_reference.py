@@ -266,6 +266,46 @@ def test_the_fixture_is_what_the_reference_text_gives_today(oracle):
             assert (got.view(np.uint32) == want.view(np.uint32)).all(), (i, n, got, want)
 
 
+def test_two_channel_volume_nearest_filter_and_bounce_limit(oracle):
+    """the second scene of the fixture: an RG8 volume (both channels of texture(uVolume, p).rg, the transfer function looked up in 2-D),
+    the NEAREST filter, at most one bounce — MIP, EAM byte for byte; MCS within rounding; MCM the same photon histories"""
+    s0, s2 = FX["scene"], FX["scene_rg8_nearest"]
+    W, H = s0["width"], s0["height"]
+    vol = arr(s2["volume_u8"], np.uint8, s2["volume_shape"]); tf = arr(s2["tf_rgba8"], np.uint8, s2["tf_shape"]); env = arr(s0["env_rgba8"], np.uint8, s0["env_shape"])
+    m = arr(s0["mvp_inverse_f32"], np.float32, (16,))
+    sc = oracle.OracleScene(vol, s2["filter"], tf=tf, env=env)
+    R = FX["renderers_rg8_nearest"]
+    for kind in ("mip", "eam"):
+        ch = 1 if kind == "mip" else 4
+        o = oracle.OracleRenderer(kind, sc, W, H)
+        o.reset(oracle.make_frame(W, H, m))
+        for k, (u, f) in enumerate(zip(R[kind]["uniforms_per_frame"], R[kind]["frames"])):
+            kw = dict(offset=u["offset"], steps=round(1.0 / u["step"]))
+            if kind == "eam":
+                kw.update(extinction=u["extinction"], mix=u["mix"])
+            o.render(oracle.make_frame(W, H, m, **kw))
+            want = np.rint(arr(f["acc"], np.float32, (H, W, ch)) * 255)
+            close(o.acc.reshape(H, W, ch), want, 0, 0, "%s accumulator %d (RG8, NEAREST)" % (kind, k))
+            close(o.image_f16().astype(np.float32), arr(f["image"], np.float32, (H, W, 4)), 0, 0, "%s image %d (RG8, NEAREST)" % (kind, k))
+            assert want.max() > 60
+    o = oracle.OracleRenderer("mcs", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m))
+    for k, (u, f) in enumerate(zip(R["mcs"]["uniforms_per_frame"], R["mcs"]["frames"])):
+        o.render(oracle.make_frame(W, H, m, seed=u["seed"], extinction=u["extinction"], light_dir=u["light"], mix=u["mix"]))
+        close(o.acc.reshape(H, W, 4), arr(f["acc"], np.float32, (H, W, 4)), 3e-4, 2e-6, "MCS accumulator %d (RG8, NEAREST)" % k)
+    o = oracle.OracleRenderer("mcm", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m, seed=s0["mcm_reset_seed"]))
+    for k, (u, f) in enumerate(zip(R["mcm"]["uniforms_per_frame"], R["mcm"]["frames"])):
+        assert u["max_bounces"] == 1
+        o.render(oracle.make_frame(W, H, m, seed=u["seed"], extinction=u["extinction"], anisotropy=u["anisotropy"], max_bounces=u["max_bounces"], mcm_steps=u["steps"]))
+        for q in range(4):
+            got, want = o.state[q].reshape(H, W, 4).astype(np.float64), arr(f["state"][q], np.float32, (H, W, 4)).astype(np.float64)
+            assert (np.abs(got - want) <= 1e-4 + (2e-3 if q == 0 else 5e-4) * np.abs(want)).all(), "MCM pass %d buffer %d (RG8, NEAREST)" % (k, q)
+        assert (o.state[1].reshape(H, W, 4)[..., 3] == arr(f["state"][1], np.float32, (H, W, 4))[..., 3]).all()
+        assert (o.state[3].reshape(H, W, 4)[..., 3] == arr(f["state"][3], np.float32, (H, W, 4))[..., 3]).all()
+    assert arr(R["mcm"]["frames"][-1]["state"][1], np.float32, (H, W, 4))[..., 3].max() == 1      # the bounce limit was reached and held
+
+
 # ---- the HIP library itself against the reference's text (not only through the oracle) -----------------------------------------------
 @pytest.mark.gpu
 def test_hip_library_against_the_reference_text(gpu_ctx, oracle):
