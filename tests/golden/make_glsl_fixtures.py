@@ -383,6 +383,23 @@ def main():
             r["uniforms_per_frame"] = frames
             fixture["renderers_rg8_nearest"][name] = r
             print("rg8 / nearest %s: %d frames in %.1f s" % (name, len(frames), time.time() - t0), flush=True)
+    # a third scene: the camera INSIDE the volume looking out (tnear < 0: max(tbounds, 0) starts the rays at the eye), a wide field of
+    # view, a 6 x 5 environment map every escaping path reads at another place, a one-texel-wide transfer function column
+    if not args.only or "inside" in args.only.split(","):
+        m3 = camera_matrix(W / H, -2.2, 0.5, 0.2, fovy=1.5)
+        env3 = np.random.default_rng(31).integers(0, 256, size=(5, 6, 4), dtype=np.uint8)
+        tf3 = np.array([[[200, 120, 40, 90]]], dtype=np.uint8)
+        sc3 = dict(sc, matrix=m3, env_s=env_sampler(env3), tf_s=tf_sampler(tf3))
+        fixture["scene_inside"] = {"mvp_inverse_f32": b64(m3), "env_rgba8": b64(env3), "env_shape": list(env3.shape), "tf_rgba8": b64(tf3), "tf_shape": list(tf3.shape)}
+        fixture["renderers_inside"] = {}
+        for name in ("mip", "eam", "mcs", "mcm", "depth"):
+            fn, frames = plans[name]
+            frames = [dict(f, extinction=3.0) if name == "mcm" else f for f in frames[:2]]
+            t0 = time.time()
+            r = fn(parts, sc3, frames)
+            r["uniforms_per_frame"] = frames
+            fixture["renderers_inside"][name] = r
+            print("inside %s: %d frames in %.1f s" % (name, len(frames), time.time() - t0), flush=True)
     if not args.only or "dos" in args.only.split(","):
         fwd = np.linalg.inv(matrix.reshape(4, 4).T.astype(np.float64))                    # column-major inverse-MVP -> the MVP itself
         corners = np.array([[x, y, z, 1.0] for x in (0, 1) for y in (0, 1) for z in (0, 1)])

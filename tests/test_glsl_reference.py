@@ -306,6 +306,49 @@ def test_two_channel_volume_nearest_filter_and_bounce_limit(oracle):
     assert arr(R["mcm"]["frames"][-1]["state"][1], np.float32, (H, W, 4))[..., 3].max() == 1      # the bounce limit was reached and held
 
 
+def test_camera_inside_the_volume_with_an_environment_map(oracle):
+    """the third scene: the eye inside the cube (tnear < 0), wide lens, a 6 x 5 environment map, a 1 x 1 transfer function"""
+    s0, s3 = FX["scene"], FX["scene_inside"]
+    W, H = s0["width"], s0["height"]
+    vol = arr(s0["volume_u8"], np.uint8, s0["volume_dims_zyx"]); tf = arr(s3["tf_rgba8"], np.uint8, s3["tf_shape"]); env = arr(s3["env_rgba8"], np.uint8, s3["env_shape"])
+    m = arr(s3["mvp_inverse_f32"], np.float32, (16,))
+    sc = oracle.OracleScene(vol, "linear", tf=tf, env=env)
+    R = FX["renderers_inside"]
+    for kind in ("mip", "eam", "depth"):
+        ch = {"mip": 1, "eam": 4, "depth": 1}[kind]
+        o = oracle.OracleRenderer(kind, sc, W, H)
+        o.reset(oracle.make_frame(W, H, m))
+        for k, (u, f) in enumerate(zip(R[kind]["uniforms_per_frame"], R[kind]["frames"])):
+            kw = dict(offset=u["offset"], steps=round(1.0 / u["step"]))
+            if kind != "mip":
+                kw.update(extinction=u["extinction"], mix=u["mix"])
+            if kind == "depth":
+                kw.update(threshold=u["threshold"])
+            o.render(oracle.make_frame(W, H, m, **kw))
+            if kind == "depth":
+                close(o.acc.reshape(H, W, 1), arr(f["acc"], np.float32, (H, W, 1)), 1e-5, 1e-6, "Depth accumulator %d (inside)" % k)
+            else:
+                close(o.acc.reshape(H, W, ch), np.rint(arr(f["acc"], np.float32, (H, W, ch)) * 255), 0, 0, "%s accumulator %d (inside)" % (kind, k))
+                close(o.image_f16().astype(np.float32), arr(f["image"], np.float32, (H, W, 4)), 0, 0, "%s image %d (inside)" % (kind, k))
+    o = oracle.OracleRenderer("mcs", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m))
+    for k, (u, f) in enumerate(zip(R["mcs"]["uniforms_per_frame"], R["mcs"]["frames"])):
+        o.render(oracle.make_frame(W, H, m, seed=u["seed"], extinction=u["extinction"], light_dir=u["light"], mix=u["mix"]))
+        # (long shadow rays from inside: a transmittance is a product of dozens of (1 - alpha) factors, 1e-4 .. 1e-3 relative by the end)
+        close(o.acc.reshape(H, W, 4), arr(f["acc"], np.float32, (H, W, 4)), 1.5e-3, 2e-6, "MCS accumulator %d (inside)" % k)
+    o = oracle.OracleRenderer("mcm", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m, seed=s0["mcm_reset_seed"]))
+    close(o.state[0].reshape(H, W, 4), arr(R["mcm"]["reset"]["state"][0], np.float32, (H, W, 4)), 1e-4, 1e-5, "MCM reset position (inside: the eye itself)")
+    for k, (u, f) in enumerate(zip(R["mcm"]["uniforms_per_frame"], R["mcm"]["frames"])):
+        o.render(oracle.make_frame(W, H, m, seed=u["seed"], extinction=u["extinction"], anisotropy=u["anisotropy"], max_bounces=u["max_bounces"], mcm_steps=u["steps"]))
+        for q in range(4):
+            got, want = o.state[q].reshape(H, W, 4).astype(np.float64), arr(f["state"][q], np.float32, (H, W, 4)).astype(np.float64)
+            assert (np.abs(got - want) <= 1e-4 + (2e-3 if q == 0 else 5e-4) * np.abs(want)).all(), "MCM pass %d buffer %d (inside)" % (k, q)
+        assert (o.state[3].reshape(H, W, 4)[..., 3] == arr(f["state"][3], np.float32, (H, W, 4))[..., 3]).all()
+    rad = arr(R["mcm"]["frames"][-1]["state"][3], np.float32, (H, W, 4))
+    assert len(np.unique(np.round(rad[..., 0], 3))) > 30                      # (the environment map colours the escaping paths)
+
+
 # ---- the HIP library itself against the reference's text (not only through the oracle) -----------------------------------------------
 @pytest.mark.gpu
 def test_hip_library_against_the_reference_text(gpu_ctx, oracle):
