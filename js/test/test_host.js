@@ -103,6 +103,23 @@ assert.strictEqual(vpt.RendererFactory('mcm'), vpt.MCMRenderer);
     assert.strictEqual(mk(vpt.DOSRenderer, [8, 8])._getAccumulationBufferSpec().length, 2);
     assert.strictEqual(mk(vpt.DepthRenderer, [8, 8])._getAccumulationBufferSpec()[0].iformat, 33326);   // R32F
 }
+// the transfer-function widget's data model (ui/TransferFunction/TransferFunction.js:74-85, 127-176) without a GPU: bump list, JSON round trip
+{
+    const tfx = JSON.parse(require('fs').readFileSync(require('path').join(__dirname, '../../tests/golden/tf_bumps_r04.json'), 'utf8'));
+    const tf = new vpt.TransferFunction(null);
+    assert.strictEqual(tf.transferFunctionWidth, 256); assert.strictEqual(tf.transferFunctionHeight, 256);
+    assert.strictEqual(tf.addBump(), 0);
+    assert.deepStrictEqual(tf.bumps, tfx.files.default_bump.bumps);
+    tf.addBump({ position: { x: 0.1 }, color: { a: 0.25 } });
+    assert.deepStrictEqual(tf.bumps[1], { position: { x: 0.1, y: 0.5 }, size: { x: 0.2, y: 0.2 }, color: { r: 1, g: 0, b: 0, a: 0.25 } });
+    assert.deepStrictEqual(JSON.parse(tf.dumps()), tf.bumps);
+    assert.deepStrictEqual(new vpt.TransferFunction(null).loads(tf.dumps()).bumps, tf.bumps);
+    assert.strictEqual(tf.packed().length, 16);
+    tf.removeBump(0); assert.strictEqual(tf.bumps.length, 1);
+    tf.removeAllBumps(); assert.strictEqual(tf.packed().length, 0);
+    assert.throws(() => new vpt.TransferFunction(null).loads('{"not":"an array"}'), TypeError);
+    for (const e of Object.values(tfx.files)) assert.deepStrictEqual(new vpt.TransferFunction(null).loads(JSON.stringify(e.bumps)).bumps, e.bumps);
+}
 // the addon loads and reports the struct size the JS side packs
 const { native } = require('../vpt/native.js');
 assert.strictEqual(native().UNIFORMS_BYTES, vpt.U.SIZE);
