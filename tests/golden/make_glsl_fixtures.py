@@ -400,6 +400,25 @@ def main():
             r["uniforms_per_frame"] = frames
             fixture["renderers_inside"][name] = r
             print("inside %s: %d frames in %.1f s" % (name, len(frames), time.time() - t0), flush=True)
+    # the first scene again with parameters at the ends of their ranges: a step count that is no power of two (the MIP loop counts by
+    # adding 1 / steps in fp32), an extinction that drives the EAM alpha above 1 (the renormalisation branch, EAMRenderer.glsl:74-76), a dense
+    # medium for the trackers, strong forward scattering, three events per pass
+    if not args.only or "extremes" in args.only.split(","):
+        ex = {
+            "mip": [{"step": float(np.float32(1.0) / np.float32(7)), "offset": seeds[2]}, {"step": float(np.float32(1.0) / np.float32(13)), "offset": 0.0}],
+            "eam": [{"step": 1.0 / 9, "offset": seeds[0], "extinction": 400.0, "mix": 1.0}, {"step": 1.0 / 33, "offset": 0.0, "extinction": 3.0, "mix": 0.5}],
+            "mcs": [{"seed": seeds[1], "extinction": 80.0, "light": [0.6, 0.0, -0.8], "mix": 1.0}],
+            "mcm": [{"seed": seeds[2], "extinction": 60.0, "anisotropy": 0.9, "max_bounces": 8, "steps": 3},
+                    {"seed": seeds[0], "extinction": 60.0, "anisotropy": -0.9, "max_bounces": 0, "steps": 11}],
+            "depth": [{"step": 1.0 / 50, "offset": seeds[1], "extinction": 500.0, "threshold": 0.99, "mix": 1.0}],
+        }
+        fixture["renderers_extremes"] = {}
+        for name, frames in ex.items():
+            t0 = time.time()
+            r = plans[name][0](parts, sc, frames)
+            r["uniforms_per_frame"] = frames
+            fixture["renderers_extremes"][name] = r
+            print("extremes %s: %d frames in %.1f s" % (name, len(frames), time.time() - t0), flush=True)
     if not args.only or "dos" in args.only.split(","):
         fwd = np.linalg.inv(matrix.reshape(4, 4).T.astype(np.float64))                    # column-major inverse-MVP -> the MVP itself
         corners = np.array([[x, y, z, 1.0] for x in (0, 1) for y in (0, 1) for z in (0, 1)])

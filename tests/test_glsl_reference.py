@@ -349,6 +349,43 @@ def test_camera_inside_the_volume_with_an_environment_map(oracle):
     assert len(np.unique(np.round(rad[..., 0], 3))) > 30                      # (the environment map colours the escaping paths)
 
 
+def test_parameters_at_the_ends_of_their_ranges(oracle):
+    """the first scene with a step count that is no power of two (the MIP loop counts by adding 1 / steps in fp32), the EAM alpha above 1
+    (its renormalisation branch), a dense medium for the trackers, |g| = 0.9, a bounce limit of 0, three / eleven events per pass"""
+    sc, m, W, H = scene(oracle)
+    R = FX["renderers_extremes"]
+    for kind in ("mip", "eam", "depth"):
+        ch = {"mip": 1, "eam": 4, "depth": 1}[kind]
+        o = oracle.OracleRenderer(kind, sc, W, H)
+        o.reset(oracle.make_frame(W, H, m))
+        for k, (u, f) in enumerate(zip(R[kind]["uniforms_per_frame"], R[kind]["frames"])):
+            fr = oracle.make_frame(W, H, m, offset=u["offset"], steps=1, **({} if kind == "mip" else dict(extinction=u["extinction"], mix=u["mix"])),
+                                   **(dict(threshold=u["threshold"]) if kind == "depth" else {}))
+            fr.step = float(np.float32(u["step"]))                             # the uniform itself (1 / steps as the host rounds it)
+            o.render(fr)
+            if kind == "depth":
+                close(o.acc.reshape(H, W, 1), arr(f["acc"], np.float32, (H, W, 1)), 1e-5, 1e-6, "Depth accumulator %d (extremes)" % k)
+            else:
+                close(o.frame.reshape(H, W, ch), np.rint(arr(f["frame"], np.float32, (H, W, ch)) * 255), 0, 0, "%s frame %d (extremes)" % (kind, k))
+                close(o.acc.reshape(H, W, ch), np.rint(arr(f["acc"], np.float32, (H, W, ch)) * 255), 0, 0, "%s accumulator %d (extremes)" % (kind, k))
+    o = oracle.OracleRenderer("mcs", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m))
+    for k, (u, f) in enumerate(zip(R["mcs"]["uniforms_per_frame"], R["mcs"]["frames"])):
+        o.render(oracle.make_frame(W, H, m, seed=u["seed"], extinction=u["extinction"], light_dir=u["light"], mix=u["mix"]))
+        close(o.acc.reshape(H, W, 4), arr(f["acc"], np.float32, (H, W, 4)), 1.5e-3, 2e-6, "MCS accumulator %d (extremes)" % k)
+    o = oracle.OracleRenderer("mcm", sc, W, H)
+    o.reset(oracle.make_frame(W, H, m, seed=FX["scene"]["mcm_reset_seed"]))
+    for k, (u, f) in enumerate(zip(R["mcm"]["uniforms_per_frame"], R["mcm"]["frames"])):
+        o.render(oracle.make_frame(W, H, m, seed=u["seed"], extinction=u["extinction"], anisotropy=u["anisotropy"], max_bounces=u["max_bounces"], mcm_steps=u["steps"]))
+        for q in range(4):
+            got, want = o.state[q].reshape(H, W, 4).astype(np.float64), arr(f["state"][q], np.float32, (H, W, 4)).astype(np.float64)
+            assert (np.abs(got - want) <= 1e-4 + (2e-3 if q == 0 else 5e-4) * np.abs(want)).all(), "MCM pass %d buffer %d (extremes)" % (k, q)
+        assert (o.state[1].reshape(H, W, 4)[..., 3] == arr(f["state"][1], np.float32, (H, W, 4))[..., 3]).all()
+        assert (o.state[3].reshape(H, W, 4)[..., 3] == arr(f["state"][3], np.float32, (H, W, 4))[..., 3]).all()
+    pos = arr(R["mcm"]["frames"][-1]["state"][0], np.float32, (H, W, 4))[..., :3]
+    assert ((pos > 0) & (pos < 1)).all(axis=2).sum() > 40                      # (the dense medium holds the photons inside the volume)
+
+
 # ---- the HIP library itself against the reference's text (not only through the oracle) -----------------------------------------------
 @pytest.mark.gpu
 def test_hip_library_against_the_reference_text(gpu_ctx, oracle):
