@@ -681,10 +681,12 @@ def test_play_frame_sequences_equal_render_calls(gpu_ctx, oracle, kind):
     """vpt_renderer_play: per-frame uniforms from a device table, eager and as a replayed hipGraph == N x render()"""
     sc = Scene(gpu_ctx, oracle, 32, 100, 70, tf=colour_tf(64, 1), camera=orbit_camera(100 / 70))
 
-    def make():
+    def make(one_stream=False):
         r = sc.renderer(kind)
         if kind in ('mcs', 'mcm'):
             r.extinction = 9
+        if one_stream:
+            r.set_option(N.OPTION_SPLIT_STREAMS, 1); r.set_option(N.OPTION_TILE_CLASSES, 0)
         r.reset()
         return r
 
@@ -697,11 +699,16 @@ def test_play_frame_sequences_equal_render_calls(gpu_ctx, oracle, kind):
     eager.play(3, use_graph=False); eager.play(7, use_graph=False)
     assert_same_bits(eager.getTexture(), want_img, "%s eager play" % kind); assert_same_bits(eager.read(buf), want_buf, "%s eager play buffer" % kind)
     assert eager.sample_count() == want_ns
+    # VPT_PLAY_GRAPH replays a hipGraph where that is the faster form: a renderer on one stream without tile classes (the first case);
+    # with the defaults the same call plays the sequence eagerly (the second) — identical buffers either way
+    for one_stream in (True, False):
+        graph = make(one_stream)
+        graph.render(); graph.render()                      # warm: lazy allocations happen outside the capture
+        graph.play(4, use_graph=True); graph.play(4, use_graph=True)     # second call replays the cached graph
+        assert_same_bits(graph.getTexture(), want_img, "%s graph play" % kind); assert_same_bits(graph.read(buf), want_buf, "%s graph play buffer" % kind)
+        assert graph.sample_count() == want_ns
+        graph.destroy()
     graph = make()
-    graph.render(); graph.render()                      # warm: lazy allocations happen outside the capture
-    graph.play(4, use_graph=True); graph.play(4, use_graph=True)     # second call replays the cached graph
-    assert_same_bits(graph.getTexture(), want_img, "%s graph play" % kind); assert_same_bits(graph.read(buf), want_buf, "%s graph play buffer" % kind)
-    assert graph.sample_count() == want_ns
     if kind == "mcm":
         fusedr = make()
         fusedr.play(4, fused=True); fusedr.play(1, fused=True); fusedr.render(); fusedr.play(4, fused=True)      # 10 passes, mixed with a plain render()

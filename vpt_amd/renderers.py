@@ -277,7 +277,8 @@ class AbstractRenderer(PropertyBag):
         return u, vars_
 
     def play(self, count, use_graph=True, fused=False, frames=False):
-        """`count` render() passes enqueued by one native call: eager launches, one hipGraph replay (use_graph), one launch
+        """`count` render() passes enqueued by one native call: eager launches, one hipGraph replay (use_graph: where the library
+        knows the graph to be the faster form — one stream, no tile classes — else eager all the same), one launch
         running all passes with the photon state / accumulator in registers (fused), or — MCM — the same with EVERY pass's
         frame written to the renderer's frame ring (frames; read_frame_slot); same buffers as count x render()"""
         self._bind_volume()
