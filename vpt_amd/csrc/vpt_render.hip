@@ -190,6 +190,12 @@ int play_args(vpt_renderer *r, const vpt_uniforms *base, int count, PassArgs *a)
     if (r->kind == VPT_RENDERER_MIP || r->kind == VPT_RENDERER_EAM) VPT_TRY(check_step(base));
     return make_args(r, base, true, a);
 }
+#define VPT_TABLE_BY_ARGS 32
+struct FrameVarBlock { FrameVar v[VPT_TABLE_BY_ARGS]; };
+__global__ void k_store_frame_vars(FrameVar *table, FrameVarBlock blk, uint32_t pos, uint32_t count, uint32_t mask) {
+    const uint32_t t = threadIdx.x;
+    if (t < count) table[(pos + t) & mask] = blk.v[t];
+}
 int play_upload_table(vpt_renderer *r, const float *vars, int count, PassArgs *a) {
     vpt_context *c = r->ctx;
     static_assert(sizeof(FrameVar) == 8 * sizeof(float), "FrameVar is 8 floats");
@@ -204,13 +210,22 @@ int play_upload_table(vpt_renderer *r, const float *vars, int count, PassArgs *a
     if ((r->frames_played % (VPT_FRAME_RING / 2)) + (uint64_t)count > VPT_FRAME_RING / 2) HIP_TRY(hipStreamSynchronize(c->stream));
     const FrameVar *src = (const FrameVar *)vars;
     int pos = (int)(r->frames_played % VPT_FRAME_RING);
-    int first = count < VPT_FRAME_RING - pos ? count : VPT_FRAME_RING - pos;
-    memcpy(r->frame_staging + pos, src, (size_t)first * sizeof(FrameVar));
-    HIP_TRY(hipMemcpyAsync(r->frame_table + pos, r->frame_staging + pos, (size_t)first * sizeof(FrameVar), hipMemcpyHostToDevice, c->stream));
-    if (first < count) {
-        memcpy(r->frame_staging, src + first, (size_t)(count - first) * sizeof(FrameVar));
-        HIP_TRY(hipMemcpyAsync(r->frame_table, r->frame_staging, (size_t)(count - first) * sizeof(FrameVar), hipMemcpyHostToDevice, c->stream));
+    if (count <= VPT_TABLE_BY_ARGS) {
+        // short sequences: the entries travel in the arguments of a one-wave kernel (a copy engine's H2D transfer in the middle of the stream
+        // costs the sequence 10-20 us of idle chip; measured per play() call of 4 / 16 frames)
+        FrameVarBlock blk;
+        memcpy(blk.v, src, (size_t)count * sizeof(FrameVar));
+        hipLaunchKernelGGL(k_store_frame_vars, dim3(1), dim3(64), 0, c->stream, r->frame_table, blk, (uint32_t)pos, (uint32_t)count, (uint32_t)(VPT_FRAME_RING - 1));
+    } else {
+        int first = count < VPT_FRAME_RING - pos ? count : VPT_FRAME_RING - pos;
+        memcpy(r->frame_staging + pos, src, (size_t)first * sizeof(FrameVar));
+        HIP_TRY(hipMemcpyAsync(r->frame_table + pos, r->frame_staging + pos, (size_t)first * sizeof(FrameVar), hipMemcpyHostToDevice, c->stream));
+        if (first < count) {
+            memcpy(r->frame_staging, src + first, (size_t)(count - first) * sizeof(FrameVar));
+            HIP_TRY(hipMemcpyAsync(r->frame_table, r->frame_staging, (size_t)(count - first) * sizeof(FrameVar), hipMemcpyHostToDevice, c->stream));
+        }
     }
+    r->main_dirty = true;                             // the side streams of a split pass read the table too: they fork behind this upload
     a->frame_base = (uint32_t)r->frames_played;       // == the device counter when the sequence starts (both advance by `count` per sequence)
     r->frames_played += (uint64_t)count;
     a->frame_table = r->frame_table;
@@ -222,7 +237,6 @@ static bool play_key_equal(const PassArgs &x, const PassArgs &y) { return memcmp
 
 extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, const float *frame_vars, int count, int use_graph) {
     if (!r || !base || !frame_vars) return fail(VPT_ERR_INVALID, "null argument");
-    VPT_TRY(join_side(r));
     if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "frame sequences are not defined for the DOS renderer: drive it slice by slice");
     vpt_context *c = r->ctx;
     HIP_TRY(hipSetDevice(c->device));
@@ -234,6 +248,9 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
     // same sequence, not for a hipGraph at any price: the graph is kept for renderers set to one stream without tile classes, where the
     // launches are the same and one replay saves the host count - 1 enqueues.
     if (use_graph == VPT_PLAY_GRAPH && (r->cls.enabled || (r->split > 1 && !r->target_is_callers))) use_graph = VPT_PLAY_EAGER;
+    // (eager sequences and the marchers' fused passes are launched exactly as render() launches them: the streams of a split pass are not
+    // joined between two calls any more than between two render() calls; a captured graph and MCM's whole-image sequence kernels join)
+    if (use_graph == VPT_PLAY_GRAPH || ((use_graph == VPT_PLAY_FUSED || use_graph == VPT_PLAY_FRAMES) && r->kind == VPT_RENDERER_MCM)) VPT_TRY(join_side(r));
     if (use_graph == VPT_PLAY_GRAPH && r->warmed) {
         VPT_TRY(play_upload_table(r, frame_vars, count, &a));
         // a captured sequence runs whole-image kernels (a graph freezes its grids; tile lists change with every reset)
