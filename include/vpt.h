@@ -228,7 +228,8 @@ VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, si
  * 8-byte ones.  0 = always the bricks. */
 #define VPT_OPTION_BOUNDARY_ATLAS 3
 /* VPT_OPTION_SPLIT_STREAMS (every renderer but DOS; default since round 4: MCM 2 — the HIT | MISS kernels of the tile classes —, MIP / EAM /
- * Depth 3, ISO / MCS / LAO 2: the measured best forms, so that a caller who sets nothing gets them; VPT_DEFAULT_SPLIT=1 in the environment restores 1
+ * Depth 3, ISO / MCS / LAO 2: the measured best forms at 1080p, so that a caller who sets nothing gets them (the default follows the launch size: a frame of a few hundred tiles
+ * stays on one or two streams; a count set through the option is taken as it is); VPT_DEFAULT_SPLIT=1 in the environment restores 1
  * everywhere): K in 2 .. VPT_MAX_SPLIT = a pass is launched as K tile-row ranges (or K parts of a tile list), all but
  * the first on private side streams (created by the first pass that uses them).  A pixel's pass depends on its own previous pass only, so consecutive passes of the
  * ranges never wait for each other and the launch gap, ramp and tail of one range overlap the body of the others (HIP

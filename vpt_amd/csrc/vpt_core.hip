@@ -442,7 +442,7 @@ extern "C" int vpt_renderer_create(vpt_context *c, int kind, int width, int heig
     r->frame_table = nullptr; r->frame_staging = nullptr; r->frame_counter = nullptr; r->frames_played = 0;
     r->warmed = false; r->play_graph = nullptr;
     r->fast_math = 0; r->boundary_atlas = 1; r->column_records = 2;
-    r->frame_ring = nullptr; r->ring_frames = 0; r->split = default_split(kind); r->target_is_callers = false; r->no_split = false; r->bucket_call = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
+    r->frame_ring = nullptr; r->ring_frames = 0; r->split = default_split(kind); r->split_auto = true; r->target_is_callers = false; r->no_split = false; r->bucket_call = false; r->last_ranges = 1; r->stop_events = nullptr; r->stop_used = false; r->ev_fork = nullptr; for (int i = 0; i < VPT_MAX_SPLIT - 1; i++) { r->side[i] = nullptr; r->ev_join[i] = nullptr; } r->side_busy = false; r->main_dirty = true; r->mcm_persistent = 0; r->work_counter = nullptr; r->mcs_persistent = false;   // measured slower than k_mcs at every extinction tried
     r->render_target = nullptr;
     memset(&r->cls, 0, sizeof(r->cls)); r->cls.enabled = true; r->last_layout = 0; { const char *e = getenv("VPT_HIT_KERNEL_FORM"); r->hit_form = (e && (e[0] == '1' || e[0] == '2') && !e[1]) ? e[0] - '0' : 0; } r->bucket_kernel = false; r->bucket_launches = 0;
     r->tm_owner = nullptr; r->tm_valid = false; r->tm_table = nullptr; r->tm_out = nullptr; r->tm_mode = 0;
@@ -967,7 +967,7 @@ extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
             if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_SPLIT_STREAMS: the DOS renderer's slices depend on each other across pixels");
             if (value < 1 || value > VPT_MAX_SPLIT) return fail(VPT_ERR_INVALID, "VPT_OPTION_SPLIT_STREAMS: 1 .. %d", VPT_MAX_SPLIT);
             VPT_TRY(join_side(r));
-            r->split = value;
+            r->split = value; r->split_auto = false;          // a count the caller asked for is taken as it is (vpt_internal.h split_for)
             return ensure_split_streams(r);
         case VPT_OPTION_FAST_MATH:
             if (r->kind != VPT_RENDERER_MCM) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_FAST_MATH: only the MCM renderer has a fast-arithmetic variant");

@@ -139,7 +139,8 @@ struct vpt_renderer {
     int last_ranges;               // how many tile-row ranges (streams) the last sampling launch used
     hipEvent_t *stop_events;       // gather pipeline: event i is attached to range i's launch (hipExtLaunchKernel stop event: the
     bool stop_used;                // dispatch packet's own completion signal, no barrier packet behind the kernel)
-    int split; hipStream_t side[VPT_MAX_SPLIT - 1]; hipEvent_t ev_fork, ev_join[VPT_MAX_SPLIT - 1]; bool side_busy, main_dirty;
+    int split; bool split_auto;     // split_auto: the stream count is the library's default and follows the launch size (split_for)
+    hipStream_t side[VPT_MAX_SPLIT - 1]; hipEvent_t ev_fork, ev_join[VPT_MAX_SPLIT - 1]; bool side_busy, main_dirty;
     int boundary_atlas;            // VPT_OPTION_BOUNDARY_ATLAS (default 1): MCM takes out-of-cube samples from the volume's boundary atlas
     int fast_math;                 // VPT_OPTION_FAST_MATH: MCM events with hardware rcp / rsq / log / sin / cos (k_mcm_integrate<.., V | VPT_V_FAST>)
     int mcm_persistent;            // 0: k_mcm_integrate; 1: k_mcm_persist; 2: k_mcm_persist with next-segment prefetch // (persistent waves, state prefetch) for the MCM integrate pass
@@ -269,6 +270,19 @@ static void launch_range(K kernel, vpt_renderer *r, dim3 grid, dim3 block, size_
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
     }
 }
+// The streams a sampling launch of `tiles` tiles is dealt to.  The library's default counts (vpt_core.hip default_split) are those of a
+// 1080p frame; a small frame is a handful of workgroups per stream and the fork / join edges cost more than the overlap returns — measured
+// per renderer at 256^2 / 512^2 / 1024^2 (us per frame on 1 | 2 | 3 streams): EAM 39 | 46 | 49, 38 | 37 | 38, 48 (3); MIP 36 | 45 | 54,
+// 40 | 34 | 38; MCS 9.8 | 12.0, 10.4 | 12.2, 14.9 | 13.8; ISO 38.8 | 43.6, 39.9 | 42.2, 45.7 | 42.4; Depth 41 | 46 | 43, 41 | 40 | 41.
+// A count set through VPT_OPTION_SPLIT_STREAMS is taken as it is.
+static inline int split_for(const vpt_renderer *r, int tiles) {
+    int k = r->split;
+    if (r->split_auto && k > 1) {
+        const int per = (r->kind == VPT_RENDERER_MIP || r->kind == VPT_RENDERER_EAM || r->kind == VPT_RENDERER_DEPTH) ? 192 : (r->kind == VPT_RENDERER_LAO ? 32 : 384);
+        k = std::min(k, std::max(1, tiles / per));
+    }
+    return k;
+}
 template <typename K>
 static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigned) {
     size_t lds = lds_bytes(r);
@@ -285,9 +299,9 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     // (vpt_renderer_play_into*: one join per bucket of frames, at the end of the call).  The gather pipeline waits for every range itself.)
     if (r->cls.list_now) {
         // the HIT tiles only (marcher_track): K equal parts of the list on the K streams
-        if (r->side_busy && r->last_layout != 1) VPT_TRY(join_side(r));
+        const int k = split ? std::min(split_for(r, r->cls.n_hit), r->cls.n_hit) : 1;
+        if (r->side_busy && (r->last_layout != 1 || r->last_ranges != k)) VPT_TRY(join_side(r));      // the tile -> stream map changes
         r->last_layout = 1;
-        const int k = split ? std::min(r->split, r->cls.n_hit) : 1;
         if (k >= 2 && r->main_dirty) {
             HIP_TRY(hipEventRecord(r->ev_fork, r->ctx->stream));
             for (int i = 0; i + 1 < r->split; i++) HIP_TRY(hipStreamWaitEvent(r->side[i], r->ev_fork, 0));
@@ -304,11 +318,12 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
         r->last_ranges = k;
         return VPT_OK;
     }
-    if (r->side_busy && r->last_layout != 0) VPT_TRY(join_side(r));     // the previous pass dealt tile LISTS to the streams
+    const int kw = split ? split_for(r, r->tiles_x * r->tiles_y) : 1;
+    if (r->side_busy && (r->last_layout != 0 || r->last_ranges != kw)) VPT_TRY(join_side(r));     // the previous pass dealt the tiles to the streams in another way
     r->last_layout = 0;
-    if (split && r->tiles_y >= r->split) {
+    if (split && kw >= 2 && r->tiles_y >= kw) {
         dim3 g = tile_grid(r);
-        const unsigned k = (unsigned)r->split;
+        const unsigned k = (unsigned)kw;
         if (r->main_dirty) {      // whatever the context's stream did to the renderer's buffers since the last join comes first
             HIP_TRY(hipEventRecord(r->ev_fork, r->ctx->stream));
             for (unsigned i = 0; i + 1 < k; i++) HIP_TRY(hipStreamWaitEvent(r->side[i], r->ev_fork, 0));
@@ -324,6 +339,7 @@ static int launch_sampling(K kernel, vpt_renderer *r, const PassArgs &a, unsigne
     } else {
         dim3 g = tile_grid(r);
         launch_range(kernel, r, dim3(g.x * xmul, g.y), block, lds, r->ctx->stream, a, 0);
+        r->last_ranges = 1;
     }
     return VPT_OK;
 }
