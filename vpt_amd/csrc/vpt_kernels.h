@@ -15,9 +15,13 @@
 #define VPT_TILE        16
 #define VPT_BLOCK       256
 #define VPT_MAX_TRACK_ITERS 65536u
+#ifndef VPT_UNROLL
 #define VPT_UNROLL      4          // samples in flight per ray in the EAM / ISO / Depth marches (8: EAM 4 %, ISO 8 % slower —
                                    // their early exits throw the speculative samples away)
+#endif
+#ifndef VPT_UNROLL_MIP
 #define VPT_UNROLL_MIP  8          // MIP has no early exit: 8 in flight is 3 % faster than 4
+#endif
 // waves per SIMD a kernel is compiled for (its register budget): VPT_WAVES_ATTR(n) = amdgpu_waves_per_eu(n, 8), n = 0 leaves the choice
 // to the compiler.  The per-kernel values are measured ones (profiles/experiments.md, "occupancy")
 #define VPT_WAVES_ATTR(n)  VPT_WAVES_ATTR_(n)
