@@ -195,6 +195,37 @@ def test_eam_full_hd_on_and_off(gpu_ctx, oracle):
     sc.gvol.destroy()
 
 
+@pytest.mark.parametrize("kind", ["mip", "eam", "mcs", "iso", "depth"])
+@pytest.mark.parametrize("size", [(256, 256), (512, 512), (816, 624)])
+def test_default_stream_count_follows_the_launch_size(gpu_ctx, oracle, kind, size):
+    """the library's default stream count is that of a 1080p frame and follows the launch size (vpt_internal.h split_for): a frame of a few
+    hundred tiles runs its whole-image passes on more streams than its HIT-tile lists (512^2: EAM 3 -> 2, MCS 2 -> 1), a smaller one stays on
+    one — every frame, with resets in between, equals the one-stream whole-image renderer's"""
+    from vpt_amd.scene import default_camera
+    w, h = size
+    sc = Scene(gpu_ctx, oracle, 48, w, h, tf=colour_tf(32, 1), camera=default_camera(w / h), noise=40.0)
+
+    def run(default):
+        r = sc.renderer(kind)
+        if not default:
+            r.set_option(N.OPTION_SPLIT_STREAMS, 1); r.set_option(N.OPTION_TILE_CLASSES, 0)
+        frames = []
+        for rounds in range(2):
+            r.reset()
+            for _ in range(5):
+                r.render()
+                frames.append(outputs(r))
+        r.play(3, use_graph=False); frames.append(outputs(r))
+        r.play(4, fused=True); frames.append(outputs(r))
+        r.destroy()
+        return frames
+
+    want, got = run(False), run(True)
+    for k, (a, b) in enumerate(zip(want, got)):
+        same(a, b, "%s %dx%d, frame %d" % (kind, w, h, k))
+    sc.gvol.destroy()
+
+
 # ---- render destinations other than the renderer's own buffer (round 4) ---------------------------------------------------------------
 # A pass that launches the HIT tiles only leaves the other texels of its DESTINATION as they are: right only where a whole-image pass has
 # written that destination since the reset.  A caller's render target, the slots of a bucket and the gather's ring change from frame to
