@@ -172,7 +172,7 @@ VPT_API int vpt_renderer_render(vpt_renderer *r, const vpt_uniforms *u);
  * VPT_PLAY_GRAPH: the launch sequence is captured once into a hipGraph and replayed (uniforms from a device table read
  * through a device-side frame counter) — where that is the faster form: a captured sequence is whole-image kernels on one stream, so a
  * renderer whose passes run as tile lists and / or on several streams (the defaults) plays the sequence eagerly instead; set
- * VPT_OPTION_SPLIT_STREAMS 1 and VPT_OPTION_TILE_CLASSES 0 to get the graph.  VPT_PLAY_FUSED (MIP, EAM, MCS, MCM, ISO, Depth): ONE launch runs all `count` passes
+ * VPT_OPTION_SPLIT_STREAMS 1 and VPT_OPTION_TILE_CLASSES 0 to get the graph.  VPT_PLAY_FUSED (MIP, EAM, MCS, MCM, ISO, Depth; MCM below 8 passes: played eagerly, the faster form there): ONE launch runs all `count` passes
  * of a pixel back to back with the photon state (MCM) or the accumulator (MIP, EAM, MCS, ISO, Depth) in registers — no
  * round trip through HBM between passes.  VPT_PLAY_FRAMES (MCM): VPT_PLAY_FUSED that still WRITES EVERY FRAME — pass f of the call
  * goes to slot f of the renderer's frame ring ([VPT_FRAME_SLOTS][local rows][width] RGBA16F, allocated on first use; count <=

@@ -248,6 +248,9 @@ extern "C" int vpt_renderer_play(vpt_renderer *r, const vpt_uniforms *base, cons
     // same sequence, not for a hipGraph at any price: the graph is kept for renderers set to one stream without tile classes, where the
     // launches are the same and one replay saves the host count - 1 enqueues.
     if (use_graph == VPT_PLAY_GRAPH && (r->cls.enabled || (r->split > 1 && !r->target_is_callers))) use_graph = VPT_PLAY_EAGER;
+    // MCM's passes-in-registers kernel is a whole-image launch on one stream: it beats the tile-class passes on two streams from 8 passes per
+    // launch on (1080p, us per pass, bit-exact | fast-math: loop 93.0 | 78.7; 2 per launch 109.1 | 100.7, 4: 97.1 | 84.6, 8: 92.5 | 75.1, 16: 90.9 | 70.2)
+    if (use_graph == VPT_PLAY_FUSED && r->kind == VPT_RENDERER_MCM && count < 8 && r->cls.enabled && r->split > 1 && !r->target_is_callers) use_graph = VPT_PLAY_EAGER;
     // (eager sequences and the marchers' fused passes are launched exactly as render() launches them: the streams of a split pass are not
     // joined between two calls any more than between two render() calls; a captured graph and MCM's whole-image sequence kernels join)
     if (use_graph == VPT_PLAY_GRAPH || ((use_graph == VPT_PLAY_FUSED || use_graph == VPT_PLAY_FRAMES) && r->kind == VPT_RENDERER_MCM)) VPT_TRY(join_side(r));
