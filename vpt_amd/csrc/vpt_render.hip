@@ -88,10 +88,10 @@ extern "C" int vpt_renderer_reset(vpt_renderer *r, const vpt_uniforms *u) {
 }
 extern "C" int vpt_renderer_generate(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r) return fail(VPT_ERR_INVALID, "null argument");
-    VPT_TRY(join_side(r));
     if (r->kind == VPT_RENDERER_DOS) return VPT_OK;                 // DOSRenderer.js has no _generateFrame (AbstractRenderer.js:122-124: empty)
     if (!u) return fail(VPT_ERR_INVALID, "null argument");
-    if (r->kind == VPT_RENDERER_MCM) return VPT_OK;                 // MCMRenderer.js:118-119: empty
+    if (r->kind == VPT_RENDERER_MCM) return VPT_OK;                 // MCMRenderer.js:118-119: empty (and nothing to order: the class kernels stay on their streams)
+    VPT_TRY(join_side(r));
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind != VPT_RENDERER_MCS) VPT_TRY(check_step(u));
     if (r->kind == VPT_RENDERER_ISO) VPT_TRY(check_iso(u));
@@ -126,7 +126,7 @@ extern "C" int vpt_renderer_integrate(vpt_renderer *r, const vpt_uniforms *u) {
 }
 extern "C" int vpt_renderer_render_frame(vpt_renderer *r, const vpt_uniforms *u) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
-    VPT_TRY(join_side(r));
+    if (r->kind != VPT_RENDERER_MCM) VPT_TRY(join_side(r));    // (MCM: mcm_render_frame — behind a pass of the tile classes each class's texels are written by its own stream)
     r->tm_valid = false;                                       // (the hook kernels do not tone-map: the next vpt_tonemapper_render runs its own pass)
     HIP_TRY(hipSetDevice(r->ctx->device));
     if (r->kind == VPT_RENDERER_ISO && !u) return fail(VPT_ERR_INVALID, "ISO renderFrame needs uniforms (uLight, uGradientStep)");
