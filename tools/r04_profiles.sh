@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 evidence: rocprofv3 kernel statistics (+ PMC passes) of the shipped library; summaries are copied to gpurun_out/r04/profiles/ under
 # the names profiles/ keeps them by.  Every *_kernel_stats.csv carries the traced run's own ms_per_step in its header.
-#   tools/r04_profiles.sh 1 | 2 | 3      (three calls on the GPU pool, each within one box's time limit)
+#   tools/r04_profiles.sh 1 | 2 | 3 | 4     (four calls on the GPU pool, each within one box's time limit)
 set -o pipefail
 P=gpurun_out/r04/profiles; mkdir -p $P
 run() {   # name, bench.py arguments
@@ -28,5 +28,12 @@ if [ $part = 3 ]; then
 PMC=0 run eam256_default_three_streams --renderer eam --volume 256
 run eam256_one_stream --renderer eam --volume 256 --split-streams 1
 PMC=0 run mcs512_default --renderer mcs
+fi
+if [ $part = 4 ]; then
+# the other ray marchers on the library's defaults (kernel traces only)
+PMC=0 run mip512_default --renderer mip
+PMC=0 run iso512_default --renderer iso
+PMC=0 run depth512_default --renderer depth
+PMC=0 run lao512_default --renderer lao --steps 20 --warmup 3
 fi
 ls $P
