@@ -111,6 +111,10 @@ def parse():
                          "collective costs the host ~25 us whatever its size and a bucket's launches ~10 us per frame, against the ~17 us a "
                          "1/8 shard's kernels take: measured on a one-rank group with 1920x136 frames 27.2 / 23.3 / 22.8 us per frame at F = 4 / 8 / 16)")
     ap.add_argument("--force-dist", type=int, default=0, help="initialise RCCL and run the frame all_gather even with one rank")
+    ap.add_argument("--rehearsal", type=int, default=0,
+                    help="1 = N ranks on ONE GPU (every rank on device 0) with the collectives over gloo instead of RCCL, which refuses two ranks on one "
+                         "device: runs the whole N > 1 control flow of this file (shards of every rank, buckets, frame checks, the forms beside the line) "
+                         "where only one GPU exists.  The line says `rehearsal`; its figures are NOT measurements of anything")
     return ap.parse_args()
 
 
@@ -468,6 +472,9 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.rehearsal:
+        local_rank = 0                                     # every rank on the box's one GPU
+        args.gather = "torch"                              # the native pipeline is RCCL's; two ranks on one device are refused by it
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -475,7 +482,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     W, H = args.width, args.height
     vol = sphere_volume(args.volume, noise=48.0)
@@ -669,6 +679,9 @@ def main():
                              "frac_own_layout": achieved / HBM_PEAK_GBS * (own_bps / bps)},
                 "frame_check": res["ok"],
             }
+            if args.rehearsal:
+                line["rehearsal"] = ("%d ranks on ONE GPU, collectives over gloo (--rehearsal 1): the N > 1 control flow only; none of this line's figures "
+                                     "is a measurement" % world)
             alone = state.get("alone")
             if alone and kernels:
                 # each class kernel ALONE on the chip (one stream, VPT_OPTION_TILE_CLASSES 2, measured after the timed region): its own fraction of

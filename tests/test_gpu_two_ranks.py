@@ -65,3 +65,40 @@ def test_torch_pipeline_on_one_rank_frame_by_frame_and_with_bucket_kernels():
     d = line["config"]["display_gather_form"]                    # ... and gathering the tone-mapped RGBA8 frames (vpt_renderer_play_into_display)
     assert d["frame_check"] is True and d["bucket_launches"] >= (1000 + 2 * 32) // 16
     assert d["bytes_per_frame_and_xgmi_link"] == 640 * 368 * 4
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_rehearsal_with_several_ranks_on_one_gpu(world):
+    """bench.py --gpus N --rehearsal 1: N rank processes on the box's ONE GPU with the collectives over gloo (RCCL refuses two ranks on one
+    device).  Everything of the N > 1 path above the collective's transport runs with a real world size: every rank's shard (interleaved row
+    blocks, padding: 368 rows over 3 ranks), buckets of 16 frames through vpt_renderer_play_into, the gathered frame bit-compared with the same
+    frames unsharded on every rank, the bucket-kernel and RGBA8 display forms, the single-GPU reference, max-over-ranks timing, ONE JSON line
+    from rank 0.  Its figures measure nothing (the ranks share one GPU); the line says so."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rehearsal", "1", "--volume", "64",
+                                       "--width", "640", "--height", "368", "--steps", "40", "--warmup", "8", "--repeats", "2", "--stream-probe", "0",
+                                       "--warmup-seconds", "0.05", "--watchdog", "500"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=560))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the rehearsal did not finish in 560 s")
+    assert all(p.returncode == 0 for p in procs), "\n".join(e.decode(errors="replace")[-2000:] for _, e in outs)
+    lines = [o.decode().strip() for o, _ in outs]
+    assert all(l == "" for l in lines[1:]), "only rank 0 prints"
+    line = json.loads(lines[0].splitlines()[-1])
+    assert line["n_gpus"] == world and "rehearsal" in line and line["frame_check"] is True
+    assert line["config"]["frames_per_gather"] == 16
+    assert line["config"]["bucket_kernel_form"]["frame_check"] is True
+    assert line["config"]["display_gather_form"]["frame_check"] is True
+    assert line["config"]["single_gpu_reference"]["frame_by_frame_ms"] > 0
+    assert 640 * 368 * 8 <= line["config"]["samples_per_step"] <= 640 * (368 + 8 * world) * 8      # every pixel of the frame (+ at most one padding block per rank)
