@@ -860,10 +860,11 @@ def main():
                 # (every rank must run the same number of steps — the collectives are matched —, so the length of the time-based part is agreed on:
                 # 1000 steps are timed, the slowest rank's figure decides how many more make up --warmup-seconds)
                 t_w = time.perf_counter()
-                run_steps(1000); drain(); torch.cuda.synchronize()
+                nw = 64 if args.rehearsal else 1000               # (a rehearsal measures nothing: a short warm-up)
+                run_steps(nw); drain(); torch.cuda.synchronize()
                 tw = torch.tensor([time.perf_counter() - t_w], dtype=torch.float64, device=device)
                 dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-                more = int(min(60000.0, max(0.0, args.warmup_seconds - float(tw[0])) / max(float(tw[0]) / 1000.0, 1e-7)))
+                more = int(min(60000.0, max(0.0, args.warmup_seconds - float(tw[0])) / max(float(tw[0]) / nw, 1e-7)))
                 more -= more % max(1, pipe["gather"].F)
                 if more > 0:
                     run_steps(more); drain(); torch.cuda.synchronize()
