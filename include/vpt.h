@@ -207,13 +207,12 @@ VPT_API int vpt_renderer_render_buffer_device(vpt_renderer *r, void **device_ptr
 VPT_API int vpt_renderer_set_render_target(vpt_renderer *r, void *device_ptr, size_t nbytes);
 /* implementation switches (results are identical either way).  VPT_OPTION_MCS_PERSISTENT (default 0): run the MCS
  * generate pass as persistent waves with __ballot/__popcll active-ray compaction instead of one thread per pixel
- * (measured slower on MI355X at extinction 1..200 for 512^3 @ 1080p).  Since round 3 the persistent kernels are
- * compiled only with `make EXTRA=-DVPT_WITH_PERSISTENT_KERNELS`; the default build accepts 0 and refuses other values
- * (VPT_ERR_UNSUPPORTED). */
+ * (measured slower on MI355X at extinction 1..200 for 512^3 @ 1080p, DESIGN.md section 5: an option, never the default).  One-channel
+ * byte volumes; other formats run the default kernels whatever the option says. */
 #define VPT_OPTION_MCS_PERSISTENT 0
 /* VPT_OPTION_MCM_PERSISTENT (default 0): 1 = run the MCM integrate pass as persistent waves walking several 8x8-pixel
  * segments (LDS tables staged once per workgroup), 2 = the same with the next segment's photon state prefetched under
- * the current segment's events.  Measured 4-8 % slower than one workgroup per tile (register pressure); same build flag. */
+ * the current segment's events.  Measured 4-8 % slower than one workgroup per tile (register pressure). */
 #define VPT_OPTION_MCM_PERSISTENT 1
 /* VPT_OPTION_FAST_MATH (default 0; MCM renderer): 1 = run the integrate pass with the arithmetic a GPU driver gives GLSL
  * (v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 / v_log_f32 / v_sin_f32 / v_cos_f32, and algebraically equal shorter forms) instead of

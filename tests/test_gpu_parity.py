@@ -235,12 +235,7 @@ def test_mcs_parity(gpu_ctx, oracle, fused, env, persistent):
     e = env_map(*env) if env else None
     sc = Scene(gpu_ctx, oracle, 40, 160, 96, tf=colour_tf(256, 1), env=e, camera=orbit_camera(160 / 96))
     r = sc.renderer('mcs', fused=fused)
-    try:
-        r.set_option(N.OPTION_MCS_PERSISTENT, persistent)
-    except vpt_amd.VptError as err:                     # the default build has no persistent-wave kernels (make EXTRA=-DVPT_WITH_PERSISTENT_KERNELS)
-        assert persistent and err.code == N.ERR_UNSUPPORTED
-        r.destroy(); sc.gvol.destroy()
-        pytest.skip("persistent-wave kernels are not part of this build")
+    r.set_option(N.OPTION_MCS_PERSISTENT, persistent)
     r.extinction = 12
     o = oracle.OracleRenderer('mcs', sc.osc, sc.w, sc.h)
     r.reset(); o.reset(oracle.make_frame(sc.w, sc.h, sc.m))
@@ -267,12 +262,7 @@ def test_mcm_parity(gpu_ctx, oracle, fused, g, env, ext, persistent):
     e = env_map(*env) if env else None
     sc = Scene(gpu_ctx, oracle, 40, 144, 80, tf=colour_tf(256, 1), env=e, camera=orbit_camera(144 / 80))
     r = sc.renderer('mcm', fused=fused)
-    try:
-        r.set_option(N.OPTION_MCM_PERSISTENT, persistent)
-    except vpt_amd.VptError as err:
-        assert persistent and err.code == N.ERR_UNSUPPORTED
-        r.destroy(); sc.gvol.destroy()
-        pytest.skip("persistent-wave kernels are not part of this build")
+    r.set_option(N.OPTION_MCM_PERSISTENT, persistent)
     r.extinction = ext; r.anisotropy = g; r.bounces = 3; r.steps = 6
     o = oracle.OracleRenderer('mcm', sc.osc, sc.w, sc.h)
     r.reset()

@@ -23,6 +23,7 @@ ap.add_argument("--shard", default="", help="rank,world,rows: time one rank's sh
 ap.add_argument("--renderer", default="mcm")
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--hit-form", type=int, default=0, help="1 / 2: force a form of the HIT-tile kernel (VPT_HIT_KERNEL_FORM in the environment of the renderer's creation)")
+ap.add_argument("--persistent", type=int, default=0, help="VPT_OPTION_MCS_PERSISTENT / VPT_OPTION_MCM_PERSISTENT (the renderer's): the persistent-wave kernel forms")
 ap.add_argument("--records", type=int, default=-1, help="VPT_OPTION_COLUMN_RECORDS (MCM): 0 / 1; -1 = the library's default")
 ap.add_argument("--camera-z", type=float, default=2.0, help="z of the default camera's translation (0.9: the volume fills the frame, every tile is a HIT tile)")
 ap.add_argument("--extinction", type=float, default=0.0)
@@ -94,6 +95,8 @@ try:
     r.set_option(N.OPTION_TILE_CLASSES, args.classes)
 except vpt_amd.VptError:
     pass                                              # a build from before the option existed
+if args.persistent and args.renderer in ("mcs", "mcm"):
+    r.set_option(N.OPTION_MCS_PERSISTENT if args.renderer == "mcs" else N.OPTION_MCM_PERSISTENT, args.persistent)
 if args.records >= 0 and args.renderer == "mcm":
     r.set_option(N.OPTION_COLUMN_RECORDS, args.records)
 if args.split >= 1:                                   # 0: the library's own default
@@ -140,5 +143,5 @@ samples = W * H * args.steps if not args.shard else None
 print("%-28s fast %d split %d classes %d%s: median %7.2f us  min %7.2f  max %7.2f%s" % (
     (args.tag or os.path.basename(args.lib) or "in-tree") + (" dummies %d" % args.dummy_contexts if args.dummy_contexts else "") + (" hit-form %d" % args.hit_form if args.hit_form else ""), args.fast, args.split, args.classes, (" shard " + args.shard) if args.shard else "",
     med, blocks[0], blocks[-1], ("  frac %.3f" % (24.0 * samples / (med * 1e-6) / 8e12)) if samples and args.renderer == "mcm" else "") +
-    (" records %d" % args.records if args.records >= 0 else "") + extra, flush=True)
+    (" records %d" % args.records if args.records >= 0 else "") + (" persistent %d" % args.persistent if args.persistent else "") + extra, flush=True)
 r.destroy(); gvol.destroy(); ctx.destroy()

@@ -953,15 +953,9 @@ extern "C" int vpt_renderer_set_lao_params(vpt_renderer *r, const struct vpt_lao
 extern "C" int vpt_renderer_set_option(vpt_renderer *r, int option, int value) {
     if (!r) return fail(VPT_ERR_INVALID, "renderer is null");
     switch (option) {
-#ifdef VPT_WITH_PERSISTENT_KERNELS
         // (the persistent kernels walk every tile from the context's stream: ranges of earlier split passes must be in first)
         case VPT_OPTION_MCS_PERSISTENT: VPT_TRY(join_side(r)); r->mcs_persistent = value != 0; return VPT_OK;
         case VPT_OPTION_MCM_PERSISTENT: VPT_TRY(join_side(r)); r->mcm_persistent = value < 0 ? 0 : (value > 2 ? 2 : value); return VPT_OK;
-#else
-        case VPT_OPTION_MCS_PERSISTENT: case VPT_OPTION_MCM_PERSISTENT:
-            if (value == 0) return VPT_OK;
-            return fail(VPT_ERR_UNSUPPORTED, "the persistent-wave kernels (measured slower, DESIGN.md section 5) are not part of this build: make EXTRA=-DVPT_WITH_PERSISTENT_KERNELS");
-#endif
         case VPT_OPTION_BOUNDARY_ATLAS: r->boundary_atlas = value != 0; return VPT_OK;
         case VPT_OPTION_SPLIT_STREAMS:
             if (r->kind == VPT_RENDERER_DOS) return fail(VPT_ERR_UNSUPPORTED, "VPT_OPTION_SPLIT_STREAMS: the DOS renderer's slices depend on each other across pixels");

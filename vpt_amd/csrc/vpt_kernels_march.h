@@ -275,7 +275,6 @@ __global__ void __launch_bounds__(VPT_BLOCK) VPT_WAVES_ATTR(VPT_MCS_WAVES) k_mcs
     }
     count_samples(a.samples, ns);
 }
-#ifdef VPT_WITH_PERSISTENT_KERNELS   // measured-slower alternatives, not in the default build: make EXTRA=-DVPT_WITH_PERSISTENT_KERNELS
 // ---- persistent-wave MCS with active-ray compaction ------------------------------------------------------------
 // The tracking loops of MCSRenderer.glsl:70-105 have data-dependent lengths (0 .. extinction * chord events), so in the
 // one-thread-per-pixel kernel above finished lanes idle until the longest ray of their wave ends and whole workgroups
@@ -427,7 +426,6 @@ __global__ void __launch_bounds__(VPT_BLOCK) k_mcs_persist(PassArgs a, uint32_t 
     }
     count_samples(a.samples, ns);
 }
-#endif
 __global__ void __launch_bounds__(VPT_BLOCK) k_mcs_integrate(PassArgs a) {
     Pix p = map_pixel(a.pm);
     if (!p.valid) return;

@@ -462,7 +462,6 @@ VPT_DEV void photon_store(const PassArgs &a, int k, const Photon &ph) {       //
     a.st3[k] = make_float4(ph.radiance.x, ph.radiance.y, ph.radiance.z, (float)ph.samples);
 }
 
-#ifdef VPT_WITH_PERSISTENT_KERNELS
 // Persistent form of the integrate pass: every wave walks several 8x8-pixel segments of the tile-ordered state arrays
 // (segment g = lanes [64g, 64g+64)) and loads the NEXT segment's photon state (4 x dwordx4 per lane) before it starts the
 // current segment's events; LDS tables are staged once per workgroup instead of once per tile.  Measured (512^3, 1080p,
@@ -505,7 +504,6 @@ __global__ void __launch_bounds__(VPT_BLOCK) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-#endif
 
 #ifndef VPT_MCM_RG_WAVES
 #define VPT_MCM_RG_WAVES 6

@@ -16,7 +16,6 @@
 #define K_MCS1(V) (k_mcs<1, V | VPT_MCS_TAPS>)
 #define LAUNCH(kernel, r, a, lds) hipLaunchKernelGGL(kernel, tile_grid(r), dim3(VPT_BLOCK), (lds), (r)->ctx->stream, (a))
 
-#ifdef VPT_WITH_PERSISTENT_KERNELS
 template <typename K>
 static int launch_mcs_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
     size_t lds = lds_bytes(r);
@@ -40,7 +39,6 @@ static int launch_mcs_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
         default: VPT_TRY(launch_mcs_persist((k_mcs_persist<MODE, 3>), (r), (a))); break; \
     } } while (0)
 
-#endif
 
 int march_reset(vpt_renderer *r, const PassArgs &a) {
     switch (r->kind) {
@@ -51,12 +49,10 @@ int march_reset(vpt_renderer *r, const PassArgs &a) {
     return VPT_OK;
 }
 static int launch_mcs(vpt_renderer *r, const PassArgs &a, bool fused) {
-#ifdef VPT_WITH_PERSISTENT_KERNELS
     if (r->mcs_persistent && r->vol->channels == 1 && !r->vol->f32) {       // (walks every tile)
         if (fused) LAUNCH_MCS_PERSIST(1, r, a); else LAUNCH_MCS_PERSIST(0, r, a);
         return VPT_OK;
     }
-#endif
     if (fused) LAUNCH_S(K_MCS1, r, a); else LAUNCH_S(K_MCS0, r, a);
     return VPT_OK;
 }

@@ -228,7 +228,6 @@ int mcm_bucket(vpt_renderer *r, const PassArgs &a, const FrameVar *v, int count,
     return VPT_OK;
 }
 
-#ifdef VPT_WITH_PERSISTENT_KERNELS
 // persistent MCM: as many workgroups as are resident at once (occupancy query x CUs), never more than there are segments
 template <typename K>
 static int launch_mcm_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
@@ -254,7 +253,6 @@ static int launch_mcm_persist(K kernel, vpt_renderer *r, const PassArgs &a) {
         case 2: VPT_TRY((r)->mcm_persistent == 2 ? launch_mcm_persist((k_mcm_persist<FUSE, 2, true>), (r), (a)) : launch_mcm_persist((k_mcm_persist<FUSE, 2, false>), (r), (a))); break; \
         default: VPT_TRY(launch_mcm_persist((k_mcm_persist<FUSE, 3, false>), (r), (a))); break; \
     } } while (0)
-#endif
 
 // MCM passes with a matrix (or a blur) other than the reset's: the photons of MISS tiles may now enter the cube — the classes are
 // void until the next reset.  Whole-image kernels need the MISS tiles' position / transmittance arrays up to date first.
@@ -276,9 +274,7 @@ static int launch_mcm_pass(vpt_renderer *r, const PassArgs &a) {
     if (two_streams) VPT_TRY(ensure_split_streams(r));
     if (same && r->cls.enabled && mcm_classes_runnable(r, a) && (two_streams || r->cls.one_stream)) return launch_mcm_classes<FUSE>(r, a);
     VPT_TRY(mcm_materialize(r));
-#ifdef VPT_WITH_PERSISTENT_KERNELS
     if (r->mcm_persistent && r->vol->channels == 1 && !r->vol->f32) { LAUNCH_MCM_PERSIST(FUSE, r, a); return VPT_OK; }
-#endif
     return mcm_general_pass(r, a, FUSE);
 }
 
