@@ -106,6 +106,11 @@ def parse():
     ap.add_argument("--bucket-form", type=int, default=1,
                     help="N > 1: 1 = after the line's measurement, measure the torch.distributed pipeline once more with VPT_OPTION_BUCKET_KERNEL and report "
                          "it beside the line (config.bucket_kernel_form); never the line's `value` unless --bucket-kernel 1")
+    ap.add_argument("--cadence-form", type=int, default=16,
+                    help="N > 1, MCM: D > 0 = measure once more with the frame gathered at a DISPLAY CADENCE: D passes accumulate on every rank by one launch "
+                         "per tile class (VPT_PLAY_FUSED) and only the D-th frame is gathered (RGBA16F all_gather) - what a progressive renderer that shows "
+                         "every D-th pass needs from xGMI: 1 / D of the line's bytes per pass.  Reported beside the line (config.display_cadence_form) with the "
+                         "single-GPU figure of the same form; never the line's `value`; 0 = skip")
     ap.add_argument("--frames-per-gather", type=int, default=16,
                     help="torch.distributed pipeline: frames per all_gather (every frame is delivered, at most F - 1 frames later; one async "
                          "collective costs the host ~25 us whatever its size and a bucket's launches ~10 us per frame, against the ~17 us a "
@@ -714,6 +719,12 @@ def main():
                 line["config"]["speedup_like_for_like"] = ratios
             if state.get("display_form"):
                 line["config"]["display_gather_form"] = state["display_form"]
+            if state.get("cadence_form"):
+                line["config"]["display_cadence_form"] = state["cadence_form"]
+                sg = state.get("single_gpu")
+                if sg and sg.get("display_cadence_ms_per_pass"):
+                    line["config"].setdefault("speedup_like_for_like", {})["display_cadence_form_vs_single_gpu_same_form"] = (
+                        sg["display_cadence_ms_per_pass"] / state["cadence_form"]["ms_per_pass"])
             return line
         state["make_line"] = make_line
 
@@ -1009,12 +1020,76 @@ def main():
                     whole.play(16, frames=True)
                 ctx.synchronize()
                 bucket = (time.perf_counter() - t0) / (12 * 16)
+                cadence = None
+                if args.cadence_form > 0:
+                    for _ in range(4):
+                        whole.play(args.cadence_form, fused=True)
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(12):
+                        whole.play(args.cadence_form, fused=True)
+                    ctx.synchronize()
+                    cadence = (time.perf_counter() - t0) / (12 * args.cadence_form) * 1e3
                 whole.destroy()
                 ref = {"frame_by_frame_ms": frame_by_frame * 1e3, "bucket_kernels_16_frames_per_launch_ms": bucket * 1e3,
+                       "display_cadence_ms_per_pass": cadence,
                        "what": "the whole %dx%d frame on rank 0's GPU alone, same library and options, measured in this run after the timed regions" % (W, H)}
             if use_dist:
                 dist.barrier()
             state["single_gpu"] = ref
+
+        def measure_cadence_form():
+            """the frame gathered at a display cadence: D passes per launch on every rank (VPT_PLAY_FUSED: same buffers as D x render()), the D-th frame
+            all_gathered; per pass; the gathered frame bit-compared with the same passes unsharded.  Beside the line, never its value."""
+            D = int(args.cadence_form)
+            drain(); torch.cuda.synchronize()
+            g1 = FrameGather(dist, torch, W, H, device, always_collective=bool(args.force_dist), frames_per_gather=1)
+            rounds = max(2, (args.steps + D - 1) // D)
+
+            def shown_frames(n):
+                for _ in range(n):
+                    t_ = g1.acquire()
+                    r.set_render_target(t_.data_ptr(), nbytes)
+                    r.play(D, fused=True)                       # D passes, one launch per tile class, the last frame into the slot
+                    r.join()                                    # both streams in front of the collective
+                    g1.commit()
+                frames_done[0] += n * D
+            shown_frames(4 if args.rehearsal else 16)
+            g1.wait_all(); torch.cuda.synchronize()
+            blocks = []
+            for rep in range(max(1, args.repeats)):
+                dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                shown_frames(rounds)
+                g1.wait_all(); torch.cuda.synchronize()
+                dist.barrier(); torch.cuda.synchronize()
+                blocks.append(time.perf_counter() - t0)
+            tb = torch.tensor(blocks, dtype=torch.float64, device=device)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            dt = sorted(float(x) for x in tb)[len(blocks) // 2]
+            ok = None
+            if args.check:
+                frame = g1.last_frame()
+                r.set_render_target(0, 0)
+                o2 = {'resolution': (W, H), 'transform': transform, 'rng': GoldenRatioRng(), 'fused': bool(args.fused)}
+                whole = vpt_amd.RendererFactory(args.renderer)(ctx, gvol, camera, None, o2)
+                if args.extinction is not None:
+                    whole.extinction = args.extinction
+                whole.set_option(N.OPTION_FAST_MATH, int(bool(args.fast_math)))
+                whole.set_option(N.OPTION_BOUNDARY_ATLAS, int(bool(args.boundary_atlas)))
+                whole.reset()
+                for _ in range(frames_done[0]):
+                    whole.render()
+                ok = bool((whole.getTexture().view(np.uint16) == frame.cpu().numpy().view(np.uint16)).all())
+                whole.destroy()
+            r.set_render_target(0, 0)
+            torch.cuda.synchronize()
+            state["cadence_form"] = {
+                "passes_per_shown_frame": D, "ms_per_pass": dt / (rounds * D) * 1e3, "value": float(W) * H * 8 * rounds * D / dt,
+                "bytes_per_pass_and_xgmi_link": int(W * gather.rows * 8 // D), "frame_check": ok,
+                "what": "every %d-th frame gathered (RGBA16F all_gather), the passes between accumulate on the owning rank by one launch per tile class "
+                        "(VPT_PLAY_FUSED); the gathered frame is checked against the same passes rendered unsharded.  Not the line's `value`: the line "
+                        "gathers every pass" % D}
 
         def measure_display_form():
             """the torch.distributed pipeline gathering the frames as the default tone mapper shows them (RGBA8): beside the line, never its value"""
@@ -1055,6 +1130,8 @@ def main():
                 measure_bucket_form()
             if args.display_form and bucket_capable:
                 measure_display_form()
+            if args.cadence_form > 0 and bucket_capable:
+                measure_cadence_form()
             deadline = threading.Timer(args.native_deadline, _native_gave_up)
             deadline.daemon = True
             deadline.start()
@@ -1071,6 +1148,10 @@ def main():
             if args.display_form and bucket_capable and not use_native[0]:
                 state["fallback"] = results[0]
                 measure_display_form()
+                state["fallback"] = None
+            if args.cadence_form > 0 and bucket_capable and not use_native[0]:
+                state["fallback"] = results[0]
+                measure_cadence_form()
                 state["fallback"] = None
         if rank == 0 and world == 1 and not use_dist and args.kernels_alone and args.renderer == "mcm" and args.tile_classes and args.fused:
             # after the timed region and its frame check: the two class kernels one after the other on ONE stream, HIP events around the pass and

@@ -65,6 +65,7 @@ def test_torch_pipeline_on_one_rank_frame_by_frame_and_with_bucket_kernels():
     d = line["config"]["display_gather_form"]                    # ... and gathering the tone-mapped RGBA8 frames (vpt_renderer_play_into_display)
     assert d["frame_check"] is True and d["bucket_launches"] >= (1000 + 2 * 32) // 16
     assert d["bytes_per_frame_and_xgmi_link"] == 640 * 368 * 4
+    assert line["config"]["display_cadence_form"]["frame_check"] is True
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -100,5 +101,8 @@ def test_bench_rehearsal_with_several_ranks_on_one_gpu(world):
     assert line["config"]["frames_per_gather"] == 16
     assert line["config"]["bucket_kernel_form"]["frame_check"] is True
     assert line["config"]["display_gather_form"]["frame_check"] is True
+    c = line["config"]["display_cadence_form"]                      # 16 passes per launch on every rank, the 16th frame gathered
+    assert c["frame_check"] is True and c["passes_per_shown_frame"] == 16
     assert line["config"]["single_gpu_reference"]["frame_by_frame_ms"] > 0
+    assert line["config"]["speedup_like_for_like"]["display_cadence_form_vs_single_gpu_same_form"] > 0
     assert 640 * 368 * 8 <= line["config"]["samples_per_step"] <= 640 * (368 + 8 * world) * 8      # every pixel of the frame (+ at most one padding block per rank)
